@@ -1,0 +1,221 @@
+/*
+ * mi_cv.h -- C ABI of the MI355X-native per-pixel CV kernel library (libmicv.so).
+ *
+ * Drop-in boundary for the cv::Mat-in / cv::Mat-out functions of
+ * tanmaniac/IntroToComputerVision (paths below are relative to that repository).
+ * Every entry point replaces one reference function; the header-only C++ shim in
+ * introtocomputervision_amd/shim/micv_shim.hpp puts the reference's namespaces and
+ * signatures (lk::, pyr::, harris::, sift::, cuda::, serial::) on top of these calls.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no C++ / torch / OpenCV types.
+ *   - images are row-major, single channel; `*_stride` is the row pitch in BYTES
+ *     (cv::Mat::step), must be a multiple of the element size.
+ *   - `_dev` functions take DEVICE pointers, enqueue on `stream` (a hipStream_t, NULL =
+ *     default stream) and do not synchronise; `_host` functions take HOST pointers, do
+ *     H2D / D2H themselves and return after the result is in host memory (this is the
+ *     behaviour of the reference's functions, which upload/download inside every call).
+ *   - return value: MICV_OK (0) or a negative MICV_E* code; micv_last_error() returns a
+ *     thread-local message.  Nothing calls exit() (the reference's checkCudaErrors does,
+ *     common/include/common/CudaCommon.cuh:13-22).
+ *   - a micv_ctx owns the device ordinal and a scratch arena that is reused between
+ *     calls; use one ctx per host thread / stream (the reference's functions are not
+ *     re-entrant either: global texture references, Harris.cu:28-31).
+ */
+#ifndef MI_CV_H
+#define MI_CV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MICV_OK            0
+#define MICV_EINVAL       -1   /* bad argument (size, stride, window, null pointer) */
+#define MICV_EHIP         -2   /* HIP runtime error (message has hipGetErrorString) */
+#define MICV_ENOMEM       -3   /* device allocation failed */
+#define MICV_EUNSUPPORTED -4   /* valid in the reference but not implemented here */
+
+typedef struct micv_ctx micv_ctx;
+typedef void *micv_stream; /* hipStream_t */
+
+const char *micv_version(void);
+const char *micv_last_error(void);
+
+int micv_ctx_create(int device, micv_ctx **out);
+void micv_ctx_destroy(micv_ctx *ctx);
+/* Bytes of device scratch currently held by the context. */
+size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
+
+/* ---------------------------------------------------------------- common/ (a17) ---- */
+/* common::warmup, common/src/CudaWarmup.cu:5-19 (10 blocks x 64 threads). */
+int micv_warmup(micv_ctx *ctx, micv_stream stream);
+/* common::divRoundUp, common/include/common/Utils.h:12-15: max(1, ceil(float(n)/float(d))). */
+size_t micv_div_round_up(size_t num, size_t denom);
+/* GpuTimer, common/include/common/GpuTimer.h:5-22 (event pair; stop() synchronises). */
+typedef struct micv_timer micv_timer;
+int micv_timer_create(micv_timer **out);
+int micv_timer_start(micv_timer *t, micv_stream stream);
+int micv_timer_stop(micv_timer *t, micv_stream stream);
+int micv_timer_elapsed_ms(micv_timer *t, float *ms);
+void micv_timer_destroy(micv_timer *t);
+
+/* Per-launch timing of the pyramid-level kernels: the reference wraps every kernel launch in
+ * a GpuTimer and logs "<kernel> took {} ms" (Pyramids.cu:61-69, Harris.cu:144-155); this is the
+ * same measurement without the log.  While enabled, micv_lk_flow_pyr*_dev brackets each
+ * pyramid level's launch(es) with an event pair on the caller's stream.
+ * micv_profile_lk_level synchronises on those events and returns their summed duration. */
+int micv_profile_enable(micv_ctx *ctx, int on);
+int micv_profile_reset(micv_ctx *ctx);
+int micv_profile_lk_level(micv_ctx *ctx, int level, double *total_ms, int64_t *launches);
+
+/* --------------------------------------------------------- ps5: LK + pyramids ------ */
+
+/* lk::calcOpticalFlowPyr, ps5_cpp/lib/OpticalFlow.cpp:122-167 (a1).  `levels` replaces
+ * the hard-coded pyrDepth = 4 (:127).  Inputs are single-channel f32 (grey); u, v are
+ * rows x cols f32.  win odd, 1..63. */
+int micv_lk_flow_pyr_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                         size_t stride, int win, int levels, float *u, float *v, size_t ostride,
+                         micv_stream stream);
+int micv_lk_flow_pyr_host(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                          size_t stride, int win, int levels, float *u, float *v, size_t ostride);
+/* The same over `batch` independent frame pairs in one set of launches.  Pair i lives at
+ * prev + i*pair_stride (bytes), likewise next / u / v with opair_stride. */
+int micv_lk_flow_pyr_batch_dev(micv_ctx *ctx, const float *prev, const float *next, int batch,
+                               size_t pair_stride, int rows, int cols, size_t stride, int win,
+                               int levels, float *u, float *v, size_t opair_stride,
+                               size_t ostride, micv_stream stream);
+
+/* lk::calcOpticalFlow, OpticalFlow.cpp:41-104 (a2; includes computeGradients :12-39, a3). */
+int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                     size_t stride, int win, float *u, float *v, size_t ostride,
+                     micv_stream stream);
+int micv_lk_flow_host(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                      size_t stride, int win, float *u, float *v, size_t ostride);
+
+/* lk::warp, OpticalFlow.cpp:106-120 (a4).  src/du/dv/dst are rows x cols f32. */
+int micv_lk_warp_dev(micv_ctx *ctx, const float *src, size_t sstride, const float *du,
+                     const float *dv, size_t fstride, int rows, int cols, float *dst,
+                     size_t dstride, micv_stream stream);
+int micv_lk_warp_host(micv_ctx *ctx, const float *src, size_t sstride, const float *du,
+                      const float *dv, size_t fstride, int rows, int cols, float *dst,
+                      size_t dstride);
+
+/* pyr::pyrDown, ps5_cpp/lib/Pyramids.cu:34-73 (a5): dst is (rows/2) x (cols/2). */
+int micv_pyr_down_dev(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                      float *dst, size_t dstride, micv_stream stream);
+int micv_pyr_down_host(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                       float *dst, size_t dstride);
+/* pyr::pyrUp, Pyramids.cu:94-131 (a6): dst is (2 rows) x (2 cols). */
+int micv_pyr_up_dev(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                    float *dst, size_t dstride, micv_stream stream);
+int micv_pyr_up_host(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                     float *dst, size_t dstride);
+/* pyr::makeGaussianPyramid, ps5_cpp/lib/Pyramids.cpp:5-26 (a7).  Level 0 is a copy of the
+ * (grey f32) input; level l is (rows>>l) x (cols>>l), written densely (pitch = cols_l*4)
+ * at dst_levels[l].  All levels are produced by one launch. */
+int micv_gaussian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                              int levels, float *const *dst_levels, micv_stream stream);
+int micv_gaussian_pyramid_host(micv_ctx *ctx, const float *src, int rows, int cols,
+                               size_t sstride, int levels, float *const *dst_levels);
+/* cv::cvtColor(COLOR_RGB2GRAY) + convertTo(CV_32F) for 8-bit 3-channel input
+ * (Pyramids.cpp:10-15). */
+int micv_rgb8_to_gray_f32_dev(micv_ctx *ctx, const uint8_t *rgb, int rows, int cols,
+                              size_t sstride, float *dst, size_t dstride, micv_stream stream);
+/* cv::resize(..., INTER_LINEAR) on f32 as used at OpticalFlow.cpp:149-150. */
+int micv_resize_linear_dev(micv_ctx *ctx, const float *src, int srows, int scols, size_t sstride,
+                           float *dst, int drows, int dcols, size_t dstride, micv_stream stream);
+
+/* ------------------------------------------------------------- ps4: Harris --------- */
+
+/* harris::getGradients, ps4_cpp/lib/Harris.cpp:14-41 (a8) and computeGradients,
+ * OpticalFlow.cpp:12-39 (a3): Sobel pair, ksize in {1,3,5,7}, scale folded into the
+ * smoothing taps (1 for Harris, 1/9 for LK). */
+int micv_sobel_dev(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride, int ksize,
+                   float scale, float *gx, float *gy, size_t gstride, micv_stream stream);
+int micv_sobel_host(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                    int ksize, float scale, float *gx, float *gy, size_t gstride);
+
+/* harris::{cpu,gpu}::getCornerResponse, Harris.cpp:43-97 / Harris.cu:96-159 (a9). */
+int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                             size_t gstride, int win, double sigma, float alpha, float *resp,
+                             size_t rstride, micv_stream stream);
+int micv_harris_response_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                              size_t gstride, int win, double sigma, float alpha, float *resp,
+                              size_t rstride);
+/* harris::{cpu,gpu}::refineCorners, Harris.cpp:99-147 / Harris.cu:243-329 (a10).
+ * corners: rows x cols f32, zero except kept maxima.  locs_yx: capacity `cap` (y,x) int32
+ * pairs, filled in row-major order; *count receives the number found (may exceed cap).
+ * The _dev flavour leaves count/locs in device memory. */
+int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,
+                           double threshold, int min_distance, float *corners, size_t cstride,
+                           int32_t *locs_yx, int64_t cap, int64_t *count, micv_stream stream);
+int micv_harris_refine_host(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,
+                            double threshold, int min_distance, float *corners, size_t cstride,
+                            int32_t *locs_yx, int64_t cap, int64_t *count);
+/* sift::getAnglesFromGradients, ps4_cpp/lib/Descriptors.cpp:7-25 (a11). */
+int micv_sift_angles_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                         size_t gstride, float *angles, size_t astride, micv_stream stream);
+int micv_sift_angles_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                          size_t gstride, float *angles, size_t astride);
+/* sift::getKeypoints, Descriptors.cpp:27-47 (a11): kp_xysa is [n][4] = x, y, size, angle. */
+int micv_sift_keypoints_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                            size_t gstride, const int32_t *locs_yx, int64_t n, float size,
+                            float *kp_xysa, micv_stream stream);
+int micv_sift_keypoints_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                             size_t gstride, const int32_t *locs_yx, int64_t n, float size,
+                             float *kp_xysa);
+
+/* ------------------------------------------------------------- ps2: stereo --------- */
+
+#define MICV_STEREO_COLS_2R     1 /* window of (2r+1) rows x 2r columns, DisparitySSD.cu:84 */
+#define MICV_STEREO_MIN_SSD_5E6 2 /* leave -1 where best SSD >= 5e6, DisparitySSD.cu:16 */
+
+/* cuda::disparitySSD, ps2_cpp/lib/DisparitySSD.cu:143-207 (a12).  disp is rows x cols int8. */
+int micv_disparity_ssd_dev(micv_ctx *ctx, const float *left, const float *right, int rows,
+                           int cols, size_t stride, int window_rad, int min_disparity,
+                           int max_disparity, int flags, int8_t *disp, size_t dstride,
+                           micv_stream stream);
+int micv_disparity_ssd_host(micv_ctx *ctx, const float *left, const float *right, int rows,
+                            int cols, size_t stride, int window_rad, int min_disparity,
+                            int max_disparity, int flags, int8_t *disp, size_t dstride);
+/* cuda::disparityNCorr, ps2_cpp/lib/DisparityNCorr.cu:177-251 (a13). */
+int micv_disparity_ncorr_dev(micv_ctx *ctx, const float *left, const float *right, int rows,
+                             int cols, size_t stride, int window_rad, int min_disparity,
+                             int max_disparity, int flags, int8_t *disp, size_t dstride,
+                             micv_stream stream);
+int micv_disparity_ncorr_host(micv_ctx *ctx, const float *left, const float *right, int rows,
+                              int cols, size_t stride, int window_rad, int min_disparity,
+                              int max_disparity, int flags, int8_t *disp, size_t dstride);
+
+/* -------------------------------------------------------------- ps1: Hough --------- */
+
+/* Accumulator shape of cuda::houghLinesAccumulate, ps1_cpp/src/Hough.cu:258-263. */
+int micv_hough_lines_dims(int rows, int cols, unsigned rho_bin, unsigned theta_bin,
+                          int *rho_bins, int *theta_bins);
+/* cuda::houghLinesAccumulate, Hough.cu:251-309 (a14): mask u8 -> acc i32 [rho_bins x theta_bins]
+ * (dense, zeroed here). */
+int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
+                         unsigned rho_bin, unsigned theta_bin, int32_t *acc, micv_stream stream);
+int micv_hough_lines_host(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
+                          unsigned rho_bin, unsigned theta_bin, int32_t *acc);
+/* cuda::houghCirclesAccumulate, Hough.cu:311-364 (a15): acc i32 [rows x cols] (dense, zeroed
+ * here -- the reference forgets to, Hough.cu:318). */
+int micv_hough_circles_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
+                           unsigned radius, int32_t *acc, micv_stream stream);
+int micv_hough_circles_host(micv_ctx *ctx, const uint8_t *mask, int rows, int cols,
+                            size_t mstride, unsigned radius, int32_t *acc);
+/* cuda::findLocalMaxima, Hough.cu:366-426 (a16): peaks_rc receives up to num_peaks (row,col)
+ * pairs ordered by votes descending (stable); *count = number written. */
+int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
+                         unsigned num_peaks, int threshold, uint32_t *peaks_rc, int64_t *count,
+                         micv_stream stream);
+int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
+                          unsigned num_peaks, int threshold, uint32_t *peaks_rc, int64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_CV_H */

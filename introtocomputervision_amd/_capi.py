@@ -1,0 +1,188 @@
+"""ctypes binding of libmicv.so (the C ABI in include/mi_cv.h).
+
+Fails loudly (ImportError) when the HIP library is missing: there is no CPU fallback in the
+product path.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``bash introtocomputervision_amd/csrc/build.sh``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmicv.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP extension has not been built "
+        "(run `bash introtocomputervision_amd/csrc/build.sh`). There is no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+sz = C.c_size_t
+i32 = C.c_int
+i64 = C.c_int64
+u32 = C.c_uint
+f32 = C.c_float
+f64 = C.c_double
+
+OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
+STEREO_COLS_2R, STEREO_MIN_SSD_5E6 = 1, 2
+
+
+class MicvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"micv error {code}: {msg}")
+        self.code = code
+
+
+# name -> (restype, argtypes).  Every symbol include/mi_cv.h declares appears here; the
+# CPU test-suite checks the two lists against each other.
+SIGNATURES = {
+    "micv_version": (C.c_char_p, []),
+    "micv_last_error": (C.c_char_p, []),
+    "micv_ctx_create": (i32, [i32, C.POINTER(vp)]),
+    "micv_ctx_destroy": (None, [vp]),
+    "micv_ctx_scratch_bytes": (sz, [vp]),
+    "micv_profile_enable": (i32, [vp, i32]),
+    "micv_profile_reset": (i32, [vp]),
+    "micv_profile_lk_level": (i32, [vp, i32, C.POINTER(f64), C.POINTER(i64)]),
+    "micv_warmup": (i32, [vp, vp]),
+    "micv_div_round_up": (sz, [sz, sz]),
+    "micv_timer_create": (i32, [C.POINTER(vp)]),
+    "micv_timer_start": (i32, [vp, vp]),
+    "micv_timer_stop": (i32, [vp, vp]),
+    "micv_timer_elapsed_ms": (i32, [vp, C.POINTER(f32)]),
+    "micv_timer_destroy": (None, [vp]),
+    # ps5
+    "micv_lk_flow_pyr_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz, vp]),
+    "micv_lk_flow_pyr_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz]),
+    "micv_lk_flow_pyr_batch_dev": (i32, [vp, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
+    "micv_lk_flow_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, vp, vp, sz, vp]),
+    "micv_lk_flow_host": (i32, [vp, vp, vp, i32, i32, sz, i32, vp, vp, sz]),
+    "micv_lk_warp_dev": (i32, [vp, vp, sz, vp, vp, sz, i32, i32, vp, sz, vp]),
+    "micv_lk_warp_host": (i32, [vp, vp, sz, vp, vp, sz, i32, i32, vp, sz]),
+    "micv_pyr_down_dev": (i32, [vp, vp, i32, i32, sz, vp, sz, vp]),
+    "micv_pyr_down_host": (i32, [vp, vp, i32, i32, sz, vp, sz]),
+    "micv_pyr_up_dev": (i32, [vp, vp, i32, i32, sz, vp, sz, vp]),
+    "micv_pyr_up_host": (i32, [vp, vp, i32, i32, sz, vp, sz]),
+    "micv_gaussian_pyramid_dev": (i32, [vp, vp, i32, i32, sz, i32, C.POINTER(vp), vp]),
+    "micv_gaussian_pyramid_host": (i32, [vp, vp, i32, i32, sz, i32, C.POINTER(vp)]),
+    "micv_rgb8_to_gray_f32_dev": (i32, [vp, vp, i32, i32, sz, vp, sz, vp]),
+    "micv_resize_linear_dev": (i32, [vp, vp, i32, i32, sz, vp, i32, i32, sz, vp]),
+    # ps4
+    "micv_sobel_dev": (i32, [vp, vp, i32, i32, sz, i32, f32, vp, vp, sz, vp]),
+    "micv_sobel_host": (i32, [vp, vp, i32, i32, sz, i32, f32, vp, vp, sz]),
+    "micv_harris_response_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, vp, sz, vp]),
+    "micv_harris_response_host": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, vp, sz]),
+    "micv_harris_refine_dev": (i32, [vp, vp, i32, i32, sz, f64, i32, vp, sz, vp, i64, vp, vp]),
+    "micv_harris_refine_host": (i32, [vp, vp, i32, i32, sz, f64, i32, vp, sz, vp, i64, vp]),
+    "micv_sift_angles_dev": (i32, [vp, vp, vp, i32, i32, sz, vp, sz, vp]),
+    "micv_sift_angles_host": (i32, [vp, vp, vp, i32, i32, sz, vp, sz]),
+    "micv_sift_keypoints_dev": (i32, [vp, vp, vp, i32, i32, sz, vp, i64, f32, vp, vp]),
+    "micv_sift_keypoints_host": (i32, [vp, vp, vp, i32, i32, sz, vp, i64, f32, vp]),
+    # ps2
+    "micv_disparity_ssd_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp]),
+    "micv_disparity_ssd_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz]),
+    "micv_disparity_ncorr_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp]),
+    "micv_disparity_ncorr_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz]),
+    # ps1
+    "micv_hough_lines_dims": (i32, [i32, i32, u32, u32, C.POINTER(i32), C.POINTER(i32)]),
+    "micv_hough_lines_dev": (i32, [vp, vp, i32, i32, sz, u32, u32, vp, vp]),
+    "micv_hough_lines_host": (i32, [vp, vp, i32, i32, sz, u32, u32, vp]),
+    "micv_hough_circles_dev": (i32, [vp, vp, i32, i32, sz, u32, vp, vp]),
+    "micv_hough_circles_host": (i32, [vp, vp, i32, i32, sz, u32, vp]),
+    "micv_hough_peaks_dev": (i32, [vp, vp, i32, i32, u32, i32, vp, vp, vp]),
+    "micv_hough_peaks_host": (i32, [vp, vp, i32, i32, u32, i32, vp, vp]),
+}
+
+MISSING = []
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError:
+        MISSING.append(_name)
+        continue
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error():
+    return lib.micv_last_error().decode()
+
+
+def check(rc):
+    if rc != OK:
+        raise MicvError(rc, last_error())
+
+
+class Context:
+    """Owns a micv_ctx (device ordinal + scratch arena). One per host thread / stream."""
+
+    def __init__(self, device=0):
+        h = vp()
+        check(lib.micv_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def scratch_bytes(self):
+        return int(lib.micv_ctx_scratch_bytes(self._h))
+
+    def profile(self, on=True):
+        check(lib.micv_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib.micv_profile_reset(self._h))
+
+    def profile_lk_level(self, level):
+        """(total_ms, launches) of pyramid level `level` since the last reset."""
+        ms, n = f64(), i64()
+        check(lib.micv_profile_lk_level(self._h, int(level), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def warmup(self, stream=None):
+        check(lib.micv_warmup(self._h, stream))
+
+    def close(self):
+        if self._h:
+            lib.micv_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Timer:
+    """GpuTimer (common/include/common/GpuTimer.h): hipEvent pair on a stream."""
+
+    def __init__(self):
+        h = vp()
+        check(lib.micv_timer_create(C.byref(h)))
+        self._h = h
+
+    def start(self, stream=None):
+        check(lib.micv_timer_start(self._h, stream))
+
+    def stop(self, stream=None):
+        check(lib.micv_timer_stop(self._h, stream))
+
+    def elapsed_ms(self):
+        ms = f32()
+        check(lib.micv_timer_elapsed_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.micv_timer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,27 @@
+#!/usr/bin/env bash
+# Builds introtocomputervision_amd/libmicv.so (gfx950 only) from csrc/*.hip.
+#   -ffp-contract=off   fused multiply-adds only where the source says fmaf() -- the
+#                       arithmetic contract that makes HIP == CPU oracle bit for bit.
+#   objects are compiled in parallel, then linked; only amdhip64 is linked (no torch).
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../libmicv.so"
+obj="$here/.obj"
+mkdir -p "$obj"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+#   -fno-gpu-flush-denormals-to-zero  keep f32 subnormals, as the host oracle does.
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math
+       -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function)
+pids=()
+objs=()
+for src in "$here"/*.hip; do
+  o="$obj/$(basename "${src%.hip}").o"
+  objs+=("$o")
+  if [[ ! -f "$o" || "$src" -nt "$o" || -n "$(find "$here" -maxdepth 1 \( -name '*.hpp' -o -name 'build.sh' \) -newer "$o" -print -quit)" || "$here/../../include/mi_cv.h" -nt "$o" ]]; then
+    "$HIPCC" "${FLAGS[@]}" ${EXTRA_HIPCC_FLAGS:-} -c "$src" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "built $out"

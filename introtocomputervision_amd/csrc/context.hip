@@ -1,0 +1,233 @@
+// context.hip -- context, errors, timer, warm-up (the common/ helpers of the reference, a17).
+#include "common.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace micv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// cv::getGaussianKernel(n, sigma, CV_32F), sigma > 0: taps evaluated in double, cast to
+// float, summed in double, normalised by 1/sum in double, cast to float.
+void gaussian_taps(int n, double sigma, Taps *out) {
+    const double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0.0;
+    out->n = n;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        out->k[i] = static_cast<float>(std::exp(scale2x * x * x));
+        sum += out->k[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; i++) out->k[i] = static_cast<float>(out->k[i] * sum);
+}
+
+// cv::getDerivKernels (normalize=false): binomial smoothing passes then `order` differences.
+int sobel_taps(int ksize, int order, Taps *out) {
+    if (ksize == 1 && order > 0) ksize = 3;
+    if (ksize < 1 || ksize > 31 || (ksize & 1) == 0 || order < 0 || order > 2) return -1;
+    int ker[40] = {0};
+    if (ksize == 1) {
+        ker[0] = 1;
+    } else if (ksize == 3) {
+        static const int k3[3][3] = {{1, 2, 1}, {-1, 0, 1}, {1, -2, 1}};
+        for (int i = 0; i < 3; i++) ker[i] = k3[order][i];
+    } else {
+        ker[0] = 1;
+        for (int pass = 0; pass < ksize - order - 1; pass++) {
+            int carry = ker[0];
+            for (int j = 1; j <= ksize; j++) {
+                const int next = ker[j] + ker[j - 1];
+                ker[j - 1] = carry;
+                carry = next;
+            }
+        }
+        for (int pass = 0; pass < order; pass++) {
+            int carry = -ker[0];
+            for (int j = 1; j <= ksize; j++) {
+                const int next = ker[j - 1] - ker[j];
+                ker[j - 1] = carry;
+                carry = next;
+            }
+        }
+    }
+    out->n = ksize;
+    for (int i = 0; i < ksize; i++) out->k[i] = static_cast<float>(ker[i]);
+    return ksize;
+}
+
+// common::warmup's kernel (CudaWarmup.cu:5-12): a little arithmetic, no memory traffic.
+__global__ void warmup_kernel() {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    float a = 1.f * tid, b = 2.f * tid;
+    asm volatile("" ::"v"(a), "v"(b));
+}
+
+}  // namespace micv
+
+int micv_ctx::reserve(size_t bytes, void **out) {
+    if (bytes > arena_bytes) {
+        MICV_HIP(hipSetDevice(device));
+        MICV_HIP(hipDeviceSynchronize());
+        if (arena) MICV_HIP(hipFree(arena));
+        arena = nullptr;
+        arena_bytes = 0;
+        const size_t want = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+        MICV_HIP(hipMalloc(&arena, want));
+        arena_bytes = want;
+    }
+    *out = arena;
+    return MICV_OK;
+}
+
+int micv_ctx::prof_begin(int level, hipStream_t s) {
+    if (!profile) return MICV_OK;
+    hipEvent_t a, b;
+    MICV_HIP(hipEventCreate(&a));
+    MICV_HIP(hipEventCreate(&b));
+    prof[level].emplace_back(a, b);
+    MICV_HIP(hipEventRecord(a, s));
+    return MICV_OK;
+}
+int micv_ctx::prof_end(int level, hipStream_t s) {
+    if (!profile) return MICV_OK;
+    MICV_HIP(hipEventRecord(prof[level].back().second, s));
+    return MICV_OK;
+}
+
+struct micv_timer {
+    hipEvent_t start, stop;
+};
+
+extern "C" {
+
+const char *micv_version(void) { return "micv 0.1 (gfx950)"; }
+const char *micv_last_error(void) { return micv::g_err; }
+
+int micv_ctx_create(int device, micv_ctx **out) {
+    MICV_REQUIRE(out != nullptr, "micv_ctx_create: out is null");
+    int n = 0;
+    MICV_HIP(hipGetDeviceCount(&n));
+    MICV_REQUIRE(device >= 0 && device < n, "micv_ctx_create: device %d out of range (%d visible)",
+                 device, n);
+    MICV_HIP(hipSetDevice(device));
+    micv_ctx *c = new (std::nothrow) micv_ctx();
+    if (!c) {
+        micv::set_error("micv_ctx_create: host allocation failed");
+        return MICV_ENOMEM;
+    }
+    c->device = device;
+    hipError_t e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        micv::set_error("hipHostMalloc failed: %s", hipGetErrorString(e));
+        delete c;
+        return MICV_EHIP;
+    }
+    *out = c;
+    return MICV_OK;
+}
+
+void micv_ctx_destroy(micv_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)micv_profile_reset(ctx);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx;
+}
+
+size_t micv_ctx_scratch_bytes(const micv_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+
+int micv_profile_enable(micv_ctx *ctx, int on) {
+    MICV_REQUIRE(ctx != nullptr, "micv_profile_enable: ctx is null");
+    ctx->profile = on != 0;
+    return MICV_OK;
+}
+
+int micv_profile_reset(micv_ctx *ctx) {
+    MICV_REQUIRE(ctx != nullptr, "micv_profile_reset: ctx is null");
+    for (auto &v : ctx->prof) {
+        for (auto &e : v) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        v.clear();
+    }
+    return MICV_OK;
+}
+
+int micv_profile_lk_level(micv_ctx *ctx, int level, double *total_ms, int64_t *launches) {
+    MICV_REQUIRE(ctx && total_ms && launches, "micv_profile_lk_level: null argument");
+    MICV_REQUIRE(level >= 0 && level < 16, "micv_profile_lk_level: bad level %d", level);
+    double sum = 0.0;
+    for (auto &e : ctx->prof[level]) {
+        MICV_HIP(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        MICV_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)ctx->prof[level].size();
+    return MICV_OK;
+}
+
+int micv_warmup(micv_ctx *ctx, micv_stream stream) {
+    MICV_REQUIRE(ctx != nullptr, "micv_warmup: ctx is null");
+    MICV_HIP(hipSetDevice(ctx->device));
+    micv::warmup_kernel<<<dim3(10), dim3(64), 0, static_cast<hipStream_t>(stream)>>>();
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+size_t micv_div_round_up(size_t num, size_t denom) {
+    // Utils.h:12-15 computes this in float on purpose-or-not; keep its rounding behaviour.
+    const float q = std::ceil(static_cast<float>(num) / static_cast<float>(denom));
+    return std::max<size_t>(1, static_cast<size_t>(q));
+}
+
+int micv_timer_create(micv_timer **out) {
+    MICV_REQUIRE(out != nullptr, "micv_timer_create: out is null");
+    micv_timer *t = new (std::nothrow) micv_timer();
+    if (!t) {
+        micv::set_error("micv_timer_create: host allocation failed");
+        return MICV_ENOMEM;
+    }
+    MICV_HIP(hipEventCreate(&t->start));
+    MICV_HIP(hipEventCreate(&t->stop));
+    *out = t;
+    return MICV_OK;
+}
+int micv_timer_start(micv_timer *t, micv_stream stream) {
+    MICV_REQUIRE(t != nullptr, "micv_timer_start: timer is null");
+    MICV_HIP(hipEventRecord(t->start, static_cast<hipStream_t>(stream)));
+    return MICV_OK;
+}
+int micv_timer_stop(micv_timer *t, micv_stream stream) {
+    MICV_REQUIRE(t != nullptr, "micv_timer_stop: timer is null");
+    MICV_HIP(hipEventRecord(t->stop, static_cast<hipStream_t>(stream)));
+    MICV_HIP(hipEventSynchronize(t->stop));
+    return MICV_OK;
+}
+int micv_timer_elapsed_ms(micv_timer *t, float *ms) {
+    MICV_REQUIRE(t != nullptr && ms != nullptr, "micv_timer_elapsed_ms: null argument");
+    MICV_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+    return MICV_OK;
+}
+void micv_timer_destroy(micv_timer *t) {
+    if (!t) return;
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+}
+
+}  // extern "C"

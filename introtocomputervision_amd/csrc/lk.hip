@@ -1,0 +1,360 @@
+// lk.hip -- Lucas-Kanade: generic (any odd window <= 63) kernels, the pyramid driver and the
+// C entry points for a1-a4.  The win = 15 metric path dispatches to lk_fused.hip.
+#include <cstdlib>
+
+#include "kernels.hpp"
+#include "lk_device.hpp"
+#include "lk_fused.hpp"
+
+namespace micv {
+
+// ---- generic single-level pieces (one thread per pixel) -------------------------------
+
+// computeGradients x2 + OpticalFlow.cpp:62-70: the five product fields, planar in S.
+__global__ __launch_bounds__(256) void lk_products_kernel(const float *__restrict__ prev,
+                                                           int pstride,
+                                                           const float *__restrict__ next,
+                                                           int nstride, int rows, int cols,
+                                                           float *__restrict__ S, size_t field) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float s1 = 1.f / 9.f, s2 = 2.f * s1;  // OpticalFlow.cpp:19, ky = [1,2,1]*scale
+    int ry[3], rx[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        ry[j] = reflect101(y + j - 1, rows);
+        rx[j] = reflect101(x + j - 1, cols);
+    }
+    float P[3][3], N[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            P[j][i] = prev[(size_t)ry[j] * pstride + rx[i]];
+            N[j][i] = next[(size_t)ry[j] * nstride + rx[i]];
+        }
+    float pgx, pgy, ngx, ngy;
+    sobel3(P, s1, s2, pgx, pgy);
+    sobel3(N, s1, s2, ngx, ngy);
+    const float ix = avg2(ngx, pgx), iy = avg2(ngy, pgy), it = N[1][1] - P[1][1];
+    const size_t i = (size_t)y * cols + x;
+    S[i] = ix * ix;
+    S[field + i] = ix * iy;
+    S[2 * field + i] = iy * iy;
+    S[3 * field + i] = ix * it;
+    S[4 * field + i] = iy * it;
+}
+
+// OpticalFlow.cpp:85-103 (+ :161-162 when base != nullptr).
+__global__ __launch_bounds__(256) void lk_solve_kernel(const float *__restrict__ S, size_t field,
+                                                        int rows, int cols,
+                                                        const float *__restrict__ base_u,
+                                                        const float *__restrict__ base_v,
+                                                        int bstride, float *__restrict__ u,
+                                                        float *__restrict__ v, int ostride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const size_t i = (size_t)y * cols + x;
+    float uu, vv;
+    lk_solve(S[i], S[field + i], S[2 * field + i], S[3 * field + i], S[4 * field + i], uu, vv);
+    if (base_u) {
+        uu = base_u[(size_t)y * bstride + x] + uu;
+        vv = base_v[(size_t)y * bstride + x] + vv;
+    }
+    u[(size_t)y * ostride + x] = uu;
+    v[(size_t)y * ostride + x] = vv;
+}
+
+__global__ __launch_bounds__(256) void lk_warp_kernel(const float *__restrict__ src, int sstride,
+                                                       const float *__restrict__ du,
+                                                       const float *__restrict__ dv, int fstride,
+                                                       int rows, int cols,
+                                                       float *__restrict__ dst, int dstride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    dst[(size_t)y * dstride + x] = warp_sample(src, rows, cols, sstride, x, y,
+                                               du[(size_t)y * fstride + x],
+                                               dv[(size_t)y * fstride + x]);
+}
+
+int launch_warp(hipStream_t s, const float *src, int sstride, const float *du, const float *dv,
+                int fstride, int rows, int cols, float *dst, int dstride) {
+    lk_warp_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(src, sstride, du, dv, fstride,
+                                                                        rows, cols, dst, dstride);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+// Scratch floats the generic level needs: 10 planar fields.
+static size_t lk_generic_scratch(int rows, int cols) { return (size_t)rows * cols * 10; }
+
+// lk::calcOpticalFlow on (prev, next); output = base + flow when base_u != nullptr.
+static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const float *next,
+                            int nstride, int rows, int cols, int win, const float *base_u,
+                            const float *base_v, int bstride, float *u, float *v, int ostride,
+                            float *scratch) {
+    const size_t n = (size_t)rows * cols;
+    float *S = scratch, *T = scratch + 5 * n;
+    Taps g;
+    gaussian_taps(win, (double)((float)win / 3.f), &g);  // OpticalFlow.cpp:73
+    const dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
+    lk_products_kernel<<<grid, 256, 0, s>>>(prev, pstride, next, nstride, rows, cols, S, n);
+    MICV_LAUNCH_CHECK();
+    MICV_TRY(launch_filter_rows(s, S, cols, n, T, cols, n, rows, cols, 5, g));
+    MICV_TRY(launch_filter_cols(s, T, cols, n, S, cols, n, rows, cols, 5, g));
+    lk_solve_kernel<<<grid, 256, 0, s>>>(S, n, rows, cols, base_u, base_v, bstride, u, v, ostride);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+// ---- pyramid driver ---------------------------------------------------------------------
+
+struct PyrPlan {
+    int levels;
+    int rows[16], cols[16];
+    size_t lvl_off[16];   // offset (floats) of level l (l >= 1) inside one image's pyramid block
+    size_t pyr_elems;     // floats per image for levels >= 1
+};
+
+static void make_plan(int rows, int cols, int levels, PyrPlan *p) {
+    p->levels = levels;
+    size_t off = 0;
+    for (int l = 0; l < levels; l++) {
+        p->rows[l] = rows >> l;
+        p->cols[l] = cols >> l;
+        p->lvl_off[l] = off;
+        if (l >= 1) off += ((size_t)p->rows[l] * p->cols[l] + 63) & ~size_t(63);
+    }
+    p->pyr_elems = off;
+}
+
+// lk::calcOpticalFlowPyr over a batch of pairs.  use_fused selects the LDS-tiled kernel
+// (win must be instantiated there); otherwise the generic kernels run pair by pair.
+static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const float *next,
+                        int batch, size_t pair_elems, int rows, int cols, int stride, int win,
+                        int levels, float *u, float *v, size_t opair_elems, int ostride,
+                        bool allow_fused) {
+    PyrPlan plan;
+    make_plan(rows, cols, levels, &plan);
+    const bool fused = allow_fused && lk_fused_supports(win);
+    const size_t n0 = (size_t)rows * cols;
+    // Scratch: pyramids (levels >= 1) of both images for the whole batch, two flow
+    // ping-pong pairs at level-0 size per pair, and per-path temporaries.
+    const size_t flow_elems = (n0 + 63) & ~size_t(63);
+    size_t total = 0;
+    total += Carver::need(plan.pyr_elems * batch, 4) * 2;
+    total += Carver::need(flow_elems * batch, 4) * 4;
+    // generic: warped + 10 fields (one pair at a time) ; both paths: pyrUp tmp + resize tmp
+    total += Carver::need(n0, 4) + Carver::need(lk_generic_scratch(rows, cols), 4);
+    total += Carver::need(n0, 4) * 2;
+    void *base;
+    MICV_TRY(ctx->reserve(total, &base));
+    Carver carve(base);
+    float *ppyr = carve.take<float>(plan.pyr_elems * batch);
+    float *npyr = carve.take<float>(plan.pyr_elems * batch);
+    float *fu[2] = {carve.take<float>(flow_elems * batch), carve.take<float>(flow_elems * batch)};
+    float *fv[2] = {carve.take<float>(flow_elems * batch), carve.take<float>(flow_elems * batch)};
+    float *warped = carve.take<float>(n0);
+    float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
+    float *tmp_a = carve.take<float>(n0);
+    float *tmp_b = carve.take<float>(n0);
+
+    // Pyramids: one launch per image set (Pyramids.cpp:19-23; every level is a direct
+    // decimation of level 0).  Level l of image b sits at pyr + lvl_off[l]*batch + b*rows_l*cols_l.
+    if (levels > 1) {
+        float *pd[16], *nd[16];
+        pd[0] = nd[0] = nullptr;
+        for (int l = 1; l < levels; l++) {
+            pd[l] = ppyr + plan.lvl_off[l] * batch;
+            nd[l] = npyr + plan.lvl_off[l] * batch;
+        }
+        MICV_TRY(launch_pyr_build(s, prev, pair_elems, stride, rows, cols, levels, pd, batch));
+        MICV_TRY(launch_pyr_build(s, next, pair_elems, stride, rows, cols, levels, nd, batch));
+    }
+    auto level_img = [&](const float *img0, float *pyr, int l, int b, int *st) -> const float * {
+        if (l == 0) {
+            *st = stride;
+            return img0 + b * pair_elems;
+        }
+        *st = plan.cols[l];
+        return pyr + plan.lvl_off[l] * batch + (size_t)b * plan.rows[l] * plan.cols[l];
+    };
+
+    int cur = 0;         // ping-pong index holding the flow of the previous (coarser) level
+    int fr = 0, fc = 0;  // its dims
+    for (int level = 0; level < levels; level++) {
+        const int k = levels - 1 - level;
+        const int R = plan.rows[k], C = plan.cols[k];
+        const bool last = (k == 0);
+        const size_t lvl_elems = (size_t)R * C;
+        // Where this level's flow is written: the user's u/v at the finest level.
+        float *out_u = last ? u : fu[cur ^ 1];
+        float *out_v = last ? v : fv[cur ^ 1];
+        const size_t out_pair = last ? opair_elems : lvl_elems;
+        const int out_stride = last ? ostride : C;
+
+        MICV_TRY(ctx->prof_begin(k, s));
+        if (fused) {
+            LkLevelArgs a;
+            a.rows = R; a.cols = C; a.batch = batch; a.win = win;
+            int ps, ns;
+            a.prev = level_img(prev, ppyr, k, 0, &ps);
+            a.next = level_img(next, npyr, k, 0, &ns);
+            a.img_stride = ps;
+            a.img_pair = (k == 0) ? pair_elems : lvl_elems;
+            a.out_u = out_u; a.out_v = out_v; a.out_stride = out_stride; a.out_pair = out_pair;
+            a.add_base = 1;
+            if (level == 0) {
+                a.mode = LK_FLOW_NONE;
+                a.flow_u = a.flow_v = nullptr; a.flow_rows = a.flow_cols = 0; a.flow_pair = 0;
+            } else if (2 * fr == R && 2 * fc == C) {
+                a.mode = LK_FLOW_COARSE;  // pyrUp + x2 fused into the level kernel
+                a.flow_u = fu[cur]; a.flow_v = fv[cur];
+                a.flow_rows = fr; a.flow_cols = fc; a.flow_pair = (size_t)fr * fc;
+            } else {
+                // OpticalFlow.cpp:148-151: odd sizes -> pyrUp, x2, cv::resize, per pair.
+                const size_t up = (size_t)fr * 2 * fc * 2;
+                float *full_u = fu[cur ^ 1], *full_v = fv[cur ^ 1];  // becomes this level's base
+                for (int b = 0; b < batch; b++) {
+                    MICV_TRY(launch_pyr_up(s, fu[cur] + b * (size_t)fr * fc, fr, fc, fc, tmp_a,
+                                           2 * fc, 2.f, tmp_b));
+                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc,
+                                                  full_u + b * lvl_elems, R, C, C));
+                    MICV_TRY(launch_pyr_up(s, fv[cur] + b * (size_t)fr * fc, fr, fc, fc, tmp_a,
+                                           2 * fc, 2.f, tmp_b));
+                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc,
+                                                  full_v + b * lvl_elems, R, C, C));
+                }
+                (void)up;
+                a.mode = LK_FLOW_FULL;
+                a.flow_u = full_u; a.flow_v = full_v;
+                a.flow_rows = R; a.flow_cols = C; a.flow_pair = lvl_elems;
+                if (!last) {  // in-place update of the base buffers is safe (same thread, same pixel)
+                    a.out_u = full_u; a.out_v = full_v;
+                }
+            }
+            MICV_TRY(launch_lk_level_fused(s, a));
+        } else {
+            for (int b = 0; b < batch; b++) {
+                int ps, ns;
+                const float *pk = level_img(prev, ppyr, k, b, &ps);
+                const float *nk = level_img(next, npyr, k, b, &ns);
+                float *bu = fu[cur ^ 1] + b * lvl_elems, *bv = fv[cur ^ 1] + b * lvl_elems;
+                if (level == 0) {
+                    MICV_HIP(hipMemsetAsync(bu, 0, lvl_elems * 4, s));  // OpticalFlow.cpp:132-133
+                    MICV_HIP(hipMemsetAsync(bv, 0, lvl_elems * 4, s));
+                } else {
+                    const float *cu = fu[cur] + b * (size_t)fr * fc;
+                    const float *cv = fv[cur] + b * (size_t)fr * fc;
+                    if (2 * fr == R && 2 * fc == C) {
+                        MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, bu, C, 2.f, tmp_b));
+                        MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, bv, C, 2.f, tmp_b));
+                    } else {
+                        MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
+                        MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bu, R, C, C));
+                        MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
+                        MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bv, R, C, C));
+                    }
+                }
+                MICV_TRY(launch_warp(s, nk, ns, bu, bv, C, R, C, warped, C));  // :155
+                float *ou = last ? u + b * opair_elems : bu;
+                float *ov = last ? v + b * opair_elems : bv;
+                MICV_TRY(lk_level_generic(s, pk, ps, warped, C, R, C, win, bu, bv, C, ou, ov,
+                                          out_stride, gen));  // :159-162
+            }
+        }
+        MICV_TRY(ctx->prof_end(k, s));
+        cur ^= 1;
+        fr = R;
+        fc = C;
+    }
+    return MICV_OK;
+}
+
+}  // namespace micv
+
+using namespace micv;
+
+static int check_lk_args(const char *fn, const void *ctx, const void *a, const void *b,
+                         const void *u, const void *v, int rows, int cols, size_t stride,
+                         size_t ostride, int win) {
+    MICV_REQUIRE(ctx && a && b && u && v, "%s: null argument", fn);
+    MICV_REQUIRE(rows > 0 && cols > 0 && rows <= 32767 && cols <= 32767, "%s: bad size %dx%d", fn,
+                 rows, cols);
+    MICV_REQUIRE(stride_ok(stride, cols, 4) && stride_ok(ostride, cols, 4), "%s: bad stride", fn);
+    MICV_REQUIRE(win >= 1 && win <= kMaxWin && (win & 1), "%s: window %d must be odd and <= %d", fn,
+                 win, kMaxWin);
+    return MICV_OK;
+}
+
+extern "C" {
+
+int micv_lk_flow_pyr_batch_dev(micv_ctx *ctx, const float *prev, const float *next, int batch,
+                               size_t pair_stride, int rows, int cols, size_t stride, int win,
+                               int levels, float *u, float *v, size_t opair_stride,
+                               size_t ostride, micv_stream stream) {
+    MICV_TRY(check_lk_args("micv_lk_flow_pyr", ctx, prev, next, u, v, rows, cols, stride, ostride,
+                           win));
+    MICV_REQUIRE(batch >= 1 && batch <= 65535, "micv_lk_flow_pyr: bad batch %d", batch);
+    MICV_REQUIRE(levels >= 1 && levels <= 16 && (rows >> (levels - 1)) > 0 &&
+                     (cols >> (levels - 1)) > 0,
+                 "micv_lk_flow_pyr: %d levels do not fit a %dx%d image", levels, rows, cols);
+    MICV_REQUIRE(pair_stride % 4 == 0 && opair_stride % 4 == 0 &&
+                     (batch == 1 || (pair_stride >= stride * (size_t)rows &&
+                                     opair_stride >= ostride * (size_t)rows)),
+                 "micv_lk_flow_pyr: bad pair stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    return lk_pyr_batch(ctx, static_cast<hipStream_t>(stream), prev, next, batch, pair_stride / 4,
+                        rows, cols, (int)(stride / 4), win, levels, u, v, opair_stride / 4,
+                        (int)(ostride / 4), !getenv("MICV_FORCE_GENERIC"));
+}
+
+int micv_lk_flow_pyr_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                         size_t stride, int win, int levels, float *u, float *v, size_t ostride,
+                         micv_stream stream) {
+    return micv_lk_flow_pyr_batch_dev(ctx, prev, next, 1, 0, rows, cols, stride, win, levels, u, v,
+                                      0, ostride, stream);
+}
+
+int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                     size_t stride, int win, float *u, float *v, size_t ostride,
+                     micv_stream stream) {
+    MICV_TRY(check_lk_args("micv_lk_flow", ctx, prev, next, u, v, rows, cols, stride, ostride, win));
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (lk_fused_supports(win) && !getenv("MICV_FORCE_GENERIC")) {
+        LkLevelArgs a;
+        a.rows = rows; a.cols = cols; a.batch = 1; a.win = win;
+        a.prev = prev; a.next = next; a.img_stride = (int)(stride / 4); a.img_pair = 0;
+        a.mode = LK_FLOW_NONE;
+        a.flow_u = a.flow_v = nullptr; a.flow_rows = a.flow_cols = 0; a.flow_pair = 0;
+        a.out_u = u; a.out_v = v; a.out_stride = (int)(ostride / 4); a.out_pair = 0;
+        a.add_base = 0;
+        return launch_lk_level_fused(s, a);
+    }
+    void *scratch;
+    MICV_TRY(ctx->reserve(Carver::need(lk_generic_scratch(rows, cols), 4), &scratch));
+    return lk_level_generic(s, prev, (int)(stride / 4), next, (int)(stride / 4), rows, cols, win,
+                            nullptr, nullptr, 0, u, v, (int)(ostride / 4),
+                            static_cast<float *>(scratch));
+}
+
+int micv_lk_warp_dev(micv_ctx *ctx, const float *src, size_t sstride, const float *du,
+                     const float *dv, size_t fstride, int rows, int cols, float *dst,
+                     size_t dstride, micv_stream stream) {
+    MICV_REQUIRE(ctx && src && du && dv && dst, "micv_lk_warp: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0 && rows <= 32767 && cols <= 32767,
+                 "micv_lk_warp: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(stride_ok(sstride, cols, 4) && stride_ok(fstride, cols, 4) &&
+                     stride_ok(dstride, cols, 4),
+                 "micv_lk_warp: bad stride");
+    MICV_REQUIRE(src != dst, "micv_lk_warp: src and dst must not alias");
+    MICV_HIP(hipSetDevice(ctx->device));
+    return launch_warp(static_cast<hipStream_t>(stream), src, (int)(sstride / 4), du, dv,
+                       (int)(fstride / 4), rows, cols, dst, (int)(dstride / 4));
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// lk_device.hpp -- device-side arithmetic shared by the generic and the fused LK kernels.
+// Every function here is the single definition of one step of the arithmetic contract
+// (DESIGN.md): the generic and fused paths call the same code, so they agree bit for bit.
+#pragma once
+#include "common.hpp"
+
+namespace micv {
+
+// Sobel 3x3 pair from a 3x3 neighbourhood I[row][col] (already border-resolved).
+// cv::cuda separable filter = row pass (float result) then column pass, each an fmaf chain
+// from +0.  d/dx: rows [-1,0,1], cols [s,2s,s];  d/dy: rows [s,2s,s], cols [-1,0,1].
+// The [-1,0,1] chain fmaf(c,1,fmaf(b,0,fmaf(a,-1,0))) equals c - a for finite inputs.
+__device__ __forceinline__ void sobel3(const float I[3][3], float s1, float s2, float &gx,
+                                       float &gy) {
+    float tx[3], ty[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        tx[j] = I[j][2] - I[j][0];
+        ty[j] = fmaf(I[j][2], s1, fmaf(I[j][1], s2, I[j][0] * s1));
+    }
+    gx = fmaf(tx[2], s1, fmaf(tx[1], s2, tx[0] * s1));
+    gy = ty[2] - ty[0];
+}
+
+// OpticalFlow.cpp:62-64: Ix = (nextIx + prevIx) / 2.f  (cv::addWeighted(a,.5,b,.5,0)),
+// It = next - prev.
+__device__ __forceinline__ float avg2(float a, float b) { return a * 0.5f + b * 0.5f; }
+
+// OpticalFlow.cpp:85-103 with cv::determinant / cv::solve(DECOMP_LU) 2x2 CV_32F: double
+// det2, threshold tau = 0.1, Cramer with d = 1/det in double, results cast to float.
+__device__ __forceinline__ void lk_solve(float sxx, float sxy, float syy, float sxt, float syt,
+                                         float &u, float &v) {
+    const double det = (double)sxx * (double)syy - (double)sxy * (double)sxy;
+    u = 0.f;
+    v = 0.f;
+    if (!(det < 0.1) && det != 0.) {
+        const double d = 1. / det;
+        const float b0 = -sxt, b1 = -syt;
+        u = (float)(((double)b0 * (double)syy - (double)b1 * (double)sxy) * d);
+        v = (float)(((double)b1 * (double)sxx - (double)b0 * (double)sxy) * d);
+    }
+}
+
+// lk::warp (OpticalFlow.cpp:111-119) for one pixel: map = (x + du, y + dv); cv::remap
+// INTER_LINEAR with 1/32-pixel fixed-point coordinates, BORDER_CONSTANT(0).
+__device__ __forceinline__ float warp_sample(const float *__restrict__ src, int rows, int cols,
+                                             int stride, int x, int y, float du, float dv) {
+    const float mx = (float)x + du, my = (float)y + dv;
+    const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
+    const int fx = sx & 31, fy = sy & 31;
+    const int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+    const float ax1 = (float)fx * 0.03125f, ax0 = 1.f - ax1;
+    const float ay1 = (float)fy * 0.03125f, ay0 = 1.f - ay1;
+    const bool x0 = (unsigned)ix < (unsigned)cols, x1 = (unsigned)(ix + 1) < (unsigned)cols;
+    const bool y0 = (unsigned)iy < (unsigned)rows, y1 = (unsigned)(iy + 1) < (unsigned)rows;
+    const float *p = src + (ptrdiff_t)iy * stride + ix;
+    const float v0 = (x0 && y0) ? p[0] : 0.f;
+    const float v1 = (x1 && y0) ? p[1] : 0.f;
+    const float v2 = (x0 && y1) ? p[stride] : 0.f;
+    const float v3 = (x1 && y1) ? p[stride + 1] : 0.f;
+    float r = v0 * (ay0 * ax0);
+    r = r + v1 * (ay0 * ax1);
+    r = r + v2 * (ay1 * ax0);
+    r = r + v3 * (ay1 * ax1);
+    return r;
+}
+
+}  // namespace micv

@@ -1,0 +1,398 @@
+// lk_fused.hip -- one pyramid level of Lucas-Kanade as ONE LDS-tiled kernel (gfx950).
+//
+// Per 64x32 output tile (256 threads = 4 wave64, 2 workgroups per CU by LDS):
+//   phase 0  stage the prev tile (+R+1 halo) and the coarse flow block in LDS
+//   phase 1  pyrUp row pass of the coarse flow              (Pyramids.cu:126, fused)
+//   phase 2  pyrUp column pass, x2, lk::warp gather of `next` -> warped tile in LDS
+//   phase 3  Sobel pairs of prev / warped, Ix Iy It -> LDS  (OpticalFlow.cpp:60-64)
+//   phase 4  five Gaussian-weighted window sums: products formed on the fly, separable
+//            (2R+1)-tap row pass (4 outputs per thread, ds_read_b128 window) into a
+//            double-buffered LDS row buffer, column pass (8 outputs per thread) in registers
+//   phase 5  2x2 solve in double, add the base flow, store du / dv
+// HBM traffic per level pixel: read prev (4 B) + gathered next (4 B, L2) + coarse flow
+// (2 B), write du, dv (8 B).  Nothing else leaves the CU.
+//
+// All arithmetic goes through lk_device.hpp / the fmaf chains below, identical to the
+// generic kernels in lk.hip and to the CPU oracle.
+#include "lk_fused.hpp"
+
+#include <mutex>
+
+#include "lk_device.hpp"
+
+namespace micv {
+
+template <int N>
+struct TapsN {
+    float k[N];
+};
+
+template <int R_>
+struct LkCfg {
+    static constexpr int R = R_;
+    static constexpr int W = 2 * R + 1;
+    static constexpr int TW = 64, TH = 32, NT = 256;
+    static constexpr int H = R + 1;                       // image halo (Sobel + window)
+    static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;  // image region
+    static constexpr int PS = RW;                          // LDS row stride of P / Wp
+    static constexpr int GW = TW + 2 * R, GH = TH + 2 * R;  // gradient region
+    static constexpr int GS = ((GW + 3) & ~3) + 4;          // 16-B aligned rows + pad
+    static constexpr int CW = RW / 2 + 3, CH = RH / 2 + 3;  // coarse flow block
+    static constexpr int ROWS_PER_THREAD = TH / (NT / TW);  // 8
+    static constexpr int IMG_F = 2 * RH * PS;
+    static constexpr int FLOW_F = 2 * CH * CW + 2 * CH * RW;
+    static constexpr int GRAD_F = 3 * GH * GS;
+    static constexpr int X_F = FLOW_F > GRAD_F ? FLOW_F : GRAD_F;
+    static constexpr int ROWBUF_F = 2 * GH * TW;
+    static_assert(ROWBUF_F <= IMG_F, "row buffers alias the image tiles");
+    static_assert(ROWS_PER_THREAD == 8, "column pass is written for 8 rows per thread");
+    static constexpr int LDS_FLOATS = IMG_F + X_F;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
+};
+
+// Row pass for one product field A*B over the gradient region.  Unit = 4 adjacent outputs.
+template <typename C, bool SAME>
+__device__ __forceinline__ void row_pass(const float *__restrict__ A, const float *__restrict__ B,
+                                         float *__restrict__ out, const TapsN<C::W> &g, int tid,
+                                         int x0, int y0, int rows, int cols, bool xint) {
+    constexpr int R = C::R, GS = C::GS, TW = C::TW, GH = C::GH;
+    constexpr int UNITS = GH * (TW / 4);
+    for (int u = tid; u < UNITS; u += C::NT) {
+        const int qy = u / (TW / 4), grp = u % (TW / 4);
+        const int gy = y0 - R + qy;
+        if ((unsigned)gy >= (unsigned)rows) continue;
+        const int c0 = 4 * grp;
+        float o[4];
+        if (xint) {
+            float p[20];
+            const float4 *a4 = reinterpret_cast<const float4 *>(A + qy * GS + c0);
+            const float4 *b4 = reinterpret_cast<const float4 *>(B + qy * GS + c0);
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                if (4 * i >= 4 + 2 * R) break;
+                const float4 av = a4[i];
+                const float4 bv = SAME ? av : b4[i];
+                p[4 * i + 0] = av.x * bv.x;
+                p[4 * i + 1] = av.y * bv.y;
+                p[4 * i + 2] = av.z * bv.z;
+                p[4 * i + 3] = av.w * bv.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < C::W; k++) acc = fmaf(p[j + k], g.k[k], acc);
+                o[j] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float acc = 0.f;
+                const int gx = x0 + c0 + j;
+                if (gx < cols) {
+                    for (int k = 0; k < C::W; k++) {
+                        const int q = reflect101(gx + k - R, cols) - (x0 - R);
+                        const float av = A[qy * GS + q];
+                        const float bv = SAME ? av : B[qy * GS + q];
+                        acc = fmaf(av * bv, g.k[k], acc);
+                    }
+                }
+                o[j] = acc;
+            }
+        }
+        *reinterpret_cast<float4 *>(out + qy * TW + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Column pass: thread (c, grp8) produces 8 vertically adjacent window sums.
+template <typename C>
+__device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S)[8],
+                                         const TapsN<C::W> &g, int c, int r0, int y0, int rows,
+                                         bool yint) {
+    constexpr int R = C::R, TW = C::TW;
+    if (yint) {
+        float v[8 + 2 * R];
+#pragma unroll
+        for (int i = 0; i < 8 + 2 * R; i++) v[i] = rb[(r0 + i) * TW + c];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < C::W; k++) acc = fmaf(v[j + k], g.k[k], acc);
+            S[j] = acc;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float acc = 0.f;
+            const int gy = y0 + r0 + j;
+            if (gy < rows) {
+                for (int k = 0; k < C::W; k++) {
+                    const int q = reflect101(gy + k - R, rows) - (y0 - R);
+                    acc = fmaf(rb[q * TW + c], g.k[k], acc);
+                }
+            }
+            S[j] = acc;
+        }
+    }
+}
+
+template <int R, int MODE>
+__global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+    using C = LkCfg<R>;
+    constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
+    constexpr int GW = C::GW, GH = C::GH, GS = C::GS, CW = C::CW, CH = C::CH, NT = C::NT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *P = lds;
+    float *Wp = lds + RH * PS;
+    float *X = lds + C::IMG_F;
+    float *Cu = X, *Cv = X + CH * CW, *Ru = X + 2 * CH * CW, *Rv = Ru + CH * RW;
+    float *Gx = X, *Gy = X + GH * GS, *Gt = X + 2 * GH * GS;
+    float *rowbuf = lds;  // aliases P / Wp after phase 3
+
+    const int tid = threadIdx.x;
+    const int rows = a.rows, cols = a.cols;
+    const int tiles_x = (cols + TW - 1) / TW;
+    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
+    const int x0 = tile_x * TW, y0 = tile_y * TH;
+    const int rx0 = x0 - H, ry0 = y0 - H;
+    const int pair = blockIdx.y;
+    const float *__restrict__ prev = a.prev + pair * a.img_pair;
+    const float *__restrict__ next = a.next + pair * a.img_pair;
+    const int istride = a.img_stride;
+
+    // ---- phase 0: prev tile (and next tile when there is no warp) ------------------------
+    for (int i = tid; i < RH * RW; i += NT) {
+        const int ly = i / RW, lx = i - ly * RW;
+        const int gy = ry0 + ly, gx = rx0 + lx;
+        if ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols) {
+            P[ly * PS + lx] = prev[(size_t)gy * istride + gx];
+            if (MODE == LK_FLOW_NONE) Wp[ly * PS + lx] = next[(size_t)gy * istride + gx];
+        }
+    }
+    float base_u[8], base_v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) base_u[j] = base_v[j] = 0.f;
+
+    if (MODE != LK_FLOW_NONE) {
+        const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};  // Pyramids.cu:19
+        int cx0 = 0, cy0 = 0;
+        if (MODE == LK_FLOW_COARSE) {
+            const float *__restrict__ fu = a.flow_u + pair * a.flow_pair;
+            const float *__restrict__ fv = a.flow_v + pair * a.flow_pair;
+            const int fr = a.flow_rows, fc = a.flow_cols;
+            cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
+            cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
+            for (int i = tid; i < CH * CW; i += NT) {
+                const int cy = i / CW, cx = i - cy * CW;
+                if (cy0 + cy < fr && cx0 + cx < fc) {
+                    Cu[i] = fu[(size_t)(cy0 + cy) * fc + cx0 + cx];
+                    Cv[i] = fv[(size_t)(cy0 + cy) * fc + cx0 + cx];
+                }
+            }
+            __syncthreads();
+            // ---- phase 1: pyrUp row pass, once per coarse row (replicated rows are equal) --
+            for (int i = tid; i < CH * RW; i += NT) {
+                const int cy = i / RW, lx = i - cy * RW;
+                const int gx = rx0 + lx;
+                if ((unsigned)gx < (unsigned)cols && cy0 + cy < fr) {
+                    float au = 0.f, av = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const int sc = (reflect101(gx + k - 2, cols) >> 1) - cx0;
+                        au = fmaf(Cu[cy * CW + sc], g5[k], au);
+                        av = fmaf(Cv[cy * CW + sc], g5[k], av);
+                    }
+                    Ru[i] = au;
+                    Rv[i] = av;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- phase 2: base flow at every region pixel, warp `next` --------------------------
+        auto do_px = [&](int ly, int lx, float &bu, float &bv) {
+            const int gy = ry0 + ly, gx = rx0 + lx;
+            if ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols) return;
+            if (MODE == LK_FLOW_COARSE) {
+                float au = 0.f, av = 0.f;
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const int rr = (reflect101(gy + k - 2, rows) >> 1) - cy0;
+                    au = fmaf(Ru[rr * RW + lx], g5[k], au);
+                    av = fmaf(Rv[rr * RW + lx], g5[k], av);
+                }
+                bu = au * 2.f;  // OpticalFlow.cpp:142,144
+                bv = av * 2.f;
+            } else {
+                bu = a.flow_u[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
+                bv = a.flow_v[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
+            }
+            Wp[ly * PS + lx] = warp_sample(next, rows, cols, istride, gx, gy, bu, bv);
+        };
+        {
+            const int c = tid & (TW - 1), grp = tid / TW;
+#pragma unroll
+            for (int j = 0; j < 8; j++) do_px(H + 8 * grp + j, H + c, base_u[j], base_v[j]);
+        }
+        constexpr int NHALO = 2 * H * RW + TH * 2 * H;
+        for (int n = tid; n < NHALO; n += NT) {
+            int ly, lx;
+            if (n < 2 * H * RW) {
+                ly = n / RW;
+                lx = n - ly * RW;
+                if (ly >= H) ly += TH;
+            } else {
+                const int m = n - 2 * H * RW;
+                const int rr = m / (2 * H), cc = m - rr * (2 * H);
+                ly = H + rr;
+                lx = cc < H ? cc : TW + cc;
+            }
+            float du_, dv_;
+            do_px(ly, lx, du_, dv_);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: gradients --------------------------------------------------------------
+    {
+        const float s1 = 1.f / 9.f, s2 = 2.f * s1;  // OpticalFlow.cpp:19
+        for (int i = tid; i < GH * GW; i += NT) {
+            const int qy = i / GW, qx = i - qy * GW;
+            const int gy = y0 - R + qy, gx = x0 - R + qx;
+            if ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols) continue;
+            int ly[3], lx[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                ly[j] = (reflect101(gy + j - 1, rows) - ry0) * PS;
+                lx[j] = reflect101(gx + j - 1, cols) - rx0;
+            }
+            float Pn[3][3], Nn[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    Pn[j][k] = P[ly[j] + lx[k]];
+                    Nn[j][k] = Wp[ly[j] + lx[k]];
+                }
+            float pgx, pgy, ngx, ngy;
+            sobel3(Pn, s1, s2, pgx, pgy);
+            sobel3(Nn, s1, s2, ngx, ngy);
+            Gx[qy * GS + qx] = avg2(ngx, pgx);
+            Gy[qy * GS + qx] = avg2(ngy, pgy);
+            Gt[qy * GS + qx] = Nn[1][1] - Pn[1][1];
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: five window sums -----------------------------------------------------------
+    const bool xint = (x0 - R >= 0) && (x0 + TW + R <= cols);
+    const bool yint = (y0 - R >= 0) && (y0 + TH + R <= rows);
+    const int c = tid & (TW - 1), r0 = 8 * (tid / TW);
+    float Sxx[8], Sxy[8], Syy[8], Sxt[8], Syt[8];
+    float *rb0 = rowbuf, *rb1 = rowbuf + GH * TW;
+
+    row_pass<C, true>(Gx, Gx, rb0, g, tid, x0, y0, rows, cols, xint);
+    __syncthreads();
+    col_pass<C>(rb0, Sxx, g, c, r0, y0, rows, yint);
+    row_pass<C, false>(Gx, Gy, rb1, g, tid, x0, y0, rows, cols, xint);
+    __syncthreads();
+    col_pass<C>(rb1, Sxy, g, c, r0, y0, rows, yint);
+    row_pass<C, true>(Gy, Gy, rb0, g, tid, x0, y0, rows, cols, xint);
+    __syncthreads();
+    col_pass<C>(rb0, Syy, g, c, r0, y0, rows, yint);
+    row_pass<C, false>(Gx, Gt, rb1, g, tid, x0, y0, rows, cols, xint);
+    __syncthreads();
+    col_pass<C>(rb1, Sxt, g, c, r0, y0, rows, yint);
+    row_pass<C, false>(Gy, Gt, rb0, g, tid, x0, y0, rows, cols, xint);
+    __syncthreads();
+    col_pass<C>(rb0, Syt, g, c, r0, y0, rows, yint);
+
+    // ---- phase 5: solve + store ----------------------------------------------------------------
+    float *__restrict__ ou = a.out_u + pair * a.out_pair;
+    float *__restrict__ ov = a.out_v + pair * a.out_pair;
+    const int gx = x0 + c;
+    if (gx < cols) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int gy = y0 + r0 + j;
+            if (gy < rows) {
+                float uu, vv;
+                lk_solve(Sxx[j], Sxy[j], Syy[j], Sxt[j], Syt[j], uu, vv);
+                if (a.add_base) {
+                    uu = base_u[j] + uu;
+                    vv = base_v[j] + vv;
+                }
+                ou[(size_t)gy * a.out_stride + gx] = uu;
+                ov[(size_t)gy * a.out_stride + gx] = vv;
+            }
+        }
+    }
+}
+
+bool lk_fused_supports(int win) { return win == 15 || win == 7; }
+
+template <int R>
+static int launch_r(hipStream_t s, const LkLevelArgs &a) {
+    using C = LkCfg<R>;
+    static TapsN<2 * R + 1> taps;
+    static std::once_flag once;
+    static bool attr_ok = true;
+    std::call_once(once, [] {
+        Taps t;
+        gaussian_taps(2 * R + 1, (double)((float)(2 * R + 1) / 3.f), &t);  // OpticalFlow.cpp:73
+        for (int i = 0; i < 2 * R + 1; i++) taps.k[i] = t.k[i];
+    });
+    // Dynamic LDS above 64 KB needs the attribute; set it on every device we launch on.
+    {
+        static thread_local int done_dev = -1;
+        int dev = 0;
+        MICV_HIP(hipGetDevice(&dev));
+        if (done_dev != dev) {
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::LDS_BYTES));
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::LDS_BYTES));
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)C::LDS_BYTES));
+            done_dev = dev;
+        }
+    }
+    (void)attr_ok;
+    const dim3 grid(cdiv(a.cols, C::TW) * cdiv(a.rows, C::TH), a.batch);
+    switch (a.mode) {
+        case LK_FLOW_NONE:
+            lk_level_kernel<R, 0><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            break;
+        case LK_FLOW_COARSE:
+            if (a.rows != 2 * a.flow_rows || a.cols != 2 * a.flow_cols) {
+                set_error("lk fused: coarse flow %dx%d does not double to %dx%d", a.flow_rows,
+                          a.flow_cols, a.rows, a.cols);
+                return MICV_EINVAL;
+            }
+            lk_level_kernel<R, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            break;
+        case LK_FLOW_FULL:
+            lk_level_kernel<R, 2><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            break;
+        default:
+            set_error("lk fused: bad mode %d", a.mode);
+            return MICV_EINVAL;
+    }
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a) {
+    switch (a.win) {
+        case 15: return launch_r<7>(s, a);
+        case 7: return launch_r<3>(s, a);
+        default:
+            set_error("lk fused: window %d has no tiled instantiation", a.win);
+            return MICV_EUNSUPPORTED;
+    }
+}
+
+}  // namespace micv

@@ -1,0 +1,31 @@
+// lk_fused.hpp -- interface of the LDS-tiled fused Lucas-Kanade level kernel.
+#pragma once
+#include "common.hpp"
+
+namespace micv {
+
+enum LkFlowMode {
+    LK_FLOW_NONE = 0,    // coarsest level / lk::calcOpticalFlow: base flow is zero, no warp
+    LK_FLOW_COARSE = 1,  // base = 2 * pyrUp(coarse flow), computed inside the kernel
+    LK_FLOW_FULL = 2,    // base flow given at this level's resolution (odd-size levels)
+};
+
+struct LkLevelArgs {
+    const float *prev, *next;  // level images of pair 0
+    int img_stride;            // elements
+    size_t img_pair;           // elements between consecutive pairs
+    int rows, cols, batch, win;
+    int mode;
+    const float *flow_u, *flow_v;  // coarse (mode 1: flow_rows x flow_cols, dense) or full (mode 2)
+    int flow_rows, flow_cols;
+    size_t flow_pair;
+    float *out_u, *out_v;
+    int out_stride;
+    size_t out_pair;
+    int add_base;  // 1: out = base + flow (OpticalFlow.cpp:161-162); 0: out = flow (:100-101)
+};
+
+bool lk_fused_supports(int win);
+int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a);
+
+}  // namespace micv

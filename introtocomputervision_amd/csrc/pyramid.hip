@@ -1,0 +1,254 @@
+// pyramid.hip -- REDUCE / EXPAND, bilinear resize, grey conversion (ps5 pyramids, a5-a7).
+#include "kernels.hpp"
+
+namespace micv {
+
+// pyr::pyrDown as the reference executes it (Pyramids.cu:31, launched on d_src :65-66):
+// pure odd-index decimation.  Because every level is a decimation of the one above,
+// level l is also a direct decimation of level 0:  L_l(y,x) = L_0(2^l y + 2^l - 1, ...).
+// The multi-level kernel below uses that to build the whole pyramid in ONE launch.
+__global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src, int sstride,
+                                                        float *__restrict__ dst, int dstride,
+                                                        int drows, int dcols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dcols || y >= drows) return;
+    dst[(size_t)y * dstride + x] = src[(size_t)(2 * y + 1) * sstride + 2 * x + 1];
+}
+
+struct PyrLevels {
+    float *dst[16];
+    int rows[16], cols[16];
+    int tiles_before[17];  // prefix sum of 64x4-tiles per level (levels 1..n-1 and level 0 copy)
+    int n;
+};
+
+// One block = 64x4 output pixels of some level; blockIdx.x indexes tiles over all levels,
+// blockIdx.y = image in the batch.  Level 0 is a plain copy (the reference clones the input,
+// Pyramids.cpp:9,18) and is only emitted when dst[0] != nullptr.
+__global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict__ src,
+                                                         size_t img_elems, int sstride,
+                                                         PyrLevels L) {
+    int l = 0;
+    const int bid = blockIdx.x;
+    while (l + 1 < L.n && bid >= L.tiles_before[l + 1]) l++;
+    if (L.dst[l] == nullptr) return;
+    const int t = bid - L.tiles_before[l];
+    const int tw = (L.cols[l] + 63) >> 6;
+    const int tx = t % tw, ty = t / tw;
+    const int x = tx * 64 + (threadIdx.x & 63);
+    const int y = ty * 4 + (threadIdx.x >> 6);
+    if (x >= L.cols[l] || y >= L.rows[l]) return;
+    const int sh = (1 << l) - 1;
+    const float *s = src + blockIdx.y * img_elems;
+    float *d = L.dst[l] + blockIdx.y * (size_t)L.rows[l] * L.cols[l];
+    d[(size_t)y * L.cols[l] + x] = s[(size_t)((y << l) + sh) * sstride + (x << l) + sh];
+}
+
+// pyr::pyrUp step 1+2a (Pyramids.cu:86-91 replicate, :126 row filter): the replicated image's
+// rows 2yc and 2yc+1 are identical, so the row pass is evaluated once per COARSE row:
+//   R(yc, x) = chain_k fmaf(src(yc, reflect101(x+k-2, 2w) / 2), g5[k], acc)
+__global__ __launch_bounds__(256) void pyr_up_rows_kernel(const float *__restrict__ src,
+                                                           int sstride, float *__restrict__ tmp,
+                                                           int rows, int cols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int uc = 2 * cols;
+    if (x >= uc || y >= rows) return;
+    const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    const float *s = src + (size_t)y * sstride;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc = fmaf(s[reflect101(x + k - 2, uc) >> 1], g5[k], acc);
+    tmp[(size_t)y * uc + x] = acc;
+}
+
+// Step 2b: column pass over the replicated rows, then the caller's exact power-of-two scale
+// (`du = 2 * du`, OpticalFlow.cpp:142,144).
+__global__ __launch_bounds__(256) void pyr_up_cols_kernel(const float *__restrict__ tmp,
+                                                           float *__restrict__ dst, int dstride,
+                                                           int rows, int cols, float scale) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int uc = 2 * cols, ur = 2 * rows;
+    if (x >= uc || y >= ur) return;
+    const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        acc = fmaf(tmp[(size_t)(reflect101(y + k - 2, ur) >> 1) * uc + x], g5[k], acc);
+    dst[(size_t)y * dstride + x] = acc * scale;
+}
+
+// cv::resize INTER_LINEAR for CV_32F: half-pixel centres, x taps zero-weighted at the edges,
+// y taps clamped; horizontal pass per source row, then the vertical blend (unfused mul/add).
+__global__ __launch_bounds__(256) void resize_linear_kernel(const float *__restrict__ src,
+                                                             int srows, int scols, int sstride,
+                                                             float *__restrict__ dst, int drows,
+                                                             int dcols, int dstride, double scale_x,
+                                                             double scale_y) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dcols || dy >= drows) return;
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= scols - 1) { fx = 0.f; sx = scols - 1; }
+    const float a0 = 1.f - fx, a1 = fx;
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    const float b0 = 1.f - fy, b1 = fy;
+    const float *r0 = src + (size_t)clampi(sy, 0, srows - 1) * sstride;
+    const float *r1 = src + (size_t)clampi(sy + 1, 0, srows - 1) * sstride;
+    float h0, h1;
+    if (sx + 1 >= scols) {
+        h0 = r0[sx] * 1.f;
+        h1 = r1[sx] * 1.f;
+    } else {
+        h0 = r0[sx] * a0 + r0[sx + 1] * a1;
+        h1 = r1[sx] * a0 + r1[sx + 1] * a1;
+    }
+    dst[(size_t)dy * dstride + dx] = h0 * b0 + h1 * b1;
+}
+
+// cv::cvtColor(COLOR_RGB2GRAY) on CV_8UC3 (R2Y=4899, G2Y=9617, B2Y=1868, shift 14, round) then
+// convertTo(CV_32F).
+__global__ __launch_bounds__(256) void rgb8_to_gray_kernel(const uint8_t *__restrict__ rgb,
+                                                            size_t sstride,
+                                                            float *__restrict__ dst, int dstride,
+                                                            int rows, int cols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const uint8_t *s = rgb + (size_t)y * sstride + 3 * x;
+    const int g = (s[0] * 4899 + s[1] * 9617 + s[2] * 1868 + (1 << 13)) >> 14;
+    dst[(size_t)y * dstride + x] = (float)g;
+}
+
+int launch_pyr_down(hipStream_t s, const float *src, int rows, int cols, int sstride, float *dst,
+                    int dstride) {
+    const int dr = rows / 2, dc = cols / 2;
+    if (dr == 0 || dc == 0) return MICV_OK;
+    pyr_down_kernel<<<dim3(cdiv(dc, 64), cdiv(dr, 4)), 256, 0, s>>>(src, sstride, dst, dstride, dr,
+                                                                     dc);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int launch_pyr_up(hipStream_t s, const float *src, int rows, int cols, int sstride, float *dst,
+                  int dstride, float scale, float *tmp) {
+    pyr_up_rows_kernel<<<dim3(cdiv(2 * cols, 64), cdiv(rows, 4)), 256, 0, s>>>(src, sstride, tmp,
+                                                                                rows, cols);
+    MICV_LAUNCH_CHECK();
+    pyr_up_cols_kernel<<<dim3(cdiv(2 * cols, 64), cdiv(2 * rows, 4)), 256, 0, s>>>(
+        tmp, dst, dstride, rows, cols, scale);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int launch_resize_linear(hipStream_t s, const float *src, int srows, int scols, int sstride,
+                         float *dst, int drows, int dcols, int dstride) {
+    const double scale_x = 1. / ((double)dcols / scols);
+    const double scale_y = 1. / ((double)drows / srows);
+    resize_linear_kernel<<<dim3(cdiv(dcols, 64), cdiv(drows, 4)), 256, 0, s>>>(
+        src, srows, scols, sstride, dst, drows, dcols, dstride, scale_x, scale_y);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+// Builds levels [first..n) of `batch` images in one launch. dst[l] holds the batch densely:
+// image b of level l at dst[l] + b*rows_l*cols_l.
+int launch_pyr_build(hipStream_t s, const float *src, size_t img_elems, int sstride, int rows,
+                     int cols, int levels, float *const *dst, int batch) {
+    PyrLevels L;
+    L.n = levels;
+    int total = 0;
+    for (int l = 0; l < levels; l++) {
+        L.rows[l] = rows >> l;
+        L.cols[l] = cols >> l;
+        L.dst[l] = dst[l];
+        L.tiles_before[l] = total;
+        if (dst[l]) total += cdiv(L.cols[l], 64) * cdiv(L.rows[l], 4);
+    }
+    L.tiles_before[levels] = total;
+    if (total == 0) return MICV_OK;
+    pyr_build_kernel<<<dim3(total, batch), 256, 0, s>>>(src, img_elems, sstride, L);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+}  // namespace micv
+
+using namespace micv;
+
+extern "C" {
+
+int micv_pyr_down_dev(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                      float *dst, size_t dstride, micv_stream stream) {
+    MICV_REQUIRE(ctx && src && dst, "micv_pyr_down: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0, "micv_pyr_down: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(stride_ok(sstride, cols, 4) && stride_ok(dstride, cols / 2, 4),
+                 "micv_pyr_down: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    return launch_pyr_down(static_cast<hipStream_t>(stream), src, rows, cols, (int)(sstride / 4),
+                           dst, (int)(dstride / 4));
+}
+
+int micv_pyr_up_dev(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                    float *dst, size_t dstride, micv_stream stream) {
+    MICV_REQUIRE(ctx && src && dst, "micv_pyr_up: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0 && rows < (1 << 29) && cols < (1 << 29),
+                 "micv_pyr_up: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(stride_ok(sstride, cols, 4) && stride_ok(dstride, 2 * cols, 4),
+                 "micv_pyr_up: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    void *scratch;
+    MICV_TRY(ctx->reserve(Carver::need((size_t)rows * cols * 2, 4), &scratch));
+    return launch_pyr_up(static_cast<hipStream_t>(stream), src, rows, cols, (int)(sstride / 4),
+                         dst, (int)(dstride / 4), 1.f, static_cast<float *>(scratch));
+}
+
+int micv_resize_linear_dev(micv_ctx *ctx, const float *src, int srows, int scols, size_t sstride,
+                           float *dst, int drows, int dcols, size_t dstride,
+                           micv_stream stream) {
+    MICV_REQUIRE(ctx && src && dst, "micv_resize_linear: null argument");
+    MICV_REQUIRE(srows > 0 && scols > 0 && drows > 0 && dcols > 0, "micv_resize_linear: bad size");
+    MICV_REQUIRE(stride_ok(sstride, scols, 4) && stride_ok(dstride, dcols, 4),
+                 "micv_resize_linear: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    return launch_resize_linear(static_cast<hipStream_t>(stream), src, srows, scols,
+                                (int)(sstride / 4), dst, drows, dcols, (int)(dstride / 4));
+}
+
+int micv_gaussian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int cols, size_t sstride,
+                              int levels, float *const *dst_levels, micv_stream stream) {
+    MICV_REQUIRE(ctx && src && dst_levels, "micv_gaussian_pyramid: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0, "micv_gaussian_pyramid: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(levels >= 1 && levels <= 16 && (rows >> (levels - 1)) > 0 &&
+                     (cols >> (levels - 1)) > 0,
+                 "micv_gaussian_pyramid: %d levels do not fit a %dx%d image", levels, rows, cols);
+    MICV_REQUIRE(stride_ok(sstride, cols, 4), "micv_gaussian_pyramid: bad stride");
+    for (int l = 0; l < levels; l++)
+        MICV_REQUIRE(dst_levels[l] != nullptr, "micv_gaussian_pyramid: dst_levels[%d] is null", l);
+    MICV_HIP(hipSetDevice(ctx->device));
+    return launch_pyr_build(static_cast<hipStream_t>(stream), src, 0, (int)(sstride / 4), rows,
+                            cols, levels, dst_levels, 1);
+}
+
+int micv_rgb8_to_gray_f32_dev(micv_ctx *ctx, const uint8_t *rgb, int rows, int cols,
+                              size_t sstride, float *dst, size_t dstride, micv_stream stream) {
+    MICV_REQUIRE(ctx && rgb && dst, "micv_rgb8_to_gray_f32: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0, "micv_rgb8_to_gray_f32: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(sstride >= (size_t)cols * 3 && stride_ok(dstride, cols, 4),
+                 "micv_rgb8_to_gray_f32: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    rgb8_to_gray_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0,
+                          static_cast<hipStream_t>(stream)>>>(rgb, sstride, dst,
+                                                              (int)(dstride / 4), rows, cols);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+}  // extern "C"

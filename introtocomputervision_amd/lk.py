@@ -1,0 +1,117 @@
+"""`lk::` namespace of the reference (ProblemSets/ps5_cpp/include/OpticalFlow.h:5-19).
+
+Same names, argument meaning and defaults (winSize = 21); `levels` exposes the pyramid depth
+the reference hard-codes to 4 (OpticalFlow.cpp:127).  numpy inputs -> host entry points,
+torch CUDA tensors -> device entry points on the current stream.
+"""
+import numpy as np
+
+from . import _buf as B
+from ._capi import Context, check, lib
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def _ctx_for(a, ctx):
+    if ctx is not None:
+        return ctx
+    return default_context(a.device.index or 0 if B.is_dev(a) else 0)
+
+
+def calcOpticalFlow(prevImg, nextImg, winSize=21, ctx=None):
+    """lk::calcOpticalFlow (OpticalFlow.cpp:41-104) -> (u, v)."""
+    B.check2d(prevImg, np.float32, name="prevImg")
+    B.check2d(nextImg, np.float32, name="nextImg")
+    if tuple(prevImg.shape) != tuple(nextImg.shape):
+        raise ValueError("prevImg and nextImg differ in size")
+    if B.stride_bytes(prevImg) != B.stride_bytes(nextImg):
+        raise ValueError("prevImg and nextImg need the same row stride")
+    rows, cols = prevImg.shape
+    u = B.empty_like_shape(prevImg, (rows, cols))
+    v = B.empty_like_shape(prevImg, (rows, cols))
+    c = _ctx_for(prevImg, ctx)
+    if B.is_dev(prevImg):
+        check(lib.micv_lk_flow_dev(c.handle, B.ptr(prevImg), B.ptr(nextImg), rows, cols,
+                                   B.stride_bytes(prevImg), int(winSize), B.ptr(u), B.ptr(v),
+                                   B.stride_bytes(u), B.stream_of(prevImg)))
+    else:
+        check(lib.micv_lk_flow_host(c.handle, B.ptr(prevImg), B.ptr(nextImg), rows, cols,
+                                    B.stride_bytes(prevImg), int(winSize), B.ptr(u), B.ptr(v),
+                                    B.stride_bytes(u)))
+    return u, v
+
+
+def warp(src, du, dv, ctx=None):
+    """lk::warp (OpticalFlow.cpp:106-120) -> dst."""
+    for a, n in ((src, "src"), (du, "du"), (dv, "dv")):
+        B.check2d(a, np.float32, name=n)
+    if not (tuple(src.shape) == tuple(du.shape) == tuple(dv.shape)):
+        raise ValueError("src, du, dv differ in size")
+    if B.stride_bytes(du) != B.stride_bytes(dv):
+        raise ValueError("du and dv need the same row stride")
+    rows, cols = src.shape
+    dst = B.empty_like_shape(src, (rows, cols))
+    c = _ctx_for(src, ctx)
+    if B.is_dev(src):
+        check(lib.micv_lk_warp_dev(c.handle, B.ptr(src), B.stride_bytes(src), B.ptr(du), B.ptr(dv),
+                                   B.stride_bytes(du), rows, cols, B.ptr(dst), B.stride_bytes(dst),
+                                   B.stream_of(src)))
+    else:
+        check(lib.micv_lk_warp_host(c.handle, B.ptr(src), B.stride_bytes(src), B.ptr(du), B.ptr(dv),
+                                    B.stride_bytes(du), rows, cols, B.ptr(dst), B.stride_bytes(dst)))
+    return dst
+
+
+def calcOpticalFlowPyr(prevImg, nextImg, winSize=21, levels=4, ctx=None):
+    """lk::calcOpticalFlowPyr (OpticalFlow.cpp:122-167) -> (u, v); levels=4 is the reference."""
+    B.check2d(prevImg, np.float32, name="prevImg")
+    B.check2d(nextImg, np.float32, name="nextImg")
+    if tuple(prevImg.shape) != tuple(nextImg.shape):
+        raise ValueError("prevImg and nextImg differ in size")
+    if B.stride_bytes(prevImg) != B.stride_bytes(nextImg):
+        raise ValueError("prevImg and nextImg need the same row stride")
+    rows, cols = prevImg.shape
+    u = B.empty_like_shape(prevImg, (rows, cols))
+    v = B.empty_like_shape(prevImg, (rows, cols))
+    c = _ctx_for(prevImg, ctx)
+    if B.is_dev(prevImg):
+        check(lib.micv_lk_flow_pyr_dev(c.handle, B.ptr(prevImg), B.ptr(nextImg), rows, cols,
+                                       B.stride_bytes(prevImg), int(winSize), int(levels),
+                                       B.ptr(u), B.ptr(v), B.stride_bytes(u),
+                                       B.stream_of(prevImg)))
+    else:
+        check(lib.micv_lk_flow_pyr_host(c.handle, B.ptr(prevImg), B.ptr(nextImg), rows, cols,
+                                        B.stride_bytes(prevImg), int(winSize), int(levels),
+                                        B.ptr(u), B.ptr(v), B.stride_bytes(u)))
+    return u, v
+
+
+def calcOpticalFlowPyrBatch(prev, next_, winSize=21, levels=4, ctx=None, out=None, stream=None):
+    """Batched device form: prev/next are [B, rows, cols] f32 CUDA tensors (contiguous).
+    Returns (u, v) of the same shape.  One set of launches for the whole batch."""
+    import torch
+    if not (B.is_dev(prev) and prev.is_cuda and prev.dim() == 3 and prev.is_contiguous()
+            and prev.dtype == torch.float32):
+        raise ValueError("prev: need a contiguous [B, rows, cols] float32 CUDA tensor")
+    if tuple(next_.shape) != tuple(prev.shape) or not next_.is_contiguous() or next_.dtype != prev.dtype:
+        raise ValueError("next: must match prev")
+    nb, rows, cols = prev.shape
+    if out is None:
+        u = torch.empty_like(prev)
+        v = torch.empty_like(prev)
+    else:
+        u, v = out
+    c = _ctx_for(prev, ctx)
+    if stream is None:
+        stream = torch.cuda.current_stream(prev.device).cuda_stream
+    check(lib.micv_lk_flow_pyr_batch_dev(c.handle, prev.data_ptr(), next_.data_ptr(), nb,
+                                         rows * cols * 4, rows, cols, cols * 4, int(winSize),
+                                         int(levels), u.data_ptr(), v.data_ptr(), rows * cols * 4,
+                                         cols * 4, stream))
+    return u, v

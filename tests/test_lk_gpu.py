@@ -1,0 +1,190 @@
+"""Parity of the HIP Lucas-Kanade / pyramid path (through the C ABI) against the CPU oracle.
+
+Bar: BIT-EXACT (np.array_equal, so -0 == +0) -- tighter than the 1e-4 the north star asks
+for, and the only way to be safe at the det < tau discontinuity (OpticalFlow.cpp:82,95).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def rand_img(rows, cols, seed):
+    from introtocomputervision_amd import synth
+    return synth.smooth_noise(seed, rows, cols)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from introtocomputervision_amd import lk, pyr
+    return lk, pyr
+
+
+SIZES = [(48, 64), (37, 53), (96, 130), (135, 240), (17, 9), (64, 200)]
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_pyr_down_up(mods, rows, cols):
+    lk, pyr = mods
+    a = rand_img(rows, cols, 11)
+    assert np.array_equal(host(pyr.pyrDown(dev(a))), orc.pyr_down(a))
+    assert np.array_equal(host(pyr.pyrUp(dev(a))), orc.pyr_up(a))
+    # host flavour
+    assert np.array_equal(pyr.pyrDown(a), orc.pyr_down(a))
+    assert np.array_equal(pyr.pyrUp(a), orc.pyr_up(a))
+
+
+def test_gaussian_pyramid(mods):
+    lk, pyr = mods
+    a = rand_img(270, 300, 5)
+    got = pyr.makeGaussianPyramid(dev(a), 5)
+    exp = orc.gaussian_pyramid(a, 5)
+    assert [tuple(g.shape) for g in got] == [e.shape for e in exp]
+    for g, e in zip(got, exp):
+        assert np.array_equal(host(g), e)
+    got_h = pyr.makeGaussianPyramid(a, 4)
+    for g, e in zip(got_h, exp):
+        assert np.array_equal(g, e)
+
+
+@pytest.mark.parametrize("shape,dshape", [((134, 240), (135, 240)), ((20, 30), (41, 61)), ((33, 17), (32, 17))])
+def test_resize_linear(mods, shape, dshape):
+    lk, pyr = mods
+    a = rand_img(shape[0], shape[1], 3) * 0.37
+    assert np.array_equal(host(pyr.resizeLinear(dev(a), *dshape)), orc.resize_linear(a, *dshape))
+
+
+def test_rgb_to_gray(mods):
+    lk, pyr = mods
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (45, 67, 3), dtype=np.uint8)
+    assert np.array_equal(host(pyr.rgb8ToGray(dev(rgb))), orc.rgb8_to_gray(rgb))
+
+
+@pytest.mark.parametrize("rows,cols", SIZES)
+def test_warp(mods, rows, cols):
+    lk, pyr = mods
+    a = rand_img(rows, cols, 7)
+    rng = np.random.default_rng(rows * cols)
+    du = (rng.standard_normal((rows, cols)) * 3).astype(np.float32)
+    dv = (rng.standard_normal((rows, cols)) * 3).astype(np.float32)
+    du[0, 0] = 1e4  # far outside -> constant border
+    dv[-1, -1] = -1e4
+    exp = orc.lk_warp(a, du, dv)
+    assert np.array_equal(host(lk.warp(dev(a), dev(du), dev(dv))), exp)
+    assert np.array_equal(lk.warp(a, du, dv), exp)
+    zero = np.zeros_like(a)
+    assert np.array_equal(host(lk.warp(dev(a), dev(zero), dev(zero))), a)  # identity
+
+
+@pytest.mark.parametrize("win", [15, 7, 5, 21, 43])
+@pytest.mark.parametrize("rows,cols", [(48, 64), (37, 53), (96, 130), (70, 200)])
+def test_lk_single_level(mods, rows, cols, win):
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(1234 + win, rows, cols, dx=1, dy=-1)
+    eu, ev = orc.lk_flow(prev, nxt, win)
+    gu, gv = lk.calcOpticalFlow(dev(prev), dev(nxt), win)
+    assert np.array_equal(host(gu), eu)
+    assert np.array_equal(host(gv), ev)
+
+
+def test_lk_single_level_generic_vs_fused(mods, monkeypatch):
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(99, 135, 240, dx=1, dy=0)
+    eu, ev = orc.lk_flow(prev, nxt, 15)
+    monkeypatch.setenv("MICV_FORCE_GENERIC", "1")
+    gu, gv = lk.calcOpticalFlow(dev(prev), dev(nxt), 15)
+    monkeypatch.delenv("MICV_FORCE_GENERIC")
+    fu, fv = lk.calcOpticalFlow(dev(prev), dev(nxt), 15)
+    assert np.array_equal(host(gu), eu) and np.array_equal(host(gv), ev)
+    assert np.array_equal(host(fu), eu) and np.array_equal(host(fv), ev)
+
+
+def test_lk_host_flavour(mods):
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(5, 60, 80, dx=1, dy=1)
+    eu, ev = orc.lk_flow(prev, nxt, 15)
+    gu, gv = lk.calcOpticalFlow(prev, nxt, 15)
+    assert np.array_equal(gu, eu) and np.array_equal(gv, ev)
+
+
+@pytest.mark.parametrize("win", [15, 9])
+@pytest.mark.parametrize("rows,cols,levels", [(270, 480, 5), (135, 240, 4), (128, 192, 3), (101, 203, 4), (64, 64, 1)])
+def test_lk_pyr(mods, rows, cols, levels, win):
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(4242, rows, cols, dx=3, dy=-2)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, win, levels)
+    gu, gv = lk.calcOpticalFlowPyr(dev(prev), dev(nxt), win, levels)
+    assert np.array_equal(host(gu), eu)
+    assert np.array_equal(host(gv), ev)
+
+
+def test_lk_pyr_generic_path_matches(mods, monkeypatch):
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(77, 270, 480, dx=3, dy=-2)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, 15, 5)
+    monkeypatch.setenv("MICV_FORCE_GENERIC", "1")
+    gu, gv = lk.calcOpticalFlowPyr(dev(prev), dev(nxt), 15, 5)
+    monkeypatch.delenv("MICV_FORCE_GENERIC")
+    assert np.array_equal(host(gu), eu) and np.array_equal(host(gv), ev)
+
+
+def test_lk_pyr_batch_and_host(mods):
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    pairs = [synth.lk_pair(100 + i, 135, 240, dx=2 + i % 2, dy=-1) for i in range(3)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    gu, gv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, 4)
+    for i in range(3):
+        eu, ev = orc.lk_flow_pyr(prev[i], nxt[i], 15, 4)
+        assert np.array_equal(host(gu[i]), eu) and np.array_equal(host(gv[i]), ev)
+    hu, hv = lk.calcOpticalFlowPyr(prev[0], nxt[0], 15, 4)
+    eu, ev = orc.lk_flow_pyr(prev[0], nxt[0], 15, 4)
+    assert np.array_equal(hu, eu) and np.array_equal(hv, ev)
+
+
+def test_lk_pyr_1080p_known_translation(mods):
+    """Full BASELINE size (C2): size-independent property -- a (+3,-2) px circular shift must
+    come back as flow u ~ +3, v ~ -2 away from the borders.  The CPU oracle itself recovers
+    (2.88, -1.97) on this texture, so the KAT bound is 0.25 px (SURVEY 8d guessed 0.1)."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(0x5EED0005, 1080, 1920, dx=3, dy=-2)
+    gu, gv = lk.calcOpticalFlowPyr(dev(prev), dev(nxt), 15, 5)
+    u = host(gu)[64:-64, 64:-64]; v = host(gv)[64:-64, 64:-64]
+    assert abs(np.median(u) - 3.0) < 0.25 and abs(np.median(v) + 2.0) < 0.25
+    # linearity-free consistency: batch of 2 identical pairs gives identical fields
+    p2 = torch.stack([dev(prev), dev(prev)]); n2 = torch.stack([dev(nxt), dev(nxt)])
+    bu, bv = lk.calcOpticalFlowPyrBatch(p2, n2, 15, 5)
+    assert torch.equal(bu[0], gu) and torch.equal(bu[1], gu) and torch.equal(bv[1], gv)
+
+
+def test_bad_arguments(mods):
+    lk, pyr = mods
+    from introtocomputervision_amd._capi import MicvError
+    a = dev(np.zeros((32, 32), np.float32))
+    with pytest.raises(MicvError):
+        lk.calcOpticalFlow(a, a, 14)  # even window (assert at OpticalFlow.cpp:48)
+    with pytest.raises(MicvError):
+        lk.calcOpticalFlowPyr(a, a, 15, 7)  # 32 >> 6 == 0
+    with pytest.raises(ValueError):
+        lk.calcOpticalFlow(a, dev(np.zeros((16, 32), np.float32)), 15)
