@@ -172,8 +172,16 @@ int micv_sift_keypoints_host(micv_ctx *ctx, const float *gx, const float *gy, in
 
 #define MICV_STEREO_COLS_2R     1 /* window of (2r+1) rows x 2r columns, DisparitySSD.cu:84 */
 #define MICV_STEREO_MIN_SSD_5E6 2 /* leave -1 where best SSD >= 5e6, DisparitySSD.cu:16 */
+#define MICV_STEREO_SERIAL      4 /* serial::disparitySSD as written (DisparitySSD.cpp:35-61):
+                                     per-term round() into an int sum, search clamped to the padded
+                                     image, best = (99999999, 0) initially.  SSD only. */
 
-/* cuda::disparitySSD, ps2_cpp/lib/DisparitySSD.cu:143-207 (a12).  disp is rows x cols int8. */
+/* cuda::disparitySSD / serial::disparitySSD, ps2_cpp/lib/DisparitySSD.cu:143-207 and
+ * DisparitySSD.cpp:9-62 (a12).  disp is rows x cols int8 (CV_8SC1), dstride in bytes.
+ * flags = 0: CUDA-path semantics with the window corrected to (2r+1)^2 columns (clamp-to-edge
+ * addressing, every d in [min,max] tried in ascending order, strict '<').
+ * flags = COLS_2R | MIN_SSD_5E6: the CUDA kernel exactly as written.  flags = SERIAL: the CPU
+ * function exactly as written. */
 int micv_disparity_ssd_dev(micv_ctx *ctx, const float *left, const float *right, int rows,
                            int cols, size_t stride, int window_rad, int min_disparity,
                            int max_disparity, int flags, int8_t *disp, size_t dstride,

@@ -1,0 +1,262 @@
+// harris.hip -- ps4: Harris response (a9), threshold + NMS + ordered corner list (a10),
+// SIFT-style keypoint angles (a11).
+#include "compact.hpp"
+#include "kernels.hpp"
+
+namespace micv {
+
+// ---- shared: scan of chunk counts (one workgroup) -----------------------------------------
+__global__ __launch_bounds__(1024) void compact_scan_kernel(const int *__restrict__ chunk_count,
+                                                             int64_t *__restrict__ chunk_off,
+                                                             int nchunks,
+                                                             int64_t *__restrict__ count) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nchunks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int64_t v = i < nchunks ? chunk_count[i] : 0;
+        int64_t incl = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const int64_t carry = carry_s;
+        if (i < nchunks) chunk_off[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = carry_s;
+}
+
+int launch_compact_scan(hipStream_t s, const int *chunk_count, int64_t *chunk_off, int nchunks,
+                        int64_t *count) {
+    compact_scan_kernel<<<1, 1024, 0, s>>>(chunk_count, chunk_off, nchunks, count);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+// ---- a9: corner response ---------------------------------------------------------------------
+// Tile 64x16 outputs; Ix, Iy staged in LDS with a clamped (2r)-halo (Harris.cpp:73-76 /
+// texture clamp on the CUDA path).  Accumulation exactly as Harris.cu:36-43,85: per tap
+// M = fma(w, I, M) in (wy, wx) raster order, w = g[wy]*g[wx] (float), then :87-91 in float.
+__global__ __launch_bounds__(256) void harris_response_kernel(const float *__restrict__ gx,
+                                                               const float *__restrict__ gy,
+                                                               int gstride, int rows, int cols,
+                                                               int r, Taps g, float alpha,
+                                                               float *__restrict__ resp,
+                                                               int rstride) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TW = 64, TH = 16;
+    const int RW = TW + 2 * r, RH = TH + 2 * r;
+    float *sx = lds, *sy = lds + RW * RH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int i = threadIdx.x; i < RW * RH; i += 256) {
+        const int ly = i / RW, lx = i - ly * RW;
+        const int yy = clampi(y0 - r + ly, 0, rows - 1), xx = clampi(x0 - r + lx, 0, cols - 1);
+        sx[i] = gx[(size_t)yy * gstride + xx];
+        sy[i] = gy[(size_t)yy * gstride + xx];
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63;
+    const int x = x0 + c;
+    for (int ry = threadIdx.x >> 6; ry < TH; ry += 4) {
+        const int y = y0 + ry;
+        if (x >= cols || y >= rows) continue;
+        float mxx = 0.f, mxy = 0.f, myy = 0.f;
+        for (int wy = 0; wy <= 2 * r; wy++) {
+            const float gw = g.k[wy];
+            const float *px = sx + (ry + wy) * RW + c, *py = sy + (ry + wy) * RW + c;
+            for (int wx = 0; wx <= 2 * r; wx++) {
+                const float ix = px[wx], iy = py[wx];
+                const float w = gw * g.k[wx];
+                mxx = fmaf(w, ix * ix, mxx);
+                mxy = fmaf(w, ix * iy, mxy);
+                myy = fmaf(w, iy * iy, myy);
+            }
+        }
+        const float trace = mxx + myy;
+        const float det = mxx * myy - mxy * mxy;
+        resp[(size_t)y * rstride + x] = det - alpha * trace * trace;
+    }
+}
+
+// ---- a10: threshold + non-maximum suppression ----------------------------------------------
+// One thread per pixel; only pixels with R >= threshold scan their (2d+1)^2 clamped window
+// (strictly greater than every OTHER pixel, Harris.cpp:119-135).  flag marks kept maxima for
+// the ordered compaction that follows.
+__global__ __launch_bounds__(256) void harris_nms_kernel(const float *__restrict__ resp,
+                                                          int rstride, int rows, int cols,
+                                                          double threshold, int d,
+                                                          float *__restrict__ corners, int cstride,
+                                                          uint8_t *__restrict__ flag) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const float v = resp[(size_t)y * rstride + x];
+    bool keep = false;
+    if ((double)v >= threshold) {
+        keep = true;
+        for (int wy = -d; wy <= d && keep; wy++) {
+            const int cy = clampi(y + wy, 0, rows - 1);
+            const float *row = resp + (size_t)cy * rstride;
+            for (int wx = -d; wx <= d; wx++) {
+                const int cx = clampi(x + wx, 0, cols - 1);
+                if (cy == y && cx == x) continue;
+                if (v <= row[cx]) {
+                    keep = false;
+                    break;
+                }
+            }
+        }
+    }
+    corners[(size_t)y * cstride + x] = keep ? v : 0.f;
+    flag[(size_t)y * cols + x] = keep ? 1 : 0;
+}
+
+struct FlagPred {
+    const uint8_t *flag;
+    __device__ bool operator()(int64_t i) const { return flag[i] != 0; }
+};
+
+// linear index -> (y, x) pairs, Harris.cu:314-318 (Conv1Dto2D).
+__global__ void idx_to_yx_kernel(int32_t *__restrict__ locs, const int32_t *__restrict__ idx,
+                                 const int64_t *__restrict__ count, int64_t cap, int cols) {
+    const int64_t n = *count < cap ? *count : cap;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = idx[i];
+        locs[2 * i] = v / cols;
+        locs[2 * i + 1] = v % cols;
+    }
+}
+
+// ---- a11 ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sift_angles_kernel(const float *__restrict__ gx,
+                                                           const float *__restrict__ gy,
+                                                           int gstride, int rows, int cols,
+                                                           float *__restrict__ ang, int astride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    ang[(size_t)y * astride + x] =
+        atan2f(gy[(size_t)y * gstride + x], gx[(size_t)y * gstride + x]);  // Descriptors.cpp:22
+}
+
+__global__ void sift_keypoints_kernel(const float *__restrict__ gx, const float *__restrict__ gy,
+                                      int gstride, const int32_t *__restrict__ locs, int64_t n,
+                                      float size, float *__restrict__ kp) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int y = locs[2 * i], x = locs[2 * i + 1];
+    const float PI = 3.1415921636f;  // sic, Descriptors.cpp:5
+    const float a = atan2f(gy[(size_t)y * gstride + x], gx[(size_t)y * gstride + x]) * 180.f / PI;
+    kp[4 * i] = (float)x;  // cv::KeyPoint(x = corner.second, y = corner.first, size, angle), :45
+    kp[4 * i + 1] = (float)y;
+    kp[4 * i + 2] = size;
+    kp[4 * i + 3] = a;
+}
+
+}  // namespace micv
+
+using namespace micv;
+
+extern "C" {
+
+int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                             size_t gstride, int win, double sigma, float alpha, float *resp,
+                             size_t rstride, micv_stream stream) {
+    MICV_REQUIRE(ctx && gx && gy && resp, "micv_harris_response: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0, "micv_harris_response: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(win >= 1 && (win & 1) && win <= kMaxWin,
+                 "micv_harris_response: window %d must be odd and <= %d", win, kMaxWin);
+    MICV_REQUIRE(sigma > 0, "micv_harris_response: sigma must be > 0");
+    MICV_REQUIRE(stride_ok(gstride, cols, 4) && stride_ok(rstride, cols, 4),
+                 "micv_harris_response: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    Taps g;
+    gaussian_taps(win, sigma, &g);  // cv::getGaussianKernel(win, sigma, CV_32F), Harris.cpp:61
+    const int r = win / 2;
+    const size_t lds = (size_t)(64 + 2 * r) * (16 + 2 * r) * 2 * sizeof(float);
+    static thread_local int attr_dev = -1;
+    if (attr_dev != ctx->device) {
+        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&harris_response_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_dev = ctx->device;
+    }
+    harris_response_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, lds,
+                             static_cast<hipStream_t>(stream)>>>(
+        gx, gy, (int)(gstride / 4), rows, cols, r, g, alpha, resp, (int)(rstride / 4));
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,
+                           double threshold, int min_distance, float *corners, size_t cstride,
+                           int32_t *locs_yx, int64_t cap, int64_t *count, micv_stream stream) {
+    MICV_REQUIRE(ctx && resp && corners && count, "micv_harris_refine: null argument");
+    MICV_REQUIRE(locs_yx || cap == 0, "micv_harris_refine: locs_yx is null");
+    MICV_REQUIRE(rows > 0 && cols > 0 && (int64_t)rows * cols < ((int64_t)1 << 31),
+                 "micv_harris_refine: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(min_distance >= 0 && cap >= 0, "micv_harris_refine: bad min_distance / cap");
+    MICV_REQUIRE(stride_ok(rstride, cols, 4) && stride_ok(cstride, cols, 4),
+                 "micv_harris_refine: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)rows * cols;
+    void *scratch;
+    MICV_TRY(ctx->reserve(Carver::need(n, 1) + Carver::need(cap, 4) + compact_scratch_bytes(n),
+                          &scratch));
+    Carver c(scratch);
+    uint8_t *flag = c.take<uint8_t>(n);
+    int32_t *idx = c.take<int32_t>(cap);
+    harris_nms_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(
+        resp, (int)(rstride / 4), rows, cols, threshold, min_distance, corners, (int)(cstride / 4),
+        flag);
+    MICV_LAUNCH_CHECK();
+    MICV_TRY(ordered_compact(s, FlagPred{flag}, n, idx, cap, count, c.base + c.off));
+    if (cap > 0) {
+        idx_to_yx_kernel<<<64, 256, 0, s>>>(locs_yx, idx, count, cap, cols);
+        MICV_LAUNCH_CHECK();
+    }
+    return MICV_OK;
+}
+
+int micv_sift_angles_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                         size_t gstride, float *angles, size_t astride, micv_stream stream) {
+    MICV_REQUIRE(ctx && gx && gy && angles, "micv_sift_angles: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0, "micv_sift_angles: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(stride_ok(gstride, cols, 4) && stride_ok(astride, cols, 4),
+                 "micv_sift_angles: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    sift_angles_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0,
+                         static_cast<hipStream_t>(stream)>>>(gx, gy, (int)(gstride / 4), rows, cols,
+                                                             angles, (int)(astride / 4));
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int micv_sift_keypoints_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                            size_t gstride, const int32_t *locs_yx, int64_t n, float size,
+                            float *kp_xysa, micv_stream stream) {
+    MICV_REQUIRE(ctx && gx && gy, "micv_sift_keypoints: null argument");
+    MICV_REQUIRE(n >= 0 && (n == 0 || (locs_yx && kp_xysa)), "micv_sift_keypoints: bad list");
+    MICV_REQUIRE(rows > 0 && cols > 0 && stride_ok(gstride, cols, 4),
+                 "micv_sift_keypoints: bad size / stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    if (n == 0) return MICV_OK;
+    sift_keypoints_kernel<<<(unsigned)((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        gx, gy, (int)(gstride / 4), locs_yx, n, size, kp_xysa);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+}  // extern "C"

@@ -195,3 +195,173 @@ int micv_sobel_host(micv_ctx *ctx, const float *src, int rows, int cols, size_t 
 }
 
 }  // extern "C"
+
+// ---- ps4 / ps2 / ps1 host flavours -----------------------------------------------------------
+extern "C" {
+
+int micv_harris_response_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                              size_t gstride, int win, double sigma, float alpha, float *resp,
+                              size_t rstride) {
+    HOST_PROLOGUE("micv_harris_response_host");
+    MICV_REQUIRE(gx && gy && resp && rows > 0 && cols > 0, "micv_harris_response_host: bad argument");
+    MICV_REQUIRE(stride_ok(gstride, cols, 4) && stride_ok(rstride, cols, 4),
+                 "micv_harris_response_host: bad stride");
+    const size_t rb = (size_t)cols * 4, n = rb * rows;
+    DevBuf dx(n), dy(n), dr(n);
+    MICV_ALLOC_OK(dx); MICV_ALLOC_OK(dy); MICV_ALLOC_OK(dr);
+    MICV_TRY(up2d(dx.p, gx, gstride, rb, rows, s));
+    MICV_TRY(up2d(dy.p, gy, gstride, rb, rows, s));
+    MICV_TRY(micv_harris_response_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb, win,
+                                      sigma, alpha, dr.as<float>(), rb, s));
+    MICV_TRY(down2d(resp, rstride, dr.p, rb, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_harris_refine_host(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,
+                            double threshold, int min_distance, float *corners, size_t cstride,
+                            int32_t *locs_yx, int64_t cap, int64_t *count) {
+    HOST_PROLOGUE("micv_harris_refine_host");
+    MICV_REQUIRE(resp && corners && count && rows > 0 && cols > 0 && cap >= 0,
+                 "micv_harris_refine_host: bad argument");
+    MICV_REQUIRE(stride_ok(rstride, cols, 4) && stride_ok(cstride, cols, 4),
+                 "micv_harris_refine_host: bad stride");
+    const size_t rb = (size_t)cols * 4, n = rb * rows;
+    DevBuf dr(n), dc(n), dl((size_t)cap * 8), dn(8);
+    MICV_ALLOC_OK(dr); MICV_ALLOC_OK(dc); MICV_ALLOC_OK(dl); MICV_ALLOC_OK(dn);
+    MICV_TRY(up2d(dr.p, resp, rstride, rb, rows, s));
+    MICV_TRY(micv_harris_refine_dev(ctx, dr.as<float>(), rows, cols, rb, threshold, min_distance,
+                                    dc.as<float>(), rb, dl.as<int32_t>(), cap, dn.as<int64_t>(), s));
+    MICV_TRY(down2d(corners, cstride, dc.p, rb, rows, s));
+    MICV_HIP(hipMemcpyAsync(count, dn.p, 8, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    const int64_t take = *count < cap ? *count : cap;
+    if (take > 0) MICV_HIP(hipMemcpy(locs_yx, dl.p, (size_t)take * 8, hipMemcpyDeviceToHost));
+    return MICV_OK;
+}
+
+int micv_sift_angles_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                          size_t gstride, float *angles, size_t astride) {
+    HOST_PROLOGUE("micv_sift_angles_host");
+    MICV_REQUIRE(gx && gy && angles && rows > 0 && cols > 0, "micv_sift_angles_host: bad argument");
+    MICV_REQUIRE(stride_ok(gstride, cols, 4) && stride_ok(astride, cols, 4),
+                 "micv_sift_angles_host: bad stride");
+    const size_t rb = (size_t)cols * 4, n = rb * rows;
+    DevBuf dx(n), dy(n), da(n);
+    MICV_ALLOC_OK(dx); MICV_ALLOC_OK(dy); MICV_ALLOC_OK(da);
+    MICV_TRY(up2d(dx.p, gx, gstride, rb, rows, s));
+    MICV_TRY(up2d(dy.p, gy, gstride, rb, rows, s));
+    MICV_TRY(micv_sift_angles_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb,
+                                  da.as<float>(), rb, s));
+    MICV_TRY(down2d(angles, astride, da.p, rb, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_sift_keypoints_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                             size_t gstride, const int32_t *locs_yx, int64_t n, float size,
+                             float *kp_xysa) {
+    HOST_PROLOGUE("micv_sift_keypoints_host");
+    MICV_REQUIRE(gx && gy && rows > 0 && cols > 0 && n >= 0 && (n == 0 || (locs_yx && kp_xysa)),
+                 "micv_sift_keypoints_host: bad argument");
+    MICV_REQUIRE(stride_ok(gstride, cols, 4), "micv_sift_keypoints_host: bad stride");
+    for (int64_t i = 0; i < n; i++)
+        MICV_REQUIRE((unsigned)locs_yx[2 * i] < (unsigned)rows && (unsigned)locs_yx[2 * i + 1] < (unsigned)cols,
+                     "micv_sift_keypoints_host: corner %lld outside the image", (long long)i);
+    if (n == 0) return MICV_OK;
+    const size_t rb = (size_t)cols * 4, bytes = rb * rows;
+    DevBuf dx(bytes), dy(bytes), dl((size_t)n * 8), dk((size_t)n * 16);
+    MICV_ALLOC_OK(dx); MICV_ALLOC_OK(dy); MICV_ALLOC_OK(dl); MICV_ALLOC_OK(dk);
+    MICV_TRY(up2d(dx.p, gx, gstride, rb, rows, s));
+    MICV_TRY(up2d(dy.p, gy, gstride, rb, rows, s));
+    MICV_HIP(hipMemcpyAsync(dl.p, locs_yx, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    MICV_TRY(micv_sift_keypoints_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb,
+                                     dl.as<int32_t>(), n, size, dk.as<float>(), s));
+    MICV_HIP(hipMemcpyAsync(kp_xysa, dk.p, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+static int stereo_host(bool ncc, micv_ctx *ctx, const float *left, const float *right, int rows,
+                       int cols, size_t stride, int rad, int min_d, int max_d, int flags,
+                       int8_t *disp, size_t dstride) {
+    HOST_PROLOGUE("micv_disparity_host");
+    MICV_REQUIRE(left && right && disp && rows > 0 && cols > 0, "micv_disparity_host: bad argument");
+    MICV_REQUIRE(stride_ok(stride, cols, 4) && dstride >= (size_t)cols, "micv_disparity_host: bad stride");
+    const size_t rb = (size_t)cols * 4, n = rb * rows;
+    DevBuf dl(n), dr(n), dd((size_t)rows * cols);
+    MICV_ALLOC_OK(dl); MICV_ALLOC_OK(dr); MICV_ALLOC_OK(dd);
+    MICV_TRY(up2d(dl.p, left, stride, rb, rows, s));
+    MICV_TRY(up2d(dr.p, right, stride, rb, rows, s));
+    if (ncc)
+        MICV_TRY(micv_disparity_ncorr_dev(ctx, dl.as<float>(), dr.as<float>(), rows, cols, rb, rad,
+                                          min_d, max_d, flags, dd.as<int8_t>(), cols, s));
+    else
+        MICV_TRY(micv_disparity_ssd_dev(ctx, dl.as<float>(), dr.as<float>(), rows, cols, rb, rad,
+                                        min_d, max_d, flags, dd.as<int8_t>(), cols, s));
+    MICV_TRY(down2d(disp, dstride, dd.p, (size_t)cols, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_disparity_ssd_host(micv_ctx *ctx, const float *left, const float *right, int rows,
+                            int cols, size_t stride, int window_rad, int min_disparity,
+                            int max_disparity, int flags, int8_t *disp, size_t dstride) {
+    return stereo_host(false, ctx, left, right, rows, cols, stride, window_rad, min_disparity,
+                       max_disparity, flags, disp, dstride);
+}
+int micv_disparity_ncorr_host(micv_ctx *ctx, const float *left, const float *right, int rows,
+                              int cols, size_t stride, int window_rad, int min_disparity,
+                              int max_disparity, int flags, int8_t *disp, size_t dstride) {
+    return stereo_host(true, ctx, left, right, rows, cols, stride, window_rad, min_disparity,
+                       max_disparity, flags, disp, dstride);
+}
+
+int micv_hough_lines_host(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
+                          unsigned rho_bin, unsigned theta_bin, int32_t *acc) {
+    HOST_PROLOGUE("micv_hough_lines_host");
+    MICV_REQUIRE(mask && acc && mstride >= (size_t)cols, "micv_hough_lines_host: bad argument");
+    int rb, tb;
+    MICV_TRY(micv_hough_lines_dims(rows, cols, rho_bin, theta_bin, &rb, &tb));
+    DevBuf dm((size_t)rows * cols), da((size_t)rb * tb * 4);
+    MICV_ALLOC_OK(dm); MICV_ALLOC_OK(da);
+    MICV_TRY(up2d(dm.p, mask, mstride, (size_t)cols, rows, s));
+    MICV_TRY(micv_hough_lines_dev(ctx, dm.as<uint8_t>(), rows, cols, cols, rho_bin, theta_bin,
+                                  da.as<int32_t>(), s));
+    MICV_HIP(hipMemcpyAsync(acc, da.p, (size_t)rb * tb * 4, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_hough_circles_host(micv_ctx *ctx, const uint8_t *mask, int rows, int cols,
+                            size_t mstride, unsigned radius, int32_t *acc) {
+    HOST_PROLOGUE("micv_hough_circles_host");
+    MICV_REQUIRE(mask && acc && rows > 0 && cols > 0 && mstride >= (size_t)cols,
+                 "micv_hough_circles_host: bad argument");
+    DevBuf dm((size_t)rows * cols), da((size_t)rows * cols * 4);
+    MICV_ALLOC_OK(dm); MICV_ALLOC_OK(da);
+    MICV_TRY(up2d(dm.p, mask, mstride, (size_t)cols, rows, s));
+    MICV_TRY(micv_hough_circles_dev(ctx, dm.as<uint8_t>(), rows, cols, cols, radius,
+                                    da.as<int32_t>(), s));
+    MICV_HIP(hipMemcpyAsync(acc, da.p, (size_t)rows * cols * 4, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
+                          unsigned num_peaks, int threshold, uint32_t *peaks_rc, int64_t *count) {
+    HOST_PROLOGUE("micv_hough_peaks_host");
+    MICV_REQUIRE(acc && count && rows > 0 && cols > 0 && (peaks_rc || num_peaks == 0),
+                 "micv_hough_peaks_host: bad argument");
+    DevBuf da((size_t)rows * cols * 4), dp((size_t)num_peaks * 8 + 8), dn(8);
+    MICV_ALLOC_OK(da); MICV_ALLOC_OK(dp); MICV_ALLOC_OK(dn);
+    MICV_HIP(hipMemcpyAsync(da.p, acc, (size_t)rows * cols * 4, hipMemcpyHostToDevice, s));
+    MICV_TRY(micv_hough_peaks_dev(ctx, da.as<int32_t>(), rows, cols, num_peaks, threshold,
+                                  dp.as<uint32_t>(), dn.as<int64_t>(), s));
+    MICV_HIP(hipMemcpyAsync(count, dn.p, 8, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    if (*count > 0) MICV_HIP(hipMemcpy(peaks_rc, dp.p, (size_t)*count * 8, hipMemcpyDeviceToHost));
+    return MICV_OK;
+}
+
+}  // extern "C"

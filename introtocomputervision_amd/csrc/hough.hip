@@ -1,0 +1,327 @@
+// hough.hip -- ps1: Hough line / circle accumulators (a14, a15) and peak finding (a16).
+//
+//  * edge mask -> ordered (row-major) point list: compact.hpp (replaces K1 + thrust::copy_if,
+//    Hough.cu:173-232, without the two full-image uint2 scratch vectors)
+//  * lines: one workgroup per (theta bin, point chunk) votes into a rho histogram that lives
+//    in LDS (<= 16 K bins) and is flushed once with global integer atomics -- the reference
+//    issues one global atomic per (point, theta) (Hough.cu:57).  Integer sums: order-free.
+//  * trig: host-built float tables (correctly rounded double cos/sin of the float radian,
+//    cast to float) replace the reference's __sincosf (Hough.cu:53), which is a hardware
+//    approximation and not reproducible off NVIDIA parts.
+//  * peaks: up/left 2x2 "local max" flags -> ordered candidate list -> the top num_peaks by
+//    (votes desc, index asc) -- the order thrust::stable_sort(greater) produces (Hough.cu:402).
+#include <cmath>
+
+#include "compact.hpp"
+#include "kernels.hpp"
+
+namespace micv {
+
+struct MaskPred {
+    const uint8_t *mask;
+    int cols;
+    size_t stride;
+    __device__ bool operator()(int64_t i) const {
+        const int y = (int)(i / cols), x = (int)(i - (int64_t)y * cols);
+        return mask[(size_t)y * stride + x] != 0;  // IsNonzero, Hough.cu:183-187
+    }
+};
+
+struct TrigTable {
+    float c[360], s[360];
+};
+
+// degToRad (Hough.cu:20-24): float theta * double PI / 180.f -> float.
+static void build_trig(int theta0, TrigTable *t) {
+    for (int i = 0; i < 360; i++) {
+        const float rad = (float)((double)(float)(theta0 + i) * 3.14159265 / 180.f);
+        t->c[i] = (float)std::cos((double)rad);
+        t->s[i] = (float)std::sin((double)rad);
+    }
+}
+
+// grid (theta bins, chunks); dynamic LDS = rho_bins ints.
+__global__ __launch_bounds__(256) void hough_lines_kernel(const int32_t *__restrict__ pts,
+                                                           const int64_t *__restrict__ npts_p,
+                                                           int cols, const float *__restrict__ ct,
+                                                           const float *__restrict__ st,
+                                                           float diag, unsigned rho_bin,
+                                                           unsigned theta_bin, int rho_bins,
+                                                           int theta_bins,
+                                                           int32_t *__restrict__ acc) {
+    extern __shared__ int hist[];
+    const int tb = blockIdx.x;
+    const int theta = -90 + tb * (int)theta_bin;  // Hough.cu:51
+    for (int i = threadIdx.x; i < rho_bins; i += 256) hist[i] = 0;
+    __syncthreads();
+    const float c = ct[theta + 90], s = st[theta + 90];
+    const int thetaBin = (int)roundf(((float)theta - -90.f) / (float)theta_bin);  // :56
+    const int64_t npts = *npts_p;
+    const int64_t per = (npts + gridDim.y - 1) / gridDim.y;
+    const int64_t lo = blockIdx.y * per, hi = lo + per < npts ? lo + per : npts;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const int32_t p = pts[i];
+        const int y = p / cols, x = p - y * cols;
+        const float rho = roundf((float)x * c + (float)y * s) + diag;  // :54
+        const int rhoBin = (int)roundf(rho / (float)rho_bin);            // :55
+        if ((unsigned)rhoBin < (unsigned)rho_bins) atomicAdd(&hist[rhoBin], 1);
+    }
+    __syncthreads();
+    if ((unsigned)thetaBin >= (unsigned)theta_bins) return;
+    for (int i = threadIdx.x; i < rho_bins; i += 256) {
+        const int v = hist[i];
+        if (v) atomicAdd(&acc[(size_t)i * theta_bins + thetaBin], v);
+    }
+}
+
+// Fallback for accumulators whose rho axis does not fit LDS: global atomics per vote.
+__global__ __launch_bounds__(256) void hough_lines_global_kernel(
+    const int32_t *__restrict__ pts, const int64_t *__restrict__ npts_p, int cols,
+    const float *__restrict__ ct, const float *__restrict__ st, float diag, unsigned rho_bin,
+    unsigned theta_bin, int rho_bins, int theta_bins, int32_t *__restrict__ acc) {
+    const int64_t npts = *npts_p;
+    const int tb = blockIdx.y;
+    const int theta = -90 + tb * (int)theta_bin;
+    const float c = ct[theta + 90], s = st[theta + 90];
+    const int thetaBin = (int)roundf(((float)theta - -90.f) / (float)theta_bin);
+    if ((unsigned)thetaBin >= (unsigned)theta_bins) return;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < npts; i += (int64_t)gridDim.x * 256) {
+        const int32_t p = pts[i];
+        const int y = p / cols, x = p - y * cols;
+        const float rho = roundf((float)x * c + (float)y * s) + diag;
+        const int rhoBin = (int)roundf(rho / (float)rho_bin);
+        if ((unsigned)rhoBin < (unsigned)rho_bins)
+            atomicAdd(&acc[(size_t)rhoBin * theta_bins + thetaBin], 1);
+    }
+}
+
+// float -> unsigned the way the reference's device code converts it (saturating truncation).
+__device__ __forceinline__ unsigned f2u_sat(float v) {
+    if (!(v > 0.f)) return 0u;
+    if (v >= 4294967296.f) return 0xFFFFFFFFu;
+    return (unsigned)v;
+}
+
+// One thread per (point, theta); Hough.cu:85-93.
+__global__ __launch_bounds__(256) void hough_circles_kernel(const int32_t *__restrict__ pts,
+                                                             const int64_t *__restrict__ npts_p,
+                                                             int rows, int cols,
+                                                             const float *__restrict__ ct,
+                                                             const float *__restrict__ st,
+                                                             float radius,
+                                                             int32_t *__restrict__ acc) {
+    const int64_t npts = *npts_p;
+    const int64_t total = npts * 360;
+    for (int64_t w = blockIdx.x * 256ll + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
+        const int64_t i = w / 360;
+        const int t = (int)(w - i * 360);
+        const int32_t p = pts[i];
+        const int y = p / cols, x = p - y * cols;
+        const unsigned a = f2u_sat((float)x - radius * ct[t]);
+        const unsigned b = f2u_sat((float)y - radius * st[t]);
+        if (a < (unsigned)cols && b < (unsigned)rows && a > 0 && b > 0)
+            atomicAdd(&acc[(size_t)b * cols + a], 1);
+    }
+}
+
+// Hough.cu:148-157 + MaskAndThreshold :239-249.
+struct PeakPred {
+    const int32_t *acc;
+    int rows, cols, threshold;
+    __device__ bool operator()(int64_t i) const {
+        const int ty = (int)(i / cols), tx = (int)(i - (int64_t)ty * cols);
+        const int v = acc[i];
+        if (v < threshold) return false;
+        const int y1 = rows - 1 < ty + 1 ? rows - 1 : ty + 1;  // exclusive bounds, as written
+        const int x1 = cols - 1 < tx + 1 ? cols - 1 : tx + 1;
+        for (int y = ty - 1 > 0 ? ty - 1 : 0; y < y1; y++)
+            for (int x = tx - 1 > 0 ? tx - 1 : 0; x < x1; x++)
+                if (acc[(size_t)y * cols + x] > v) return false;
+        return true;
+    }
+};
+
+// Selection round k: the largest key strictly below the key chosen in round k-1.
+// key = (votes biased to unsigned) << 32 | (0xFFFFFFFF - index): larger = more votes, then
+// smaller index -- the stable descending order.
+__device__ __forceinline__ unsigned long long peak_key(int votes, uint32_t idx) {
+    return ((unsigned long long)((uint32_t)votes ^ 0x80000000u) << 32) | (0xFFFFFFFFu - idx);
+}
+
+__global__ __launch_bounds__(256) void peak_select_kernel(const int32_t *__restrict__ acc,
+                                                           const int32_t *__restrict__ cand,
+                                                           const int64_t *__restrict__ ncand_p,
+                                                           int64_t cap,
+                                                           unsigned long long *__restrict__ sel,
+                                                           int k) {
+    __shared__ unsigned long long wmax[4];
+    const int64_t n = *ncand_p < cap ? *ncand_p : cap;
+    const unsigned long long bound = k == 0 ? ~0ull : sel[k - 1];
+    unsigned long long m = 0;
+    if (k == 0 || bound != 0) {
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const uint32_t idx = (uint32_t)cand[i];
+            const unsigned long long key = peak_key(acc[idx], idx);
+            if (key < bound && key > m) m = key;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(m, d);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) m = wmax[w] > m ? wmax[w] : m;
+        if (m) atomicMax(&sel[k], m);
+    }
+}
+
+__global__ void peak_emit_kernel(const unsigned long long *__restrict__ sel, unsigned num_peaks,
+                                 int cols, uint32_t *__restrict__ peaks_rc,
+                                 int64_t *__restrict__ count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t n = 0;
+    for (unsigned k = 0; k < num_peaks; k++) {
+        if (sel[k] == 0) break;
+        const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(sel[k] & 0xFFFFFFFFull);
+        peaks_rc[2 * n] = idx / (uint32_t)cols;      // rho = row
+        peaks_rc[2 * n + 1] = idx % (uint32_t)cols;  // theta = col
+        n++;
+    }
+    *count = n;
+}
+
+static size_t hough_diag(int rows, int cols) {
+    return (size_t)std::ceil(std::sqrt((double)(rows * rows + cols * cols)));  // Hough.cu:258-259
+}
+
+}  // namespace micv
+
+using namespace micv;
+
+extern "C" {
+
+int micv_hough_lines_dims(int rows, int cols, unsigned rho_bin, unsigned theta_bin, int *rho_bins,
+                          int *theta_bins) {
+    MICV_REQUIRE(rows > 0 && cols > 0 && rows <= 32767 && cols <= 32767 && rho_bin > 0 &&
+                     theta_bin > 0 && rho_bins && theta_bins,
+                 "micv_hough_lines_dims: bad argument");
+    const size_t max_dist = hough_diag(rows, cols);
+    const size_t rb = (size_t)std::ceil((float)(2 * max_dist) / (float)rho_bin);  // :260
+    const size_t tb = (size_t)std::ceil(180.f / (float)theta_bin);                // :261-262
+    *rho_bins = (int)(rb < 1 ? 1 : rb);
+    *theta_bins = (int)(tb < 1 ? 1 : tb);
+    return MICV_OK;
+}
+
+static int hough_points(micv_ctx *ctx, hipStream_t s, const uint8_t *mask, int rows, int cols,
+                        size_t mstride, size_t extra_bytes, int32_t **pts, int64_t **npts,
+                        char **extra) {
+    const int64_t n = (int64_t)rows * cols;
+    void *scratch;
+    MICV_TRY(ctx->reserve(Carver::need(n, 4) + Carver::need(1, 8) + compact_scratch_bytes(n) +
+                              ((extra_bytes + 255) & ~size_t(255)),
+                          &scratch));
+    Carver c(scratch);
+    *pts = c.take<int32_t>(n);
+    *npts = c.take<int64_t>(1);
+    *extra = c.take<char>(extra_bytes);
+    return ordered_compact(s, MaskPred{mask, cols, mstride}, n, *pts, n, *npts, c.base + c.off);
+}
+
+int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
+                         unsigned rho_bin, unsigned theta_bin, int32_t *acc, micv_stream stream) {
+    MICV_REQUIRE(ctx && mask && acc, "micv_hough_lines: null argument");
+    MICV_REQUIRE(mstride >= (size_t)cols, "micv_hough_lines: bad stride");
+    int rb, tb;
+    MICV_TRY(micv_hough_lines_dims(rows, cols, rho_bin, theta_bin, &rb, &tb));
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t *pts;
+    int64_t *npts;
+    char *extra;
+    MICV_TRY(hough_points(ctx, s, mask, rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
+    TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
+    static TrigTable ht;
+    static bool ht_ok = false;
+    if (!ht_ok) {
+        build_trig(-90, &ht);
+        ht_ok = true;
+    }
+    MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
+    MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rb * tb * sizeof(int32_t), s));
+    const float diag = (float)hough_diag(rows, cols);
+    // theta loop `for (theta = -90; theta < 90; theta += bin)` has ceil(180/bin) iterations = tb
+    const int n_theta = (int)((180 + theta_bin - 1) / theta_bin);
+    if ((size_t)rb * 4 <= 64 * 1024) {
+        hough_lines_kernel<<<dim3(n_theta, 16), 256, (size_t)rb * 4, s>>>(
+            pts, npts, cols, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
+    } else {
+        hough_lines_global_kernel<<<dim3(64, n_theta), 256, 0, s>>>(
+            pts, npts, cols, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
+    }
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int micv_hough_circles_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
+                           unsigned radius, int32_t *acc, micv_stream stream) {
+    MICV_REQUIRE(ctx && mask && acc, "micv_hough_circles: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0 && rows <= 32767 && cols <= 32767,
+                 "micv_hough_circles: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(mstride >= (size_t)cols, "micv_hough_circles: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int32_t *pts;
+    int64_t *npts;
+    char *extra;
+    MICV_TRY(hough_points(ctx, s, mask, rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
+    TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
+    static TrigTable ht;
+    static bool ht_ok = false;
+    if (!ht_ok) {
+        build_trig(0, &ht);  // theta = 0..359, Hough.cu:85
+        ht_ok = true;
+    }
+    MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
+    MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rows * cols * sizeof(int32_t), s));  // ref forgets, :318
+    hough_circles_kernel<<<2048, 256, 0, s>>>(pts, npts, rows, cols, dt->c, dt->s, (float)radius, acc);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
+                         unsigned num_peaks, int threshold, uint32_t *peaks_rc, int64_t *count,
+                         micv_stream stream) {
+    MICV_REQUIRE(ctx && acc && count, "micv_hough_peaks: null argument");
+    MICV_REQUIRE(peaks_rc || num_peaks == 0, "micv_hough_peaks: peaks_rc is null");
+    MICV_REQUIRE(rows > 0 && cols > 0 && (int64_t)rows * cols < ((int64_t)1 << 31),
+                 "micv_hough_peaks: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(num_peaks <= 4096, "micv_hough_peaks: num_peaks %u > 4096 not supported",
+                 num_peaks);
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)rows * cols;
+    void *scratch;
+    MICV_TRY(ctx->reserve(Carver::need(n, 4) + Carver::need(1, 8) +
+                              Carver::need((size_t)num_peaks + 1, 8) + compact_scratch_bytes(n),
+                          &scratch));
+    Carver c(scratch);
+    int32_t *cand = c.take<int32_t>(n);
+    int64_t *ncand = c.take<int64_t>(1);
+    unsigned long long *sel = c.take<unsigned long long>((size_t)num_peaks + 1);
+    MICV_TRY(ordered_compact(s, PeakPred{acc, rows, cols, threshold}, n, cand, n, ncand,
+                             c.base + c.off));
+    MICV_HIP(hipMemsetAsync(sel, 0, ((size_t)num_peaks + 1) * 8, s));
+    for (unsigned k = 0; k < num_peaks; k++) {
+        peak_select_kernel<<<64, 256, 0, s>>>(acc, cand, ncand, n, sel, (int)k);
+        MICV_LAUNCH_CHECK();
+    }
+    peak_emit_kernel<<<1, 64, 0, s>>>(sel, num_peaks, cols, peaks_rc, count);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// stereo.hip -- ps2 window stereo: SSD (a12) and normalised cross-correlation (a13).
+//
+// Cost definition (DESIGN.md "Arithmetic contract", following DisparitySSD.cu:68-86):
+//   colsum(y, xc, d) = sum over wy = -r..r (top -> bottom, float adds) of the per-pixel term
+//   cost(y, x, d)    = sum over the window's columns (left -> right, float adds) of colsum
+// with clamp-to-edge addressing of both images, every d in [minD, maxD] evaluated in ascending
+// order, strict compare (lowest d wins ties).
+//
+// Kernel shape: one wave64 owns a strip of 64 window-columns x 8 output rows.  A lane walks
+// down its column keeping the last 2r+1 per-pixel terms in registers (fully unrolled, so the
+// ring is static), re-adds them in the contract's order for every output row, and the
+// horizontal sum runs as a systolic chain of v_add_f32 with a DPP wave_shr:1 operand:
+//   acc <- shift_right_one_lane(acc) + colsum     (2r steps)
+// which is exactly the left -> right association and needs no LDS at all.  Running best
+// cost / disparity live in registers; nothing but the two images is read and only the int8
+// disparity is written (9 B/px algorithmic).
+#include <type_traits>
+
+#include "kernels.hpp"
+
+namespace micv {
+
+enum { ST_SSD = 0, ST_SSD_SERIAL = 1, ST_NCC = 2 };
+
+__device__ __forceinline__ float dpp_shr1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
+}
+__device__ __forceinline__ int dpp_shr1(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
+}
+
+struct StereoArgs {
+    const float *left, *right;
+    int stride, rows, cols, min_d, max_d;
+    int wcols;        // 2r+1, or 2r with MICV_STEREO_COLS_2R
+    float init_best;  // +inf, or 5e6 with MICV_STEREO_MIN_SSD_5E6 (SSD); 0 for NCC
+    int8_t *disp;
+    int dstride;
+};
+
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
+    constexpr int W = 2 * R + 1, RPW = 8, STEPS = RPW + 2 * R, OUTW = 64 - 2 * R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ys = blockIdx.y * (4 * RPW) + wave * RPW;
+    if (ys >= a.rows) return;
+    const int x_base = blockIdx.x * OUTW - R;
+    const int xc = x_base + lane;  // window column of this lane (unclamped)
+    const int xl = clampi(xc, 0, a.cols - 1);
+    // output pixel whose window ENDS at this lane
+    const int xo = (a.wcols == W) ? xc - R : xc - R + 1;
+    const bool lane_ok = lane >= a.wcols - 1 && xo >= blockIdx.x * OUTW &&
+                         xo < (blockIdx.x + 1) * OUTW && xo < a.cols;
+
+    float Lv[STEPS];
+    const float *rrow[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        const int yy = clampi(ys - R + s, 0, a.rows - 1);
+        Lv[s] = a.left[(size_t)yy * a.stride + xl];
+        rrow[s] = a.right + (size_t)yy * a.stride;
+    }
+
+    using acc_t = typename std::conditional<MODE == ST_SSD_SERIAL, int, float>::type;
+    acc_t best[RPW];
+    int bestd[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+        best[j] = MODE == ST_SSD_SERIAL ? (acc_t)99999999 : (acc_t)a.init_best;
+        bestd[j] = MODE == ST_SSD_SERIAL ? 0 : -1;  // DisparitySSD.cpp:37-38 / .cu:177
+    }
+    // NCC: the template's own energy does not depend on d -- sum it once.
+    float AT[RPW];
+    if (MODE == ST_NCC) {
+        float ring[W];
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            ring[s % W] = Lv[s] * Lv[s];
+            if (s >= 2 * R) {
+                float cs = 0.f;
+#pragma unroll
+                for (int k = 0; k < W; k++) cs += ring[(s - 2 * R + k) % W];
+                float acc = cs;
+                for (int k = 1; k < a.wcols; k++) acc = dpp_shr1(acc) + cs;
+                AT[s - 2 * R] = acc;
+            }
+        }
+    }
+    // serial:: search range of this output pixel (DisparitySSD.cpp:42-43), padded coords.
+    const int d_lo = MODE == ST_SSD_SERIAL ? -(xo + R) : a.min_d;
+    const int d_hi = MODE == ST_SSD_SERIAL ? a.cols - 1 + R - xo : a.max_d;
+
+    for (int d = a.min_d; d <= a.max_d; d++) {
+        const int xr = clampi(xc + d, 0, a.cols - 1);
+        const bool d_ok = d >= d_lo && d <= d_hi;
+        acc_t ring[W];
+        float ringB[W];
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const float rv = rrow[s][xr];
+            if (MODE == ST_NCC) {
+                ring[s % W] = (acc_t)(Lv[s] * rv);
+                ringB[s % W] = rv * rv;
+            } else {
+                const float diff = Lv[s] - rv;
+                const float sq = diff * diff;
+                ring[s % W] = MODE == ST_SSD_SERIAL ? (acc_t)(int)roundf(sq) : (acc_t)sq;
+            }
+            if (s >= 2 * R) {
+                const int j = s - 2 * R;
+                acc_t cs = 0;
+#pragma unroll
+                for (int k = 0; k < W; k++) cs += ring[(s - 2 * R + k) % W];
+                acc_t acc = cs;
+                for (int k = 1; k < a.wcols; k++) acc = dpp_shr1(acc) + cs;
+                if (MODE == ST_NCC) {
+                    float csb = 0.f;
+#pragma unroll
+                    for (int k = 0; k < W; k++) csb += ringB[(s - 2 * R + k) % W];
+                    float accb = csb;
+                    for (int k = 1; k < a.wcols; k++) accb = dpp_shr1(accb) + csb;
+                    const float nc = (float)acc / sqrtf(AT[j] * accb);  // DisparityNCorr.cu:106
+                    if (nc > (float)best[j]) {                          // :108
+                        best[j] = (acc_t)nc;
+                        bestd[j] = d;
+                    }
+                } else if (d_ok && acc < best[j]) {  // DisparitySSD.cu:88 / .cpp:54
+                    best[j] = acc;
+                    bestd[j] = d;
+                }
+            }
+        }
+    }
+    if (lane_ok) {
+#pragma unroll
+        for (int j = 0; j < RPW; j++)
+            if (ys + j < a.rows) a.disp[(size_t)(ys + j) * a.dstride + xo] = (int8_t)bestd[j];
+    }
+}
+
+// Any radius: one thread per pixel, same arithmetic order, no reuse.
+template <int MODE>
+__global__ __launch_bounds__(256) void stereo_generic_kernel(StereoArgs a, int r) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.cols || y >= a.rows) return;
+    const int x_first = x - r;  // first window column
+    float best = MODE == ST_SSD_SERIAL ? 0.f : a.init_best;
+    int besti = 99999999, bestd = MODE == ST_SSD_SERIAL ? 0 : -1;
+    const int d_lo = MODE == ST_SSD_SERIAL ? -(x + r) : a.min_d;
+    const int d_hi = MODE == ST_SSD_SERIAL ? a.cols - 1 + r - x : a.max_d;
+    for (int d = a.min_d; d <= a.max_d; d++) {
+        float tot = 0.f, totA = 0.f, totB = 0.f;
+        int toti = 0;
+        for (int i = 0; i < a.wcols; i++) {
+            const int xl = clampi(x_first + i, 0, a.cols - 1);
+            const int xr = clampi(x_first + i + d, 0, a.cols - 1);
+            float cs = 0.f, csA = 0.f, csB = 0.f;
+            int csi = 0;
+            for (int wy = -r; wy <= r; wy++) {
+                const int yy = clampi(y + wy, 0, a.rows - 1);
+                const float l = a.left[(size_t)yy * a.stride + xl];
+                const float rv = a.right[(size_t)yy * a.stride + xr];
+                if (MODE == ST_NCC) {
+                    cs += l * rv;
+                    csA += l * l;
+                    csB += rv * rv;
+                } else {
+                    const float diff = l - rv;
+                    if (MODE == ST_SSD_SERIAL) csi += (int)roundf(diff * diff);
+                    else cs += diff * diff;
+                }
+            }
+            tot += cs; totA += csA; totB += csB; toti += csi;
+        }
+        if (MODE == ST_NCC) {
+            const float nc = tot / sqrtf(totA * totB);
+            if (nc > best) { best = nc; bestd = d; }
+        } else if (MODE == ST_SSD_SERIAL) {
+            if (d >= d_lo && d <= d_hi && toti < besti) { besti = toti; bestd = d; }
+        } else if (tot < best) {
+            best = tot;
+            bestd = d;
+        }
+    }
+    a.disp[(size_t)y * a.dstride + x] = (int8_t)bestd;
+}
+
+template <int MODE>
+static int launch_stereo(hipStream_t s, const StereoArgs &a, int r) {
+#define MICV_ST_CASE(RR)                                                                      \
+    case RR:                                                                                  \
+        stereo_kernel<RR, MODE><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 32)), 256, 0, s>>>(a); \
+        break;
+    switch (r) {
+        MICV_ST_CASE(1) MICV_ST_CASE(2) MICV_ST_CASE(3) MICV_ST_CASE(4) MICV_ST_CASE(5)
+        MICV_ST_CASE(6) MICV_ST_CASE(7) MICV_ST_CASE(8) MICV_ST_CASE(9) MICV_ST_CASE(10)
+        default:
+            stereo_generic_kernel<MODE><<<dim3(cdiv(a.cols, 64), cdiv(a.rows, 4)), 256, 0, s>>>(a, r);
+    }
+#undef MICV_ST_CASE
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const float *right,
+                         int rows, int cols, size_t stride, int rad, int min_d, int max_d,
+                         int flags, int8_t *disp, size_t dstride, micv_stream stream, bool ncc) {
+    MICV_REQUIRE(ctx && left && right && disp, "%s: null argument", fn);
+    MICV_REQUIRE(rows > 0 && cols > 0, "%s: bad size %dx%d", fn, rows, cols);
+    MICV_REQUIRE(rad >= 0 && rad <= 31, "%s: window radius %d out of range 0..31", fn, rad);
+    MICV_REQUIRE(min_d <= max_d && min_d >= -128 && max_d <= 127,
+                 "%s: disparities [%d, %d] do not fit the int8 output (CV_8SC1)", fn, min_d, max_d);
+    MICV_REQUIRE(stride_ok(stride, cols, 4) && dstride >= (size_t)cols, "%s: bad stride", fn);
+    MICV_REQUIRE((flags & ~7) == 0, "%s: unknown flags 0x%x", fn, flags);
+    MICV_REQUIRE(!(ncc && (flags & MICV_STEREO_SERIAL)), "%s: SERIAL applies to SSD only", fn);
+    MICV_REQUIRE(!((flags & MICV_STEREO_COLS_2R) && rad == 0), "%s: COLS_2R needs radius >= 1", fn);
+    MICV_HIP(hipSetDevice(ctx->device));
+    StereoArgs a;
+    a.left = left; a.right = right; a.stride = (int)(stride / 4);
+    a.rows = rows; a.cols = cols; a.min_d = min_d; a.max_d = max_d;
+    a.wcols = (flags & MICV_STEREO_COLS_2R) ? 2 * rad : 2 * rad + 1;
+    a.init_best = ncc ? 0.f : ((flags & MICV_STEREO_MIN_SSD_5E6) ? 5000000.f : INFINITY);
+    a.disp = disp; a.dstride = (int)dstride;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ncc) return launch_stereo<ST_NCC>(s, a, rad);
+    if (flags & MICV_STEREO_SERIAL) return launch_stereo<ST_SSD_SERIAL>(s, a, rad);
+    return launch_stereo<ST_SSD>(s, a, rad);
+}
+
+}  // namespace micv
+
+using namespace micv;
+
+extern "C" {
+
+int micv_disparity_ssd_dev(micv_ctx *ctx, const float *left, const float *right, int rows,
+                           int cols, size_t stride, int window_rad, int min_disparity,
+                           int max_disparity, int flags, int8_t *disp, size_t dstride,
+                           micv_stream stream) {
+    return stereo_common("micv_disparity_ssd", ctx, left, right, rows, cols, stride, window_rad,
+                         min_disparity, max_disparity, flags, disp, dstride, stream, false);
+}
+
+int micv_disparity_ncorr_dev(micv_ctx *ctx, const float *left, const float *right, int rows,
+                             int cols, size_t stride, int window_rad, int min_disparity,
+                             int max_disparity, int flags, int8_t *disp, size_t dstride,
+                             micv_stream stream) {
+    return stereo_common("micv_disparity_ncorr", ctx, left, right, rows, cols, stride, window_rad,
+                         min_disparity, max_disparity, flags, disp, dstride, stream, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""`harris::` and `sift::` namespaces of the reference (ProblemSets/ps4_cpp/include/Harris.h,
+Descriptors.h).  `harris.cpu.*` and `harris.gpu.*` of the reference share one implementation
+here (their results are identical by specification)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _buf as B
+from ._capi import check, i64, lib
+from .lk import _ctx_for
+
+
+def getGradients(img, kernelSize=3, scale=1.0, ctx=None):
+    """harris::getGradients (Harris.cpp:14-41) -> (diffX, diffY).  scale = 1/9 gives the LK
+    computeGradients (OpticalFlow.cpp:12-39)."""
+    B.check2d(img, np.float32, name="in")
+    rows, cols = img.shape
+    gx = B.empty_like_shape(img, (rows, cols))
+    gy = B.empty_like_shape(img, (rows, cols))
+    c = _ctx_for(img, ctx)
+    if B.is_dev(img):
+        check(lib.micv_sobel_dev(c.handle, B.ptr(img), rows, cols, B.stride_bytes(img),
+                                 int(kernelSize), float(scale), B.ptr(gx), B.ptr(gy),
+                                 B.stride_bytes(gx), B.stream_of(img)))
+    else:
+        check(lib.micv_sobel_host(c.handle, B.ptr(img), rows, cols, B.stride_bytes(img),
+                                  int(kernelSize), float(scale), B.ptr(gx), B.ptr(gy),
+                                  B.stride_bytes(gx)))
+    return gx, gy
+
+
+def getCornerResponse(gradX, gradY, windowSize, gaussianSigma, harrisScore, ctx=None):
+    """harris::{cpu,gpu}::getCornerResponse (Harris.cpp:43-97 / Harris.cu:96-159) -> R."""
+    B.check2d(gradX, np.float32, name="gradX")
+    B.check2d(gradY, np.float32, name="gradY")
+    if tuple(gradX.shape) != tuple(gradY.shape) or B.stride_bytes(gradX) != B.stride_bytes(gradY):
+        raise ValueError("gradX and gradY differ in size / stride")
+    rows, cols = gradX.shape
+    resp = B.empty_like_shape(gradX, (rows, cols))
+    c = _ctx_for(gradX, ctx)
+    if B.is_dev(gradX):
+        check(lib.micv_harris_response_dev(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                           B.stride_bytes(gradX), int(windowSize),
+                                           float(gaussianSigma), float(harrisScore), B.ptr(resp),
+                                           B.stride_bytes(resp), B.stream_of(gradX)))
+    else:
+        check(lib.micv_harris_response_host(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                            B.stride_bytes(gradX), int(windowSize),
+                                            float(gaussianSigma), float(harrisScore), B.ptr(resp),
+                                            B.stride_bytes(resp)))
+    return resp
+
+
+def refineCorners(cornerResponse, threshold, minDistance, capacity=None, ctx=None):
+    """harris::{cpu,gpu}::refineCorners (Harris.cpp:99-147 / Harris.cu:243-329) ->
+    (corners, cornerLocs) with cornerLocs an [n, 2] int32 array of (y, x) in row-major order."""
+    B.check2d(cornerResponse, np.float32, name="cornerResponse")
+    rows, cols = cornerResponse.shape
+    cap = int(capacity) if capacity is not None else rows * cols
+    corners = B.empty_like_shape(cornerResponse, (rows, cols))
+    c = _ctx_for(cornerResponse, ctx)
+    if B.is_dev(cornerResponse):
+        import torch
+        locs = torch.empty((cap, 2), dtype=torch.int32, device=cornerResponse.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=cornerResponse.device)
+        check(lib.micv_harris_refine_dev(c.handle, B.ptr(cornerResponse), rows, cols,
+                                         B.stride_bytes(cornerResponse), float(threshold),
+                                         int(minDistance), B.ptr(corners), B.stride_bytes(corners),
+                                         locs.data_ptr(), cap, cnt.data_ptr(),
+                                         B.stream_of(cornerResponse)))
+        n = min(int(cnt.item()), cap)
+        return corners, locs[:n]
+    locs = np.empty((cap, 2), np.int32)
+    cnt = i64(0)
+    check(lib.micv_harris_refine_host(c.handle, B.ptr(cornerResponse), rows, cols,
+                                      B.stride_bytes(cornerResponse), float(threshold),
+                                      int(minDistance), B.ptr(corners), B.stride_bytes(corners),
+                                      locs.ctypes.data, cap, C.byref(cnt)))
+    return corners, locs[:min(cnt.value, cap)]
+
+
+# The reference's two namespaces, for code that spells them out.
+class cpu:  # noqa: N801
+    getCornerResponse = staticmethod(getCornerResponse)
+    refineCorners = staticmethod(refineCorners)
+
+
+gpu = cpu
+
+
+def getAnglesFromGradients(gradX, gradY, ctx=None):
+    """sift::getAnglesFromGradients (Descriptors.cpp:7-25) -> angles (radians)."""
+    B.check2d(gradX, np.float32, name="gradX")
+    B.check2d(gradY, np.float32, name="gradY")
+    if tuple(gradX.shape) != tuple(gradY.shape) or B.stride_bytes(gradX) != B.stride_bytes(gradY):
+        raise ValueError("gradX and gradY differ in size / stride")
+    rows, cols = gradX.shape
+    ang = B.empty_like_shape(gradX, (rows, cols))
+    c = _ctx_for(gradX, ctx)
+    if B.is_dev(gradX):
+        check(lib.micv_sift_angles_dev(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                       B.stride_bytes(gradX), B.ptr(ang), B.stride_bytes(ang),
+                                       B.stream_of(gradX)))
+    else:
+        check(lib.micv_sift_angles_host(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                        B.stride_bytes(gradX), B.ptr(ang), B.stride_bytes(ang)))
+    return ang
+
+
+def getKeypoints(gradX, gradY, cornerLocs, size, ctx=None):
+    """sift::getKeypoints (Descriptors.cpp:27-47) -> [n, 4] float32 (x, y, size, angle_deg):
+    the fields of the cv::KeyPoint the reference constructs."""
+    B.check2d(gradX, np.float32, name="gradX")
+    B.check2d(gradY, np.float32, name="gradY")
+    rows, cols = gradX.shape
+    c = _ctx_for(gradX, ctx)
+    n = int(cornerLocs.shape[0])
+    if B.is_dev(gradX):
+        import torch
+        locs = cornerLocs.to(torch.int32).contiguous()
+        kp = torch.empty((n, 4), dtype=torch.float32, device=gradX.device)
+        check(lib.micv_sift_keypoints_dev(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                          B.stride_bytes(gradX), locs.data_ptr(), n, float(size),
+                                          kp.data_ptr(), B.stream_of(gradX)))
+        return kp
+    locs = np.ascontiguousarray(cornerLocs, dtype=np.int32)
+    kp = np.empty((n, 4), np.float32)
+    check(lib.micv_sift_keypoints_host(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                       B.stride_bytes(gradX), locs.ctypes.data, n, float(size),
+                                       kp.ctypes.data))
+    return kp

@@ -56,6 +56,34 @@ def stereo_pair(seed, rows, cols):
     return left, np.ascontiguousarray(right), -d
 
 
+def hough_mask(rows, cols, n_lines=12, radii=(20, 24, 28, 32, 36, 40), seed=0x5EED0001):
+    """Binary (0/255) edge mask with `n_lines` straight lines at theta in {-60..75 step 15} deg
+    (rho chosen by the splitmix stream) and one circle per radius.  Returns (mask, lines, circles)
+    with lines = [(rho, theta_deg)], circles = [(cy, cx, r)]."""
+    mask = np.zeros((rows, cols), np.uint8)
+    rnd = splitmix64_u8(seed, 4 * (n_lines + len(radii)) + 8).astype(np.int64)
+    lines, circles = [], []
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    for i in range(n_lines):
+        theta = -60 + 15 * (i % 10)
+        t = np.deg2rad(theta)
+        # a line through a pseudo-random interior point
+        py = rows // 4 + (rnd[4 * i] * rows // 2) // 256
+        px = cols // 4 + (rnd[4 * i + 1] * cols // 2) // 256
+        rho = px * np.cos(t) + py * np.sin(t)
+        d = np.abs(xx * np.cos(t) + yy * np.sin(t) - rho)
+        mask[d < 0.5] = 255
+        lines.append((float(rho), theta))
+    for j, r in enumerate(radii):
+        k = 4 * (n_lines + j)
+        cy = r + 2 + (rnd[k] * (rows - 2 * r - 4)) // 256
+        cx = r + 2 + (rnd[k + 1] * (cols - 2 * r - 4)) // 256
+        d = np.abs(np.hypot(yy - cy, xx - cx) - r)
+        mask[d < 0.5] = 255
+        circles.append((int(cy), int(cx), int(r)))
+    return mask, lines, circles
+
+
 def checkerboard(rows, cols, square=40, lo=64, hi=192, seed=None, amp=4):
     """C1 checkerboard (+- amp of the same noise stream when seed is given)."""
     yy, xx = np.mgrid[0:rows, 0:cols]

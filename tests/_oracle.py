@@ -164,6 +164,118 @@ def lk_flow_pyr(prev, nxt, win, levels):
     return u, v
 
 
+_hresp = _sig("orc_harris_response", i32, [vp, vp, i32, i32, sz, i32, f64, f32, vp, sz])
+_hrefine = _sig("orc_harris_refine", i64, [vp, i32, i32, sz, f64, i32, vp, sz, vp, i64])
+_sang = _sig("orc_sift_angles", None, [vp, vp, i32, i32, sz, vp, sz])
+_skp = _sig("orc_sift_keypoints", None, [vp, vp, i32, i32, sz, vp, i64, f32, vp])
+_ssd = _sig("orc_disparity_ssd", i32, [vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz])
+_ssds = _sig("orc_disparity_ssd_serial", i32, [vp, vp, i32, i32, sz, i32, i32, i32, vp, sz])
+_ncc = _sig("orc_disparity_ncorr", i32, [vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz])
+_hdims = _sig("orc_hough_lines_dims", None, [i32, i32, C.c_uint, C.c_uint, C.POINTER(i32), C.POINTER(i32)])
+_hlines = _sig("orc_hough_lines", i32, [vp, i32, i32, sz, C.c_uint, C.c_uint, vp])
+_hcirc = _sig("orc_hough_circles", i32, [vp, i32, i32, sz, C.c_uint, vp])
+_hpeaks = _sig("orc_hough_peaks", i64, [vp, i32, i32, C.c_uint, i32, vp])
+
+
+def harris_response(gx, gy, win, sigma, alpha):
+    gx = _f(gx); gy = _f(gy)
+    r, c = gx.shape
+    out = np.empty_like(gx)
+    rc = _hresp(_p(gx), _p(gy), r, c, c, win, float(sigma), float(np.float32(alpha)), _p(out), c)
+    if rc:
+        raise ValueError(f"orc_harris_response rc={rc}")
+    return out
+
+
+def harris_refine(resp, threshold, min_distance):
+    resp = _f(resp)
+    r, c = resp.shape
+    corners = np.empty_like(resp)
+    locs = np.empty((r * c, 2), np.int32)
+    n = _hrefine(_p(resp), r, c, c, float(threshold), int(min_distance), _p(corners), c, _p(locs), r * c)
+    return corners, locs[:n].copy()
+
+
+def sift_angles(gx, gy):
+    gx = _f(gx); gy = _f(gy)
+    r, c = gx.shape
+    out = np.empty_like(gx)
+    _sang(_p(gx), _p(gy), r, c, c, _p(out), c)
+    return out
+
+
+def sift_keypoints(gx, gy, locs, size):
+    gx = _f(gx); gy = _f(gy)
+    locs = np.ascontiguousarray(locs, dtype=np.int32)
+    r, c = gx.shape
+    kp = np.empty((len(locs), 4), np.float32)
+    _skp(_p(gx), _p(gy), r, c, c, _p(locs), len(locs), float(size), _p(kp))
+    return kp
+
+
+def disparity_ssd(left, right, rad, min_d, max_d, flags=0):
+    left = _f(left); right = _f(right)
+    r, c = left.shape
+    out = np.empty((r, c), np.int8)
+    rc = _ssd(_p(left), _p(right), r, c, c, rad, min_d, max_d, flags, _p(out), c)
+    if rc:
+        raise ValueError(f"orc_disparity_ssd rc={rc}")
+    return out
+
+
+def disparity_ssd_serial(left, right, rad, min_d, max_d):
+    left = _f(left); right = _f(right)
+    r, c = left.shape
+    out = np.empty((r, c), np.int8)
+    rc = _ssds(_p(left), _p(right), r, c, c, rad, min_d, max_d, _p(out), c)
+    if rc:
+        raise ValueError(f"orc_disparity_ssd_serial rc={rc}")
+    return out
+
+
+def disparity_ncorr(left, right, rad, min_d, max_d, flags=0):
+    left = _f(left); right = _f(right)
+    r, c = left.shape
+    out = np.empty((r, c), np.int8)
+    rc = _ncc(_p(left), _p(right), r, c, c, rad, min_d, max_d, flags, _p(out), c)
+    if rc:
+        raise ValueError(f"orc_disparity_ncorr rc={rc}")
+    return out
+
+
+def hough_lines_dims(rows, cols, rho_bin=1, theta_bin=1):
+    rb, tb = i32(), i32()
+    _hdims(rows, cols, rho_bin, theta_bin, C.byref(rb), C.byref(tb))
+    return rb.value, tb.value
+
+
+def hough_lines(mask, rho_bin=1, theta_bin=1):
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    r, c = mask.shape
+    rb, tb = hough_lines_dims(r, c, rho_bin, theta_bin)
+    acc = np.empty((rb, tb), np.int32)
+    rc = _hlines(_p(mask), r, c, c, rho_bin, theta_bin, _p(acc))
+    if rc:
+        raise ValueError(f"orc_hough_lines rc={rc}")
+    return acc
+
+
+def hough_circles(mask, radius):
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    r, c = mask.shape
+    acc = np.empty((r, c), np.int32)
+    _hcirc(_p(mask), r, c, c, radius, _p(acc))
+    return acc
+
+
+def hough_peaks(acc, num_peaks, threshold):
+    acc = np.ascontiguousarray(acc, dtype=np.int32)
+    r, c = acc.shape
+    peaks = np.empty((max(num_peaks, 1), 2), np.uint32)
+    n = _hpeaks(_p(acc), r, c, num_peaks, threshold, _p(peaks))
+    return peaks[:n].copy()
+
+
 def rgb8_to_gray(rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     r, c, _ = rgb.shape
