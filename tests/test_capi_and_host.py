@@ -1,0 +1,85 @@
+"""CPU-side checks: libmicv.so loads and exports every symbol include/mi_cv.h declares (no
+compute calls here), host-only entry points, the synthetic-input generator and the byte model."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mi_cv.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(micv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from introtocomputervision_amd import _capi
+    names = header_functions()
+    assert len(names) >= 50
+    missing = [n for n in names if not hasattr(_capi.lib, n)]
+    assert not missing, f"declared in include/mi_cv.h but not exported: {missing}"
+    assert not _capi.MISSING
+    undeclared = [n for n in names if n not in _capi.SIGNATURES]
+    assert not undeclared, f"no ctypes signature for: {undeclared}"
+    assert _capi.lib.micv_version().decode().startswith("micv")
+
+
+def test_product_does_not_link_or_reference_the_oracle():
+    import subprocess
+    so = os.path.join(ROOT, "introtocomputervision_amd", "libmicv.so")
+    deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "oracle" not in deps and "torch" not in deps
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "introtocomputervision_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "_oracle" not in text and "orc_" not in text, f
+
+
+def test_host_only_entry_points():
+    from introtocomputervision_amd import _capi, hough
+    # common::divRoundUp (Utils.h:12-15): max(1, ceil(float(n)/float(d)))
+    assert _capi.lib.micv_div_round_up(10, 3) == 4
+    assert _capi.lib.micv_div_round_up(0, 16) == 1
+    assert _capi.lib.micv_div_round_up(1920, 64) == 30
+    assert hough.linesAccumulatorShape(1080, 1920, 1, 1) == (4406, 180)
+    assert hough.linesAccumulatorShape(1080, 1920, 2, 7) == (2203, 26)
+    with pytest.raises(_capi.MicvError):
+        hough.linesAccumulatorShape(0, 10)
+
+
+def test_errors_do_not_need_a_gpu():
+    from introtocomputervision_amd import _capi
+    import ctypes as C
+    h = _capi.vp()
+    rc = _capi.lib.micv_ctx_create(0, C.byref(h))
+    if rc == 0:  # a GPU is present: nothing to check here
+        _capi.lib.micv_ctx_destroy(h)
+        return
+    assert rc in (_capi.EHIP, _capi.EINVAL) and _capi.last_error()
+
+
+def test_splitmix64_reference_values():
+    from introtocomputervision_amd import synth
+    # splitmix64(seed=0) first outputs: e220a8397b1dcdaf 6e789e6aa1b965f4 06c45d188009454f
+    assert synth.splitmix64_u8(0, 3).tolist() == [0xE2, 0x6E, 0x06]
+    a = synth.smooth_noise(0x5EED0005, 32, 48)
+    assert a.dtype == np.float32 and np.array_equal(a, np.round(a)) and 0 <= a.min() and a.max() <= 255
+    p, n = synth.lk_pair(0x5EED0005, 32, 48, 3, -2)
+    assert np.array_equal(n[0, 3:], p[2, :-3])  # next(y, x) = prev(y + 2, x - 3)
+    l, r, nd = synth.stereo_pair(1, 20, 64)
+    assert np.array_equal(r[5, :30], l[5, -nd[5]:-nd[5] + 30])
+
+
+def test_byte_model_matches_baseline_md():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.algorithmic_bytes_pair(1080, 1920, 5) == 55207680
+    assert b.algorithmic_bytes_pair(1080, 1920, 4) == 54950400
+    assert b.algorithmic_bytes_pair(2160, 3840, 5) == 220838400
+    assert b.level0_kernel_bytes_pair(1080, 1920, 5) == 16 * 2073600 + 8 * 518400

@@ -1,0 +1,140 @@
+"""Independent cross-checks of the oracle's OpenCV-semantics restatements (the reference cannot
+be run here, so these are the strongest pins available): scipy.ndimage for the linear filters,
+numpy for borders / decimation, analytic known answers for LK, stereo, Harris and Hough."""
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+import _oracle as orc
+from introtocomputervision_amd import synth
+
+
+def test_reflect101_is_numpy_reflect():
+    for n in (1, 2, 5, 17):
+        ref = np.pad(np.arange(n), 3 * n + 2, mode="reflect") if n > 1 else np.zeros(7 * n + 4, int)
+        for i, p in enumerate(range(-(3 * n + 2), n + 3 * n + 2)):
+            assert orc.reflect101(p, n) == ref[i], (p, n)
+
+
+def test_sep_filter_matches_scipy_mirror():
+    img = synth.smooth_noise(1, 41, 67)
+    g = orc.gaussian_kernel(15, 5.0)
+    got = orc.sep_filter(img, g, g)
+    ref = ndi.correlate1d(ndi.correlate1d(img.astype(np.float64), g.astype(np.float64), axis=1, mode="mirror"),
+                          g.astype(np.float64), axis=0, mode="mirror")
+    assert np.abs(got - ref).max() < 1e-4 * 255
+
+
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_sobel_matches_binomial_kernels(ksize):
+    img = synth.smooth_noise(2, 33, 45)
+    gx, gy = orc.sobel(img, ksize, 1.0)
+    smooth = {3: [1, 2, 1], 5: [1, 4, 6, 4, 1], 7: [1, 6, 15, 20, 15, 6, 1]}[ksize]
+    deriv = {3: [-1, 0, 1], 5: [-1, -2, 0, 2, 1], 7: [-1, -4, -5, 0, 5, 4, 1]}[ksize]
+    f = img.astype(np.float64)
+    rx = ndi.correlate1d(ndi.correlate1d(f, deriv, axis=1, mode="mirror"), smooth, axis=0, mode="mirror")
+    ry = ndi.correlate1d(ndi.correlate1d(f, smooth, axis=1, mode="mirror"), deriv, axis=0, mode="mirror")
+    assert np.array_equal(gx, rx.astype(np.float32)) and np.array_equal(gy, ry.astype(np.float32))  # integers: exact
+    if ksize == 3:
+        assert np.array_equal(gx, ndi.sobel(f, axis=1, mode="mirror").astype(np.float32))
+
+
+def test_pyr_down_is_odd_decimation_and_up_is_blurred_replication():
+    img = synth.smooth_noise(3, 31, 44)
+    assert np.array_equal(orc.pyr_down(img), img[1::2, 1::2][:15, :22])
+    up = np.repeat(np.repeat(img.astype(np.float64), 2, axis=0), 2, axis=1)
+    k = np.array([1, 4, 6, 4, 1]) / 16.0
+    ref = ndi.correlate1d(ndi.correlate1d(up, k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    assert np.abs(orc.pyr_up(img) - ref).max() < 1e-3
+    pyr = orc.gaussian_pyramid(img, 4)
+    assert [p.shape for p in pyr] == [(31, 44), (15, 22), (7, 11), (3, 5)]
+    for l, p in enumerate(pyr):  # every level is a direct decimation of level 0
+        s = (1 << l) - 1
+        assert np.array_equal(p, img[s::1 << l, s::1 << l][:p.shape[0], :p.shape[1]])
+
+
+def test_remap_matches_map_coordinates_on_the_1_32_grid():
+    img = synth.smooth_noise(4, 30, 40)
+    rng = np.random.default_rng(0)
+    mx = (rng.integers(-64, 40 * 32 + 64, (30, 40)) / 32.0).astype(np.float32)  # exact 1/32 steps
+    my = (rng.integers(-64, 30 * 32 + 64, (30, 40)) / 32.0).astype(np.float32)
+    got = orc.remap_linear(img, mx, my)
+    # BORDER_CONSTANT(0) blends the in-image taps with zeros: model it by zero-padding first
+    # (scipy alone returns cval for any coordinate outside the grid).
+    ref = ndi.map_coordinates(np.pad(img.astype(np.float64), 4), [my.astype(np.float64) + 4, mx.astype(np.float64) + 4],
+                              order=1, mode="constant", cval=0.0)
+    assert np.abs(got - ref).max() < 1e-3
+    # identity map returns the image exactly
+    yy, xx = np.mgrid[0:30, 0:40].astype(np.float32)
+    assert np.array_equal(orc.remap_linear(img, xx, yy), img)
+    # coordinates are quantised to 1/32 px with round-half-even
+    one = orc.remap_linear(img, xx + np.float32(1 / 64), yy)
+    assert np.array_equal(one, img)
+
+
+def test_resize_identity_and_edges():
+    img = synth.smooth_noise(5, 20, 30)
+    assert np.array_equal(orc.resize_linear(img, 20, 30), img)
+    up = orc.resize_linear(img, 21, 30)  # the 134 -> 135 rows case of the 1080p pyramid
+    assert up.shape == (21, 30)
+    assert np.abs(up[0] - img[0]).max() < 1e-3 and np.abs(up[-1] - img[-1]).max() < 1e-3
+    assert img.min() - 1e-3 <= up.min() and up.max() <= img.max() + 1e-3
+
+
+@pytest.mark.parametrize("dx,dy", [(1, 0), (0, -1), (1, 1)])
+def test_lk_recovers_subwindow_translation(dx, dy):
+    prev, nxt = synth.lk_pair(11, 96, 128, dx, dy)
+    u, v = orc.lk_flow(prev, nxt, 15)
+    assert abs(np.median(u[20:-20, 20:-20]) - dx) < 0.35 and abs(np.median(v[20:-20, 20:-20]) - dy) < 0.35
+
+
+def test_lk_pyr_recovers_large_translation_and_zero_motion():
+    prev, nxt = synth.lk_pair(12, 160, 224, 6, -4)
+    u, v = orc.lk_flow_pyr(prev, nxt, 15, 4)
+    assert abs(np.median(u[40:-40, 40:-40]) - 6) < 0.5 and abs(np.median(v[40:-40, 40:-40]) + 4) < 0.5
+    u0, v0 = orc.lk_flow_pyr(prev, prev, 15, 4)
+    assert not u0.any() and not v0.any()
+    flat = np.full((64, 64), 7, np.float32)  # det < tau everywhere -> zero flow (OpticalFlow.cpp:95)
+    uf, vf = orc.lk_flow(flat, flat + 1, 15)
+    assert not uf.any() and not vf.any()
+
+
+def test_stereo_recovers_constant_disparity_and_serial_agrees():
+    left = synth.smooth_noise(13, 40, 160)
+    right = np.roll(left, -9, axis=1)  # right(x) = left(x + 9) -> left-reference disparity -9
+    d = orc.disparity_ssd(left, right, 4, -20, 0)
+    assert (d[6:-6, 40:-40] == -9).all()
+    ds = orc.disparity_ssd_serial(left, right, 4, -20, 0)
+    assert np.array_equal(d[:, 30:-30], ds[:, 30:-30])  # integer images: identical costs
+    dn = orc.disparity_ncorr(left + 1, right + 1, 4, -20, 0)
+    assert (dn[6:-6, 40:-40] == -9).mean() > 0.99
+
+
+def test_harris_finds_the_checker_lattice():
+    img = synth.checkerboard(200, 240, square=40, seed=5)
+    gx, gy = orc.sobel(img, 3, 1.0)
+    R = orc.harris_response(gx, gy, 5, 1.5, 0.04)
+    _, locs = orc.harris_refine(R, 5e8, 5)
+    want = {(y, x) for y in range(40, 200, 40) for x in range(40, 240, 40)}
+    near = {(int(round(y / 40.0)) * 40, int(round(x / 40.0)) * 40) for y, x in locs}
+    assert want <= near and all(min(y % 40, 40 - y % 40) <= 2 and min(x % 40, 40 - x % 40) <= 2 for y, x in locs)
+    assert np.array_equal(locs, np.array(sorted(map(tuple, locs)), dtype=np.int32))  # row-major order
+
+
+def test_hough_votes_and_peaks():
+    mask, lines, circles = synth.hough_mask(200, 300, n_lines=5, radii=(25,))
+    acc = orc.hough_lines(mask, 1, 1)
+    rb, tb = orc.hough_lines_dims(200, 300, 1, 1)
+    diag = int(np.ceil(np.hypot(200, 300)))
+    assert (rb, tb) == (2 * diag, 180) and acc.shape == (rb, tb)
+    assert acc.sum() == int((mask > 0).sum()) * 180
+    peaks = orc.hough_peaks(acc, 30, 60)
+    found = {(int(p[0]) - diag, int(p[1]) - 90) for p in peaks}
+    for rho, theta in lines:
+        assert any(abs(fr - rho) <= 2 and abs(ft - theta) <= 1 for fr, ft in found)
+    votes = [acc[p[0], p[1]] for p in peaks]
+    assert votes == sorted(votes, reverse=True)
+    ca = orc.hough_circles(mask, 25)
+    cy, cx, r = circles[0]
+    py, px = np.unravel_index(ca.argmax(), ca.shape)
+    assert abs(py - cy) <= 2 and abs(px - cx) <= 2
