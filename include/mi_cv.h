@@ -70,6 +70,12 @@ void micv_timer_destroy(micv_timer *t);
 int micv_profile_enable(micv_ctx *ctx, int on);
 int micv_profile_reset(micv_ctx *ctx);
 int micv_profile_lk_level(micv_ctx *ctx, int level, double *total_ms, int64_t *launches);
+/* In-kernel phase stamps of the fused LK level kernel (diagnostic builds of a timing study, never
+ * on in a timed run): while enabled, wave 0 of every workgroup adds the s_memtime ticks it spent
+ * in each phase to 16 device counters ([0..5] interior tiles, [8..13] border tiles: stage, pyrUp
+ * rows, warp, gradients, window sums, solve).  Reads the counters into ticks16 (may be NULL),
+ * then enables/disables and zeroes them.  Synchronises the device. */
+int micv_profile_lk_phases(micv_ctx *ctx, int enable, uint64_t *ticks16);
 
 /* --------------------------------------------------------- ps5: LK + pyramids ------ */
 

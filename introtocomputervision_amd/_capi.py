@@ -48,6 +48,7 @@ SIGNATURES = {
     "micv_profile_enable": (i32, [vp, i32]),
     "micv_profile_reset": (i32, [vp]),
     "micv_profile_lk_level": (i32, [vp, i32, C.POINTER(f64), C.POINTER(i64)]),
+    "micv_profile_lk_phases": (i32, [vp, i32, vp]),
     "micv_warmup": (i32, [vp, vp]),
     "micv_div_round_up": (sz, [sz, sz]),
     "micv_timer_create": (i32, [C.POINTER(vp)]),
@@ -144,6 +145,12 @@ class Context:
         ms, n = f64(), i64()
         check(lib.micv_profile_lk_level(self._h, int(level), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_lk_phases(self, enable):
+        """Read + reset the 16 in-kernel phase counters, then enable/disable stamping."""
+        buf = (C.c_uint64 * 16)()
+        check(lib.micv_profile_lk_phases(self._h, 1 if enable else 0, buf))
+        return list(buf)
 
     def warmup(self, stream=None):
         check(lib.micv_warmup(self._h, stream))

@@ -96,6 +96,7 @@ struct micv_ctx {
     // Per-launch timing of the pyramid-level kernels (micv_profile_*): event pairs per level.
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[16];
+    unsigned long long *stamps = nullptr;  // 16 device counters (micv_profile_lk_phases)
     int prof_begin(int level, hipStream_t s);
     int prof_end(int level, hipStream_t s);
     // Returns scratch of at least `bytes` (256-B aligned). Growing synchronises the device.

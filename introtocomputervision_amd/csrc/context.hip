@@ -141,6 +141,7 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)micv_profile_reset(ctx);
+    if (ctx->stamps) (void)hipFree(ctx->stamps);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
@@ -151,6 +152,26 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx) { return ctx ? ctx->arena_byt
 int micv_profile_enable(micv_ctx *ctx, int on) {
     MICV_REQUIRE(ctx != nullptr, "micv_profile_enable: ctx is null");
     ctx->profile = on != 0;
+    return MICV_OK;
+}
+
+int micv_profile_lk_phases(micv_ctx *ctx, int enable, uint64_t *ticks16) {
+    MICV_REQUIRE(ctx != nullptr, "micv_profile_lk_phases: ctx is null");
+    MICV_HIP(hipSetDevice(ctx->device));
+    if (ticks16) {
+        for (int i = 0; i < 16; i++) ticks16[i] = 0;
+        if (ctx->stamps) {
+            MICV_HIP(hipDeviceSynchronize());
+            MICV_HIP(hipMemcpy(ticks16, ctx->stamps, 16 * 8, hipMemcpyDeviceToHost));
+        }
+    }
+    if (enable && !ctx->stamps) MICV_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->stamps), 16 * 8));
+    if (!enable && ctx->stamps) {
+        MICV_HIP(hipDeviceSynchronize());
+        MICV_HIP(hipFree(ctx->stamps));
+        ctx->stamps = nullptr;
+    }
+    if (ctx->stamps) MICV_HIP(hipMemset(ctx->stamps, 0, 16 * 8));
     return MICV_OK;
 }
 

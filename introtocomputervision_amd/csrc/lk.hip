@@ -207,6 +207,7 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
             a.img_pair = (k == 0) ? pair_elems : lvl_elems;
             a.out_u = out_u; a.out_v = out_v; a.out_stride = out_stride; a.out_pair = out_pair;
             a.add_base = 1;
+            a.stamps = (k == 0) ? ctx->stamps : nullptr;  // phase stamps: level 0 only
             if (level == 0) {
                 a.mode = LK_FLOW_NONE;
                 a.flow_u = a.flow_v = nullptr; a.flow_rows = a.flow_cols = 0; a.flow_pair = 0;

@@ -12,8 +12,14 @@
 // HBM traffic per level pixel: read prev (4 B) + gathered next (4 B, L2) + coarse flow
 // (2 B), write du, dv (8 B).  Nothing else leaves the CU.
 //
+// Two bodies share the arithmetic:
+//   * border tiles   -- every neighbour index goes through reflect101 / bounds checks;
+//   * interior tiles -- (the tile, its halo and the pyrUp support lie inside the image) no
+//     border logic at all, 16-byte global loads, and phases 2/3 run as vertical "marching"
+//     jobs that keep their sliding windows in registers (pyrUp column taps: 12 LDS reads per
+//     8 rows instead of 80; Sobel: 6 LDS reads per pixel instead of 18).
 // All arithmetic goes through lk_device.hpp / the fmaf chains below, identical to the
-// generic kernels in lk.hip and to the CPU oracle.
+// generic kernels in lk.hip and to the CPU oracle: both bodies produce the same bits.
 #include "lk_fused.hpp"
 
 #include <mutex>
@@ -32,36 +38,46 @@ struct LkCfg {
     static constexpr int R = R_;
     static constexpr int W = 2 * R + 1;
     static constexpr int TW = 64, TH = 32, NT = 256;
-    static constexpr int H = R + 1;                       // image halo (Sobel + window)
+    static constexpr int H = R + 1;                         // image halo (Sobel + window)
     static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;  // image region
-    static constexpr int PS = RW;                          // LDS row stride of P / Wp
+    static constexpr int PS = RW;                           // LDS row stride of P / Wp
     static constexpr int GW = TW + 2 * R, GH = TH + 2 * R;  // gradient region
-    static constexpr int GS = ((GW + 3) & ~3) + 4;          // 16-B aligned rows + pad
+    // Row stride of the gradient planes: 16-B aligned.  With GS/4 = 4 (mod 16) (GS = 80 for
+    // R = 7) the row pass's ds_read_b128 pattern (4 rows x 16 groups per wave) is conflict-free.
+    static constexpr int GS = (GW + 3) & ~3;
+    static constexpr int RBS = TW + 8;                      // row-buffer stride (conflict-free b128 stores)
     static constexpr int CW = RW / 2 + 3, CH = RH / 2 + 3;  // coarse flow block
     static constexpr int ROWS_PER_THREAD = TH / (NT / TW);  // 8
     static constexpr int IMG_F = 2 * RH * PS;
     static constexpr int FLOW_F = 2 * CH * CW + 2 * CH * RW;
     static constexpr int GRAD_F = 3 * GH * GS;
     static constexpr int X_F = FLOW_F > GRAD_F ? FLOW_F : GRAD_F;
-    static constexpr int ROWBUF_F = 2 * GH * TW;
+    static constexpr int ROWBUF_F = 2 * GH * RBS;
     static_assert(ROWBUF_F <= IMG_F, "row buffers alias the image tiles");
     static_assert(ROWS_PER_THREAD == 8, "column pass is written for 8 rows per thread");
     static constexpr int LDS_FLOATS = IMG_F + X_F;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
+    // The marching bodies of the interior path are written for 8-row segments.
+    static constexpr bool FAST = (H % 8 == 0) && (RW % 4 == 0);
 };
 
-// Row pass for one product field A*B over the gradient region.  Unit = 4 adjacent outputs.
+// ---- phase 4 building blocks ------------------------------------------------------------------
+
+// Row pass for one product field A*B over the gradient region.  Unit = 4 adjacent outputs of
+// one row; a wave covers 4 rows x 16 groups per iteration (lane = row_local + 4*group), which
+// makes its ds_read_b128 windows bank-conflict-free for GS = 80.
 template <typename C, bool SAME>
 __device__ __forceinline__ void row_pass(const float *__restrict__ A, const float *__restrict__ B,
                                          float *__restrict__ out, const TapsN<C::W> &g, int tid,
                                          int x0, int y0, int rows, int cols, bool xint) {
-    constexpr int R = C::R, GS = C::GS, TW = C::TW, GH = C::GH;
-    constexpr int UNITS = GH * (TW / 4);
-    for (int u = tid; u < UNITS; u += C::NT) {
-        const int qy = u / (TW / 4), grp = u % (TW / 4);
+    constexpr int R = C::R, GS = C::GS, GH = C::GH, RBS = C::RBS;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 2, c0 = 4 * grp;
+#pragma unroll 1
+    for (int it = 0; it < (GH + 15) / 16; it++) {
+        const int qy = it * 16 + wave * 4 + (lane & 3);
         const int gy = y0 - R + qy;
-        if ((unsigned)gy >= (unsigned)rows) continue;
-        const int c0 = 4 * grp;
+        if (qy >= GH || (unsigned)gy >= (unsigned)rows) continue;
         float o[4];
         if (xint) {
             float p[20];
@@ -100,7 +116,7 @@ __device__ __forceinline__ void row_pass(const float *__restrict__ A, const floa
                 o[j] = acc;
             }
         }
-        *reinterpret_cast<float4 *>(out + qy * TW + c0) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(out + qy * RBS + c0) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -109,11 +125,11 @@ template <typename C>
 __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S)[8],
                                          const TapsN<C::W> &g, int c, int r0, int y0, int rows,
                                          bool yint) {
-    constexpr int R = C::R, TW = C::TW;
+    constexpr int R = C::R, RBS = C::RBS;
     if (yint) {
         float v[8 + 2 * R];
 #pragma unroll
-        for (int i = 0; i < 8 + 2 * R; i++) v[i] = rb[(r0 + i) * TW + c];
+        for (int i = 0; i < 8 + 2 * R; i++) v[i] = rb[(r0 + i) * RBS + c];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             float acc = 0.f;
@@ -129,7 +145,7 @@ __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S
             if (gy < rows) {
                 for (int k = 0; k < C::W; k++) {
                     const int q = reflect101(gy + k - R, rows) - (y0 - R);
-                    acc = fmaf(rb[q * TW + c], g.k[k], acc);
+                    acc = fmaf(rb[q * RBS + c], g.k[k], acc);
                 }
             }
             S[j] = acc;
@@ -137,12 +153,14 @@ __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S
     }
 }
 
-template <int R, int MODE>
-__global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+// ---- the tile body ---------------------------------------------------------------------------
+
+template <int R, int MODE, bool INT>
+__device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
+                                        float *lds, int tile_x, int tile_y, int pair) {
     using C = LkCfg<R>;
     constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
     constexpr int GW = C::GW, GH = C::GH, GS = C::GS, CW = C::CW, CH = C::CH, NT = C::NT;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     float *P = lds;
     float *Wp = lds + RH * PS;
     float *X = lds + C::IMG_F;
@@ -152,30 +170,51 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
 
     const int tid = threadIdx.x;
     const int rows = a.rows, cols = a.cols;
-    const int tiles_x = (cols + TW - 1) / TW;
-    const int tile_y = blockIdx.x / tiles_x, tile_x = blockIdx.x - tile_y * tiles_x;
     const int x0 = tile_x * TW, y0 = tile_y * TH;
     const int rx0 = x0 - H, ry0 = y0 - H;
-    const int pair = blockIdx.y;
     const float *__restrict__ prev = a.prev + pair * a.img_pair;
     const float *__restrict__ next = a.next + pair * a.img_pair;
     const int istride = a.img_stride;
+    const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};  // Pyramids.cu:19
+    unsigned long long t_prev = 0;
+    if (a.stamps && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
+#define MICV_STAMP(k)                                                        \
+    if (a.stamps && tid == 0) {                                              \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();       \
+        atomicAdd(&a.stamps[(k) + (INT ? 0 : 8)], t_now - t_prev);           \
+        t_prev = t_now;                                                      \
+    }
 
     // ---- phase 0: prev tile (and next tile when there is no warp) ------------------------
-    for (int i = tid; i < RH * RW; i += NT) {
-        const int ly = i / RW, lx = i - ly * RW;
-        const int gy = ry0 + ly, gx = rx0 + lx;
-        if ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols) {
-            P[ly * PS + lx] = prev[(size_t)gy * istride + gx];
-            if (MODE == LK_FLOW_NONE) Wp[ly * PS + lx] = next[(size_t)gy * istride + gx];
+    const bool vec_ok = INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
+    if (INT && vec_ok) {
+        constexpr int V = RW / 4;
+        for (int i = tid; i < RH * V; i += NT) {
+            const int ly = i / V, lv = i - ly * V;
+            const size_t goff = (size_t)(ry0 + ly) * istride + rx0 + 4 * lv;
+            *reinterpret_cast<float4 *>(P + ly * PS + 4 * lv) =
+                *reinterpret_cast<const float4 *>(prev + goff);
+            if (MODE == LK_FLOW_NONE)
+                *reinterpret_cast<float4 *>(Wp + ly * PS + 4 * lv) =
+                    *reinterpret_cast<const float4 *>(next + goff);
+        }
+    } else {
+        for (int i = tid; i < RH * RW; i += NT) {
+            const int ly = i / RW, lx = i - ly * RW;
+            const int gy = ry0 + ly, gx = rx0 + lx;
+            if (INT || ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols)) {
+                P[ly * PS + lx] = prev[(size_t)gy * istride + gx];
+                if (MODE == LK_FLOW_NONE) Wp[ly * PS + lx] = next[(size_t)gy * istride + gx];
+            }
         }
     }
     float base_u[8], base_v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) base_u[j] = base_v[j] = 0.f;
+    MICV_STAMP(0)
 
     if (MODE != LK_FLOW_NONE) {
-        const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};  // Pyramids.cu:19
         int cx0 = 0, cy0 = 0;
         if (MODE == LK_FLOW_COARSE) {
             const float *__restrict__ fu = a.flow_u + pair * a.flow_pair;
@@ -195,11 +234,11 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
             for (int i = tid; i < CH * RW; i += NT) {
                 const int cy = i / RW, lx = i - cy * RW;
                 const int gx = rx0 + lx;
-                if ((unsigned)gx < (unsigned)cols && cy0 + cy < fr) {
+                if ((INT || (unsigned)gx < (unsigned)cols) && cy0 + cy < fr) {
                     float au = 0.f, av = 0.f;
 #pragma unroll
                     for (int k = 0; k < 5; k++) {
-                        const int sc = (reflect101(gx + k - 2, cols) >> 1) - cx0;
+                        const int sc = ((INT ? gx + k - 2 : reflect101(gx + k - 2, cols)) >> 1) - cx0;
                         au = fmaf(Cu[cy * CW + sc], g5[k], au);
                         av = fmaf(Cv[cy * CW + sc], g5[k], av);
                     }
@@ -208,88 +247,205 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
                 }
             }
             __syncthreads();
+            MICV_STAMP(1)
         }
         // ---- phase 2: base flow at every region pixel, warp `next` --------------------------
-        auto do_px = [&](int ly, int lx, float &bu, float &bv) {
-            const int gy = ry0 + ly, gx = rx0 + lx;
-            if ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols) return;
-            if (MODE == LK_FLOW_COARSE) {
-                float au = 0.f, av = 0.f;
+        if (INT && C::FAST) {
+            // Marching job: column lx, 8 region rows from ly0 (global row even).  The pyrUp column
+            // taps of rows 2m and 2m+1 read coarse rows {m-1,m-1,m,m,m+1} / {m-1,m,m,m+1,m+1}:
+            // six R values per field serve all 8 rows.
+            auto march = [&](int lx, int ly0, float *bu8, float *bv8) {
+                const int gx = rx0 + lx, gy0 = ry0 + ly0;
+                float ru[6], rv[6];
+                if (MODE == LK_FLOW_COARSE) {
+                    const int cyb = ((gy0 >> 1) - 1) - cy0;
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const int rr = (reflect101(gy + k - 2, rows) >> 1) - cy0;
-                    au = fmaf(Ru[rr * RW + lx], g5[k], au);
-                    av = fmaf(Rv[rr * RW + lx], g5[k], av);
+                    for (int i = 0; i < 6; i++) {
+                        ru[i] = Ru[(cyb + i) * RW + lx];
+                        rv[i] = Rv[(cyb + i) * RW + lx];
+                    }
                 }
-                bu = au * 2.f;  // OpticalFlow.cpp:142,144
-                bv = av * 2.f;
-            } else {
-                bu = a.flow_u[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
-                bv = a.flow_v[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
-            }
-            Wp[ly * PS + lx] = warp_sample(next, rows, cols, istride, gx, gy, bu, bv);
-        };
-        {
-            const int c = tid & (TW - 1), grp = tid / TW;
 #pragma unroll
-            for (int j = 0; j < 8; j++) do_px(H + 8 * grp + j, H + c, base_u[j], base_v[j]);
-        }
-        constexpr int NHALO = 2 * H * RW + TH * 2 * H;
-        for (int n = tid; n < NHALO; n += NT) {
-            int ly, lx;
-            if (n < 2 * H * RW) {
-                ly = n / RW;
-                lx = n - ly * RW;
-                if (ly >= H) ly += TH;
-            } else {
-                const int m = n - 2 * H * RW;
-                const int rr = m / (2 * H), cc = m - rr * (2 * H);
-                ly = H + rr;
-                lx = cc < H ? cc : TW + cc;
+                for (int p = 0; p < 4; p++) {
+#pragma unroll
+                    for (int o = 0; o < 2; o++) {
+                        const int j = 2 * p + o;
+                        float bu, bv;
+                        if (MODE == LK_FLOW_COARSE) {
+                            // even row: r[p],r[p],r[p+1],r[p+1],r[p+2]; odd: r[p],r[p+1],r[p+1],r[p+2],r[p+2]
+                            const int i1 = o ? p + 1 : p, i3 = o ? p + 2 : p + 1;
+                            float au = ru[p] * g5[0];
+                            au = fmaf(ru[i1], g5[1], au);
+                            au = fmaf(ru[p + 1], g5[2], au);
+                            au = fmaf(ru[i3], g5[3], au);
+                            au = fmaf(ru[p + 2], g5[4], au);
+                            float av = rv[p] * g5[0];
+                            av = fmaf(rv[i1], g5[1], av);
+                            av = fmaf(rv[p + 1], g5[2], av);
+                            av = fmaf(rv[i3], g5[3], av);
+                            av = fmaf(rv[p + 2], g5[4], av);
+                            bu = au * 2.f;  // OpticalFlow.cpp:142,144
+                            bv = av * 2.f;
+                        } else {
+                            bu = a.flow_u[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
+                            bv = a.flow_v[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
+                        }
+                        bu8[j] = bu;
+                        bv8[j] = bv;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    Wp[(ly0 + j) * PS + lx] =
+                        warp_sample(next, rows, cols, istride, gx, gy0 + j, bu8[j], bv8[j]);
+            };
+            march(H + (tid & (TW - 1)), H + 8 * (tid / TW), base_u, base_v);  // own outputs
+            // halo jobs: top / bottom bands (RW columns each), left / right bands (H columns x TH/8)
+            constexpr int NJ = 2 * RW + 2 * H * (TH / 8);
+            for (int n = tid; n < NJ; n += NT) {
+                int lx, ly0;
+                if (n < 2 * RW) {
+                    lx = n < RW ? n : n - RW;
+                    ly0 = n < RW ? 0 : H + TH;
+                } else {
+                    const int m = n - 2 * RW;
+                    const int seg = m / (2 * H), cc = m - seg * (2 * H);
+                    lx = cc < H ? cc : TW + cc;
+                    ly0 = H + 8 * seg;
+                }
+                float tu[8], tv[8];
+                march(lx, ly0, tu, tv);
             }
-            float du_, dv_;
-            do_px(ly, lx, du_, dv_);
+        } else {
+            auto do_px = [&](int ly, int lx, float &bu, float &bv) {
+                const int gy = ry0 + ly, gx = rx0 + lx;
+                if (!INT && ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols)) return;
+                if (MODE == LK_FLOW_COARSE) {
+                    float au = 0.f, av = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const int rr = ((INT ? gy + k - 2 : reflect101(gy + k - 2, rows)) >> 1) - cy0;
+                        au = fmaf(Ru[rr * RW + lx], g5[k], au);
+                        av = fmaf(Rv[rr * RW + lx], g5[k], av);
+                    }
+                    bu = au * 2.f;  // OpticalFlow.cpp:142,144
+                    bv = av * 2.f;
+                } else {
+                    bu = a.flow_u[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
+                    bv = a.flow_v[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
+                }
+                Wp[ly * PS + lx] = warp_sample(next, rows, cols, istride, gx, gy, bu, bv);
+            };
+            {
+                const int c = tid & (TW - 1), grp = tid / TW;
+#pragma unroll
+                for (int j = 0; j < 8; j++) do_px(H + 8 * grp + j, H + c, base_u[j], base_v[j]);
+            }
+            constexpr int NHALO = 2 * H * RW + TH * 2 * H;
+            for (int n = tid; n < NHALO; n += NT) {
+                int ly, lx;
+                if (n < 2 * H * RW) {
+                    ly = n / RW;
+                    lx = n - ly * RW;
+                    if (ly >= H) ly += TH;
+                } else {
+                    const int m = n - 2 * H * RW;
+                    const int rr = m / (2 * H), cc = m - rr * (2 * H);
+                    ly = H + rr;
+                    lx = cc < H ? cc : TW + cc;
+                }
+                float du_, dv_;
+                do_px(ly, lx, du_, dv_);
+            }
         }
     }
     __syncthreads();
+    MICV_STAMP(2)
 
     // ---- phase 3: gradients --------------------------------------------------------------
     {
         const float s1 = 1.f / 9.f, s2 = 2.f * s1;  // OpticalFlow.cpp:19
-        for (int i = tid; i < GH * GW; i += NT) {
-            const int qy = i / GW, qx = i - qy * GW;
-            const int gy = y0 - R + qy, gx = x0 - R + qx;
-            if ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols) continue;
-            int ly[3], lx[3];
+        if (INT) {
+            // Marching job: gradient column qx, a run of gradient rows.  Row pass of the Sobel
+            // pair (tx = right - left, ty = [s,2s,s]) is computed once per image row and kept in
+            // a 3-row register window; the column pass finishes one output per step.
+            constexpr int SEG = 16, NSEG = (GH + SEG - 1) / SEG;
+            for (int n = tid; n < GW * NSEG; n += NT) {
+                const int seg = n / GW, qx = n - seg * GW;
+                const int q0 = seg * SEG, q1 = q0 + SEG < GH ? q0 + SEG : GH;
+                const int lx = qx + (H - R);
+                // image rows ly = qy + (H - R) - 1 .. : window rows a (ly-1), b (ly), c (ly+1)
+                float ptx[3], pty[3], wtx[3], wty[3], pc[3], wc[3];
+                auto rowpass = [&](int ly, int slot) {
+                    const float *pr = P + ly * PS + lx, *wr = Wp + ly * PS + lx;
+                    const float pa = pr[-1], pb = pr[0], pcv = pr[1];
+                    const float wa = wr[-1], wb = wr[0], wcv = wr[1];
+                    ptx[slot] = pcv - pa;
+                    pty[slot] = fmaf(pcv, s1, fmaf(pb, s2, pa * s1));
+                    wtx[slot] = wcv - wa;
+                    wty[slot] = fmaf(wcv, s1, fmaf(wb, s2, wa * s1));
+                    pc[slot] = pb;
+                    wc[slot] = wb;
+                };
+                const int lyb = q0 + (H - R);  // image row of gradient row q0
+                rowpass(lyb - 1, 0);
+                rowpass(lyb, 1);
+#pragma unroll 1
+                for (int qy = q0; qy < q1; qy += 3) {
+                    // three outputs per trip so the window slots stay compile-time constants
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                ly[j] = (reflect101(gy + j - 1, rows) - ry0) * PS;
-                lx[j] = reflect101(gx + j - 1, cols) - rx0;
-            }
-            float Pn[3][3], Nn[3][3];
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    Pn[j][k] = P[ly[j] + lx[k]];
-                    Nn[j][k] = Wp[ly[j] + lx[k]];
+                    for (int t = 0; t < 3; t++) {
+                        if (qy + t < q1) {
+                            const int s_new = (t + 2) % 3, s_top = t % 3, s_mid = (t + 1) % 3;
+                            rowpass(qy + t + (H - R) + 1, s_new);
+                            const float pgx = fmaf(ptx[s_new], s1, fmaf(ptx[s_mid], s2, ptx[s_top] * s1));
+                            const float pgy = pty[s_new] - pty[s_top];
+                            const float ngx = fmaf(wtx[s_new], s1, fmaf(wtx[s_mid], s2, wtx[s_top] * s1));
+                            const float ngy = wty[s_new] - wty[s_top];
+                            Gx[(qy + t) * GS + qx] = avg2(ngx, pgx);
+                            Gy[(qy + t) * GS + qx] = avg2(ngy, pgy);
+                            Gt[(qy + t) * GS + qx] = wc[s_mid] - pc[s_mid];
+                        }
+                    }
                 }
-            float pgx, pgy, ngx, ngy;
-            sobel3(Pn, s1, s2, pgx, pgy);
-            sobel3(Nn, s1, s2, ngx, ngy);
-            Gx[qy * GS + qx] = avg2(ngx, pgx);
-            Gy[qy * GS + qx] = avg2(ngy, pgy);
-            Gt[qy * GS + qx] = Nn[1][1] - Pn[1][1];
+            }
+        } else {
+            for (int i = tid; i < GH * GW; i += NT) {
+                const int qy = i / GW, qx = i - qy * GW;
+                const int gy = y0 - R + qy, gx = x0 - R + qx;
+                if ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols) continue;
+                int ly[3], lx[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    ly[j] = (reflect101(gy + j - 1, rows) - ry0) * PS;
+                    lx[j] = reflect101(gx + j - 1, cols) - rx0;
+                }
+                float Pn[3][3], Nn[3][3];
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        Pn[j][k] = P[ly[j] + lx[k]];
+                        Nn[j][k] = Wp[ly[j] + lx[k]];
+                    }
+                float pgx, pgy, ngx, ngy;
+                sobel3(Pn, s1, s2, pgx, pgy);
+                sobel3(Nn, s1, s2, ngx, ngy);
+                Gx[qy * GS + qx] = avg2(ngx, pgx);
+                Gy[qy * GS + qx] = avg2(ngy, pgy);
+                Gt[qy * GS + qx] = Nn[1][1] - Pn[1][1];
+            }
         }
     }
     __syncthreads();
+    MICV_STAMP(3)
 
     // ---- phase 4: five window sums -----------------------------------------------------------
-    const bool xint = (x0 - R >= 0) && (x0 + TW + R <= cols);
-    const bool yint = (y0 - R >= 0) && (y0 + TH + R <= rows);
+    const bool xint = INT || ((x0 - R >= 0) && (x0 + TW + R <= cols));
+    const bool yint = INT || ((y0 - R >= 0) && (y0 + TH + R <= rows));
     const int c = tid & (TW - 1), r0 = 8 * (tid / TW);
     float Sxx[8], Sxy[8], Syy[8], Sxt[8], Syt[8];
-    float *rb0 = rowbuf, *rb1 = rowbuf + GH * TW;
+    float *rb0 = rowbuf, *rb1 = rowbuf + GH * C::RBS;
 
     row_pass<C, true>(Gx, Gx, rb0, g, tid, x0, y0, rows, cols, xint);
     __syncthreads();
@@ -306,16 +462,17 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
     row_pass<C, false>(Gy, Gt, rb0, g, tid, x0, y0, rows, cols, xint);
     __syncthreads();
     col_pass<C>(rb0, Syt, g, c, r0, y0, rows, yint);
+    MICV_STAMP(4)
 
     // ---- phase 5: solve + store ----------------------------------------------------------------
     float *__restrict__ ou = a.out_u + pair * a.out_pair;
     float *__restrict__ ov = a.out_v + pair * a.out_pair;
     const int gx = x0 + c;
-    if (gx < cols) {
+    if (INT || gx < cols) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int gy = y0 + r0 + j;
-            if (gy < rows) {
+            if (INT || gy < rows) {
                 float uu, vv;
                 lk_solve(Sxx[j], Sxy[j], Syy[j], Sxt[j], Syt[j], uu, vv);
                 if (a.add_base) {
@@ -327,6 +484,29 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
             }
         }
     }
+    MICV_STAMP(5)
+#undef MICV_STAMP
+}
+
+template <int R, int MODE>
+__global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+    using C = LkCfg<R>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
+    // and b+8 share an L2.  Give each XCD a contiguous run of row-major tiles, so neighbouring
+    // tiles (which share halo rows of prev / next / coarse flow) hit the same L2.  Speed only.
+    const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t = xcd * per + (xcd < rem ? xcd : rem) + idx;
+    const int tiles_x = (a.cols + C::TW - 1) / C::TW;
+    const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
+    const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
+    const bool interior = rx0 - 2 >= 0 && rx0 + C::RW + 2 <= a.cols && ry0 - 2 >= 0 &&
+                          ry0 + C::RH + 2 <= a.rows;
+    if (interior)
+        lk_tile<R, MODE, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
+    else
+        lk_tile<R, MODE, false>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
 bool lk_fused_supports(int win) { return win == 15 || win == 7; }
@@ -336,7 +516,6 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     using C = LkCfg<R>;
     static TapsN<2 * R + 1> taps;
     static std::once_flag once;
-    static bool attr_ok = true;
     std::call_once(once, [] {
         Taps t;
         gaussian_taps(2 * R + 1, (double)((float)(2 * R + 1) / 3.f), &t);  // OpticalFlow.cpp:73
@@ -360,7 +539,6 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             done_dev = dev;
         }
     }
-    (void)attr_ok;
     const dim3 grid(cdiv(a.cols, C::TW) * cdiv(a.rows, C::TH), a.batch);
     switch (a.mode) {
         case LK_FLOW_NONE:
