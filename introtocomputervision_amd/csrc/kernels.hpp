@@ -29,6 +29,10 @@ int launch_pyr_build(hipStream_t s, const float *src, size_t img_elems, int sstr
                      int cols, int levels, float *const *dst, int batch);
 int launch_resize_linear(hipStream_t s, const float *src, int srows, int scols, int sstride,
                          float *dst, int drows, int dcols, int dstride);
+// du = resize(2 * pyrUp(du_coarse), drows x dcols) for `batch` pairs and both fields, one launch.
+int launch_flow_expand_resize(hipStream_t s, const float *src_u, const float *src_v, int fr, int fc,
+                              size_t src_pair, float *dst_u, float *dst_v, int drows, int dcols,
+                              size_t dst_pair, int batch);
 int launch_warp(hipStream_t s, const float *src, int sstride, const float *du, const float *dv,
                 int fstride, int rows, int cols, float *dst, int dstride);
 

@@ -216,20 +216,11 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
                 a.flow_u = fu[cur]; a.flow_v = fv[cur];
                 a.flow_rows = fr; a.flow_cols = fc; a.flow_pair = (size_t)fr * fc;
             } else {
-                // OpticalFlow.cpp:148-151: odd sizes -> pyrUp, x2, cv::resize, per pair.
-                const size_t up = (size_t)fr * 2 * fc * 2;
+                // OpticalFlow.cpp:139-151: odd sizes -> pyrUp, x2, cv::resize; one launch for
+                // the whole batch and both fields.
                 float *full_u = fu[cur ^ 1], *full_v = fv[cur ^ 1];  // becomes this level's base
-                for (int b = 0; b < batch; b++) {
-                    MICV_TRY(launch_pyr_up(s, fu[cur] + b * (size_t)fr * fc, fr, fc, fc, tmp_a,
-                                           2 * fc, 2.f, tmp_b));
-                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc,
-                                                  full_u + b * lvl_elems, R, C, C));
-                    MICV_TRY(launch_pyr_up(s, fv[cur] + b * (size_t)fr * fc, fr, fc, fc, tmp_a,
-                                           2 * fc, 2.f, tmp_b));
-                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc,
-                                                  full_v + b * lvl_elems, R, C, C));
-                }
-                (void)up;
+                MICV_TRY(launch_flow_expand_resize(s, fu[cur], fv[cur], fr, fc, (size_t)fr * fc,
+                                                   full_u, full_v, R, C, lvl_elems, batch));
                 a.mode = LK_FLOW_FULL;
                 a.flow_u = full_u; a.flow_v = full_v;
                 a.flow_rows = R; a.flow_cols = C; a.flow_pair = lvl_elems;
@@ -299,7 +290,7 @@ int micv_lk_flow_pyr_batch_dev(micv_ctx *ctx, const float *prev, const float *ne
                                size_t ostride, micv_stream stream) {
     MICV_TRY(check_lk_args("micv_lk_flow_pyr", ctx, prev, next, u, v, rows, cols, stride, ostride,
                            win));
-    MICV_REQUIRE(batch >= 1 && batch <= 65535, "micv_lk_flow_pyr: bad batch %d", batch);
+    MICV_REQUIRE(batch >= 1 && batch <= 32767, "micv_lk_flow_pyr: bad batch %d", batch);
     MICV_REQUIRE(levels >= 1 && levels <= 16 && (rows >> (levels - 1)) > 0 &&
                      (cols >> (levels - 1)) > 0,
                  "micv_lk_flow_pyr: %d levels do not fit a %dx%d image", levels, rows, cols);

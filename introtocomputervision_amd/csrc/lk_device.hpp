@@ -41,6 +41,44 @@ __device__ __forceinline__ void lk_solve(float sxx, float sxy, float syy, float 
     }
 }
 
+// The same sample, with the four taps served from an LDS copy of `next` when they fall inside
+// the staged window [nx0, nx0+NW) x [ny0, ny0+NH) (which must lie inside the image) and from
+// global memory otherwise.  Coordinates, weights and the blend are identical to warp_sample.
+template <int NW, int NH>
+__device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N, int nx0, int ny0,
+                                                    const float *__restrict__ src, int rows,
+                                                    int cols, int stride, int x, int y, float du,
+                                                    float dv) {
+    const float mx = (float)x + du, my = (float)y + dv;
+    const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
+    const int fx = sx & 31, fy = sy & 31;
+    const int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+    const float ax1 = (float)fx * 0.03125f, ax0 = 1.f - ax1;
+    const float ay1 = (float)fy * 0.03125f, ay0 = 1.f - ay1;
+    float v0, v1, v2, v3;
+    const int lx = ix - nx0, ly = iy - ny0;
+    if ((unsigned)lx < (unsigned)(NW - 1) && (unsigned)ly < (unsigned)(NH - 1)) {
+        const float *p = N + ly * NW + lx;
+        v0 = p[0];
+        v1 = p[1];
+        v2 = p[NW];
+        v3 = p[NW + 1];
+    } else {
+        const bool x0 = (unsigned)ix < (unsigned)cols, x1 = (unsigned)(ix + 1) < (unsigned)cols;
+        const bool y0 = (unsigned)iy < (unsigned)rows, y1 = (unsigned)(iy + 1) < (unsigned)rows;
+        const float *p = src + (ptrdiff_t)iy * stride + ix;
+        v0 = (x0 && y0) ? p[0] : 0.f;
+        v1 = (x1 && y0) ? p[1] : 0.f;
+        v2 = (x0 && y1) ? p[stride] : 0.f;
+        v3 = (x1 && y1) ? p[stride + 1] : 0.f;
+    }
+    float r = v0 * (ay0 * ax0);
+    r = r + v1 * (ay0 * ax1);
+    r = r + v2 * (ay1 * ax0);
+    r = r + v3 * (ay1 * ax1);
+    return r;
+}
+
 // lk::warp (OpticalFlow.cpp:111-119) for one pixel: map = (x + du, y + dv); cv::remap
 // INTER_LINEAR with 1/32-pixel fixed-point coordinates, BORDER_CONSTANT(0).
 __device__ __forceinline__ float warp_sample(const float *__restrict__ src, int rows, int cols,

@@ -1,25 +1,27 @@
 // lk_fused.hip -- one pyramid level of Lucas-Kanade as ONE LDS-tiled kernel (gfx950).
 //
 // Per 64x32 output tile (256 threads = 4 wave64, 2 workgroups per CU by LDS):
-//   phase 0  stage the prev tile (+R+1 halo) and the coarse flow block in LDS
-//   phase 1  pyrUp row pass of the coarse flow              (Pyramids.cu:126, fused)
-//   phase 2  pyrUp column pass, x2, lk::warp gather of `next` -> warped tile in LDS
-//   phase 3  Sobel pairs of prev / warped, Ix Iy It -> LDS  (OpticalFlow.cpp:60-64)
-//   phase 4  five Gaussian-weighted window sums: products formed on the fly, separable
-//            (2R+1)-tap row pass (4 outputs per thread, ds_read_b128 window) into a
-//            double-buffered LDS row buffer, column pass (8 outputs per thread) in registers
+//   phase 0  stage in LDS: the prev tile (+R+1 halo), a window of `next` (tile + halo + 8 px
+//            margin) and the coarse flow block                     -- 16-byte coalesced loads
+//   phase 2  "marching" jobs (one column x 8 rows each): pyrUp of the coarse flow (row taps,
+//            column taps, x2 -- Pyramids.cu:126-127, OpticalFlow.cpp:142), then lk::warp of
+//            `next` with the 4 bilinear taps served from the LDS window (global fallback for
+//            flows that leave it)                                      -> warped tile in LDS
+//   phase 3  Sobel pairs of prev / warped with a 3-row register window, Ix Iy It -> LDS
+//   phase 4  five Gaussian-weighted window sums in two sweeps (xx,xy,yy then xt,yt): products
+//            formed on the fly, separable (2R+1)-tap row pass (4 outputs per thread from
+//            ds_read_b128 windows) into XOR-swizzled LDS row buffers, column pass (8 outputs
+//            per thread) in registers
 //   phase 5  2x2 solve in double, add the base flow, store du / dv
-// HBM traffic per level pixel: read prev (4 B) + gathered next (4 B, L2) + coarse flow
-// (2 B), write du, dv (8 B).  Nothing else leaves the CU.
+// HBM traffic per level pixel: read prev (4 B) + next (4 B) + coarse flow (2 B), write du, dv
+// (8 B).  Nothing else leaves the CU.
 //
-// Two bodies share the arithmetic:
-//   * border tiles   -- every neighbour index goes through reflect101 / bounds checks;
-//   * interior tiles -- (the tile, its halo and the pyrUp support lie inside the image) no
-//     border logic at all, 16-byte global loads, and phases 2/3 run as vertical "marching"
-//     jobs that keep their sliding windows in registers (pyrUp column taps: 12 LDS reads per
-//     8 rows instead of 80; Sobel: 6 LDS reads per pixel instead of 18).
+// Border tiles (tile, halo or pyrUp support touching the image edge) run a slower body for
+// phases 0-3 (reflect101 / bounds checks on every neighbour, separate pyrUp row-pass phase,
+// global gathers), then fill the out-of-image cells of the gradient planes by reflection so
+// that phase 4 is the same straight-line code for every tile.
 // All arithmetic goes through lk_device.hpp / the fmaf chains below, identical to the
-// generic kernels in lk.hip and to the CPU oracle: both bodies produce the same bits.
+// generic kernels in lk.hip and to the CPU oracle: every body produces the same bits.
 #include "lk_fused.hpp"
 
 #include <mutex>
@@ -45,111 +47,80 @@ struct LkCfg {
     // Row stride of the gradient planes: 16-B aligned.  With GS/4 = 4 (mod 16) (GS = 80 for
     // R = 7) the row pass's ds_read_b128 pattern (4 rows x 16 groups per wave) is conflict-free.
     static constexpr int GS = (GW + 3) & ~3;
-    static constexpr int RBS = TW + 8;                      // row-buffer stride (conflict-free b128 stores)
+    static constexpr int RBS = TW;                          // row-buffer stride (XOR-swizzled chunks)
     static constexpr int CW = RW / 2 + 3, CH = RH / 2 + 3;  // coarse flow block
+    static constexpr int M = 8;                             // margin of the staged `next` window
+    static constexpr int NW = RW + 2 * M, NH = RH + 2 * M;
     static constexpr int ROWS_PER_THREAD = TH / (NT / TW);  // 8
-    static constexpr int IMG_F = 2 * RH * PS;
-    static constexpr int FLOW_F = 2 * CH * CW + 2 * CH * RW;
+    static constexpr int ROWBUF_F = 3 * GH * RBS;
+    static constexpr int IMG_F = (2 * RH * PS > ROWBUF_F ? 2 * RH * PS : ROWBUF_F);
+    static constexpr int C_F = (2 * CH * CW + 3) & ~3;         // coarse block, both fields, 16-B padded
+    static constexpr int FLOW_F = C_F + 2 * CH * RW;           // border tiles: C + R
+    static constexpr int STAGE_F = C_F + NW * NH;              // interior tiles: C + next window
     static constexpr int GRAD_F = 3 * GH * GS;
-    static constexpr int X_F = FLOW_F > GRAD_F ? FLOW_F : GRAD_F;
-    static constexpr int ROWBUF_F = 2 * GH * RBS;
-    static_assert(ROWBUF_F <= IMG_F, "row buffers alias the image tiles");
+    static constexpr int X_F = (FLOW_F > GRAD_F ? FLOW_F : GRAD_F) > STAGE_F
+                                   ? (FLOW_F > GRAD_F ? FLOW_F : GRAD_F)
+                                   : STAGE_F;
     static_assert(ROWS_PER_THREAD == 8, "column pass is written for 8 rows per thread");
     static constexpr int LDS_FLOATS = IMG_F + X_F;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
-    // The marching bodies of the interior path are written for 8-row segments.
+    // The marching body of phase 2 is written for 8-row segments and 16-B rows.
     static constexpr bool FAST = (H % 8 == 0) && (RW % 4 == 0);
 };
 
 // ---- phase 4 building blocks ------------------------------------------------------------------
 
-// Row pass for one product field A*B over the gradient region.  Unit = 4 adjacent outputs of
-// one row; a wave covers 4 rows x 16 groups per iteration (lane = row_local + 4*group), which
-// makes its ds_read_b128 windows bank-conflict-free for GS = 80.
-template <typename C, bool SAME>
-__device__ __forceinline__ void row_pass(const float *__restrict__ A, const float *__restrict__ B,
-                                         float *__restrict__ out, const TapsN<C::W> &g, int tid,
-                                         int x0, int y0, int rows, int cols, bool xint) {
-    constexpr int R = C::R, GS = C::GS, GH = C::GH, RBS = C::RBS;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int grp = lane >> 2, c0 = 4 * grp;
-#pragma unroll 1
-    for (int it = 0; it < (GH + 15) / 16; it++) {
-        const int qy = it * 16 + wave * 4 + (lane & 3);
-        const int gy = y0 - R + qy;
-        if (qy >= GH || (unsigned)gy >= (unsigned)rows) continue;
-        float o[4];
-        if (xint) {
-            float p[20];
-            const float4 *a4 = reinterpret_cast<const float4 *>(A + qy * GS + c0);
-            const float4 *b4 = reinterpret_cast<const float4 *>(B + qy * GS + c0);
+// Row-buffer addressing: row q, 16-byte chunk ch lives at chunk (ch ^ 2*(q&3)).  The row
+// pass's b128 stores (4 rows x 2 chunks per 8-lane group) and the column pass's b32 loads are
+// both bank-conflict-free with this layout at a 64-float row pitch.
+__device__ __forceinline__ int rb_off(int q, int chunk) { return q * 64 + 4 * (chunk ^ (2 * (q & 3))); }
+
+template <typename C>
+__device__ __forceinline__ void load_window(const float *__restrict__ A, int qy, int c0, float (&w)[20]) {
+    const float4 *a4 = reinterpret_cast<const float4 *>(A + qy * C::GS + c0);
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
-                if (4 * i >= 4 + 2 * R) break;
-                const float4 av = a4[i];
-                const float4 bv = SAME ? av : b4[i];
-                p[4 * i + 0] = av.x * bv.x;
-                p[4 * i + 1] = av.y * bv.y;
-                p[4 * i + 2] = av.z * bv.z;
-                p[4 * i + 3] = av.w * bv.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < C::W; k++) acc = fmaf(p[j + k], g.k[k], acc);
-                o[j] = acc;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float acc = 0.f;
-                const int gx = x0 + c0 + j;
-                if (gx < cols) {
-                    for (int k = 0; k < C::W; k++) {
-                        const int q = reflect101(gx + k - R, cols) - (x0 - R);
-                        const float av = A[qy * GS + q];
-                        const float bv = SAME ? av : B[qy * GS + q];
-                        acc = fmaf(av * bv, g.k[k], acc);
-                    }
-                }
-                o[j] = acc;
-            }
-        }
-        *reinterpret_cast<float4 *>(out + qy * RBS + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    for (int i = 0; i < 5; i++) {
+        if (4 * i >= 4 + 2 * C::R) break;
+        const float4 v = a4[i];
+        w[4 * i + 0] = v.x;
+        w[4 * i + 1] = v.y;
+        w[4 * i + 2] = v.z;
+        w[4 * i + 3] = v.w;
     }
 }
 
-// Column pass: thread (c, grp8) produces 8 vertically adjacent window sums.
+// Four adjacent outputs of the (2R+1)-tap row pass of the product field a*b.
+template <typename C>
+__device__ __forceinline__ void row_taps(const float (&a)[20], const float (&b)[20],
+                                         const TapsN<C::W> &g, float *__restrict__ out) {
+    float p[4 + 2 * C::R];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * C::R; i++) p[i] = a[i] * b[i];
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < C::W; k++) acc = fmaf(p[j + k], g.k[k], acc);
+        o[j] = acc;
+    }
+    *reinterpret_cast<float4 *>(out) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// Column pass: thread (c, r0) produces 8 vertically adjacent window sums from one row buffer.
 template <typename C>
 __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S)[8],
-                                         const TapsN<C::W> &g, int c, int r0, int y0, int rows,
-                                         bool yint) {
-    constexpr int R = C::R, RBS = C::RBS;
-    if (yint) {
-        float v[8 + 2 * R];
+                                         const TapsN<C::W> &g, int c, int r0) {
+    constexpr int R = C::R;
+    float v[8 + 2 * R];
 #pragma unroll
-        for (int i = 0; i < 8 + 2 * R; i++) v[i] = rb[(r0 + i) * RBS + c];
+    for (int i = 0; i < 8 + 2 * R; i++) v[i] = rb[rb_off(r0 + i, c >> 2) + (c & 3)];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float acc = 0.f;
+    for (int j = 0; j < 8; j++) {
+        float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < C::W; k++) acc = fmaf(v[j + k], g.k[k], acc);
-            S[j] = acc;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float acc = 0.f;
-            const int gy = y0 + r0 + j;
-            if (gy < rows) {
-                for (int k = 0; k < C::W; k++) {
-                    const int q = reflect101(gy + k - R, rows) - (y0 - R);
-                    acc = fmaf(rb[q * RBS + c], g.k[k], acc);
-                }
-            }
-            S[j] = acc;
-        }
+        for (int k = 0; k < C::W; k++) acc = fmaf(v[j + k], g.k[k], acc);
+        S[j] = acc;
     }
 }
 
@@ -161,12 +132,16 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     using C = LkCfg<R>;
     constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
     constexpr int GW = C::GW, GH = C::GH, GS = C::GS, CW = C::CW, CH = C::CH, NT = C::NT;
+    constexpr int M = C::M, NW = C::NW, NH = C::NH;
+    constexpr bool STAGED = INT && C::FAST && MODE != LK_FLOW_NONE;  // next window in LDS
     float *P = lds;
     float *Wp = lds + RH * PS;
     float *X = lds + C::IMG_F;
-    float *Cu = X, *Cv = X + CH * CW, *Ru = X + 2 * CH * CW, *Rv = Ru + CH * RW;
+    float *Cu = X, *Cv = X + CH * CW;
+    float *Ru = X + C::C_F, *Rv = Ru + CH * RW;  // border tiles
+    float *Nx = X + C::C_F;                       // interior tiles (aliases Ru/Rv)
     float *Gx = X, *Gy = X + GH * GS, *Gt = X + 2 * GH * GS;
-    float *rowbuf = lds;  // aliases P / Wp after phase 3
+    float *rb0 = lds, *rb1 = lds + GH * C::RBS, *rb2 = lds + 2 * GH * C::RBS;  // alias P / Wp
 
     const int tid = threadIdx.x;
     const int rows = a.rows, cols = a.cols;
@@ -185,7 +160,22 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         t_prev = t_now;                                                      \
     }
 
-    // ---- phase 0: prev tile (and next tile when there is no warp) ------------------------
+    // ---- phase 0: stage prev (+ next / its window) and the coarse flow block -----------------
+    int cx0 = 0, cy0 = 0;
+    if (MODE == LK_FLOW_COARSE) {
+        const float *__restrict__ fu = a.flow_u + pair * a.flow_pair;
+        const float *__restrict__ fv = a.flow_v + pair * a.flow_pair;
+        const int fr = a.flow_rows, fc = a.flow_cols;
+        cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
+        cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
+        for (int i = tid; i < CH * CW; i += NT) {
+            const int cy = i / CW, cx = i - cy * CW;
+            if (cy0 + cy < fr && cx0 + cx < fc) {
+                Cu[i] = fu[(size_t)(cy0 + cy) * fc + cx0 + cx];
+                Cv[i] = fv[(size_t)(cy0 + cy) * fc + cx0 + cx];
+            }
+        }
+    }
     const bool vec_ok = INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
     if (INT && vec_ok) {
@@ -199,6 +189,14 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 *reinterpret_cast<float4 *>(Wp + ly * PS + 4 * lv) =
                     *reinterpret_cast<const float4 *>(next + goff);
         }
+        if (STAGED) {
+            constexpr int VN = NW / 4;
+            for (int i = tid; i < NH * VN; i += NT) {
+                const int ly = i / VN, lv = i - ly * VN;
+                *reinterpret_cast<float4 *>(Nx + ly * NW + 4 * lv) = *reinterpret_cast<const float4 *>(
+                    next + (size_t)(ry0 - M + ly) * istride + rx0 - M + 4 * lv);
+            }
+        }
     } else {
         for (int i = tid; i < RH * RW; i += NT) {
             const int ly = i / RW, lx = i - ly * RW;
@@ -208,61 +206,51 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 if (MODE == LK_FLOW_NONE) Wp[ly * PS + lx] = next[(size_t)gy * istride + gx];
             }
         }
+        if (STAGED) {
+            for (int i = tid; i < NH * NW; i += NT) {
+                const int ly = i / NW, lx = i - ly * NW;
+                Nx[i] = next[(size_t)(ry0 - M + ly) * istride + rx0 - M + lx];
+            }
+        }
     }
     float base_u[8], base_v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) base_u[j] = base_v[j] = 0.f;
+    if (MODE != LK_FLOW_NONE) __syncthreads();
     MICV_STAMP(0)
 
     if (MODE != LK_FLOW_NONE) {
-        int cx0 = 0, cy0 = 0;
-        if (MODE == LK_FLOW_COARSE) {
-            const float *__restrict__ fu = a.flow_u + pair * a.flow_pair;
-            const float *__restrict__ fv = a.flow_v + pair * a.flow_pair;
-            const int fr = a.flow_rows, fc = a.flow_cols;
-            cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
-            cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
-            for (int i = tid; i < CH * CW; i += NT) {
-                const int cy = i / CW, cx = i - cy * CW;
-                if (cy0 + cy < fr && cx0 + cx < fc) {
-                    Cu[i] = fu[(size_t)(cy0 + cy) * fc + cx0 + cx];
-                    Cv[i] = fv[(size_t)(cy0 + cy) * fc + cx0 + cx];
-                }
-            }
-            __syncthreads();
-            // ---- phase 1: pyrUp row pass, once per coarse row (replicated rows are equal) --
-            for (int i = tid; i < CH * RW; i += NT) {
-                const int cy = i / RW, lx = i - cy * RW;
-                const int gx = rx0 + lx;
-                if ((INT || (unsigned)gx < (unsigned)cols) && cy0 + cy < fr) {
-                    float au = 0.f, av = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        const int sc = ((INT ? gx + k - 2 : reflect101(gx + k - 2, cols)) >> 1) - cx0;
-                        au = fmaf(Cu[cy * CW + sc], g5[k], au);
-                        av = fmaf(Cv[cy * CW + sc], g5[k], av);
-                    }
-                    Ru[i] = au;
-                    Rv[i] = av;
-                }
-            }
-            __syncthreads();
-            MICV_STAMP(1)
-        }
         // ---- phase 2: base flow at every region pixel, warp `next` --------------------------
         if (INT && C::FAST) {
-            // Marching job: column lx, 8 region rows from ly0 (global row even).  The pyrUp column
-            // taps of rows 2m and 2m+1 read coarse rows {m-1,m-1,m,m,m+1} / {m-1,m,m,m+1,m+1}:
-            // six R values per field serve all 8 rows.
+            // Marching job: column lx, 8 region rows from ly0 (global row even).
+            // pyrUp = 2x replicate + [1,4,6,4,1]/16 rows then columns.  Row taps of column gx read
+            // coarse columns {m-1,m-1,m,m,m+1} (gx = 2m) or {m-1,m,m,m+1,m+1} (gx = 2m+1); column
+            // taps of rows 2m / 2m+1 read the same pattern of coarse rows: six row-pass values per
+            // field, built from 3 coarse columns each, serve all 8 rows.
             auto march = [&](int lx, int ly0, float *bu8, float *bv8) {
                 const int gx = rx0 + lx, gy0 = ry0 + ly0;
                 float ru[6], rv[6];
                 if (MODE == LK_FLOW_COARSE) {
                     const int cyb = ((gy0 >> 1) - 1) - cy0;
+                    const int ccb = ((gx >> 1) - 1) - cx0;
+                    const bool odd = gx & 1;
 #pragma unroll
                     for (int i = 0; i < 6; i++) {
-                        ru[i] = Ru[(cyb + i) * RW + lx];
-                        rv[i] = Rv[(cyb + i) * RW + lx];
+                        const float *cu = Cu + (cyb + i) * CW + ccb, *cv = Cv + (cyb + i) * CW + ccb;
+                        const float u0 = cu[0], u1 = cu[1], u2 = cu[2];
+                        const float v0 = cv[0], v1 = cv[1], v2 = cv[2];
+                        const float ua = odd ? u1 : u0, ub = odd ? u2 : u1;
+                        const float va = odd ? v1 : v0, vb = odd ? v2 : v1;
+                        float t = u0 * g5[0];
+                        t = fmaf(ua, g5[1], t);
+                        t = fmaf(u1, g5[2], t);
+                        t = fmaf(ub, g5[3], t);
+                        ru[i] = fmaf(u2, g5[4], t);
+                        t = v0 * g5[0];
+                        t = fmaf(va, g5[1], t);
+                        t = fmaf(v1, g5[2], t);
+                        t = fmaf(vb, g5[3], t);
+                        rv[i] = fmaf(v2, g5[4], t);
                     }
                 }
 #pragma unroll
@@ -272,7 +260,6 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         const int j = 2 * p + o;
                         float bu, bv;
                         if (MODE == LK_FLOW_COARSE) {
-                            // even row: r[p],r[p],r[p+1],r[p+1],r[p+2]; odd: r[p],r[p+1],r[p+1],r[p+2],r[p+2]
                             const int i1 = o ? p + 1 : p, i3 = o ? p + 2 : p + 1;
                             float au = ru[p] * g5[0];
                             au = fmaf(ru[i1], g5[1], au);
@@ -296,8 +283,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    Wp[(ly0 + j) * PS + lx] =
-                        warp_sample(next, rows, cols, istride, gx, gy0 + j, bu8[j], bv8[j]);
+                    Wp[(ly0 + j) * PS + lx] = warp_sample_staged<NW, NH>(
+                        Nx, rx0 - M, ry0 - M, next, rows, cols, istride, gx, gy0 + j, bu8[j], bv8[j]);
             };
             march(H + (tid & (TW - 1)), H + 8 * (tid / TW), base_u, base_v);  // own outputs
             // halo jobs: top / bottom bands (RW columns each), left / right bands (H columns x TH/8)
@@ -317,6 +304,27 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 march(lx, ly0, tu, tv);
             }
         } else {
+            if (MODE == LK_FLOW_COARSE) {
+                // ---- phase 1 (border tiles): pyrUp row pass, once per coarse row -------------
+                const int fr = a.flow_rows;
+                for (int i = tid; i < CH * RW; i += NT) {
+                    const int cy = i / RW, lx = i - cy * RW;
+                    const int gx = rx0 + lx;
+                    if ((INT || (unsigned)gx < (unsigned)cols) && cy0 + cy < fr) {
+                        float au = 0.f, av = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) {
+                            const int sc = ((INT ? gx + k - 2 : reflect101(gx + k - 2, cols)) >> 1) - cx0;
+                            au = fmaf(Cu[cy * CW + sc], g5[k], au);
+                            av = fmaf(Cv[cy * CW + sc], g5[k], av);
+                        }
+                        Ru[i] = au;
+                        Rv[i] = av;
+                    }
+                }
+                __syncthreads();
+                MICV_STAMP(1)
+            }
             auto do_px = [&](int ly, int lx, float &bu, float &bv) {
                 const int gy = ry0 + ly, gx = rx0 + lx;
                 if (!INT && ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols)) return;
@@ -374,7 +382,6 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 const int seg = n / GW, qx = n - seg * GW;
                 const int q0 = seg * SEG, q1 = q0 + SEG < GH ? q0 + SEG : GH;
                 const int lx = qx + (H - R);
-                // image rows ly = qy + (H - R) - 1 .. : window rows a (ly-1), b (ly), c (ly+1)
                 float ptx[3], pty[3], wtx[3], wty[3], pc[3], wc[3];
                 auto rowpass = [&](int ly, int slot) {
                     const float *pr = P + ly * PS + lx, *wr = Wp + ly * PS + lx;
@@ -435,33 +442,69 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 Gy[qy * GS + qx] = avg2(ngy, pgy);
                 Gt[qy * GS + qx] = Nn[1][1] - Pn[1][1];
             }
+            // BORDER_REFLECT_101 of the window sums (cv::GaussianBlur default border) = the
+            // product fields at reflected positions: fill the out-of-image cells once, so the
+            // window sums below run the same straight-line code as interior tiles.  Cells whose
+            // source lies outside this tile feed only outputs that are outside the image.
+            __syncthreads();
+            for (int i = tid; i < GH * GW; i += NT) {
+                const int qy = i / GW, qx = i - qy * GW;
+                const int gy = y0 - R + qy, gx = x0 - R + qx;
+                if ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols) continue;
+                const int sy = reflect101(gy, rows) - (y0 - R), sx = reflect101(gx, cols) - (x0 - R);
+                const bool ok = (unsigned)sy < (unsigned)GH && (unsigned)sx < (unsigned)GW;
+                Gx[qy * GS + qx] = ok ? Gx[sy * GS + sx] : 0.f;
+                Gy[qy * GS + qx] = ok ? Gy[sy * GS + sx] : 0.f;
+                Gt[qy * GS + qx] = ok ? Gt[sy * GS + sx] : 0.f;
+            }
         }
     }
     __syncthreads();
     MICV_STAMP(3)
 
-    // ---- phase 4: five window sums -----------------------------------------------------------
-    const bool xint = INT || ((x0 - R >= 0) && (x0 + TW + R <= cols));
-    const bool yint = INT || ((y0 - R >= 0) && (y0 + TH + R <= rows));
+    // ---- phase 4: five window sums, two sweeps ----------------------------------------------
     const int c = tid & (TW - 1), r0 = 8 * (tid / TW);
     float Sxx[8], Sxy[8], Syy[8], Sxt[8], Syt[8];
-    float *rb0 = rowbuf, *rb1 = rowbuf + GH * C::RBS;
-
-    row_pass<C, true>(Gx, Gx, rb0, g, tid, x0, y0, rows, cols, xint);
-    __syncthreads();
-    col_pass<C>(rb0, Sxx, g, c, r0, y0, rows, yint);
-    row_pass<C, false>(Gx, Gy, rb1, g, tid, x0, y0, rows, cols, xint);
-    __syncthreads();
-    col_pass<C>(rb1, Sxy, g, c, r0, y0, rows, yint);
-    row_pass<C, true>(Gy, Gy, rb0, g, tid, x0, y0, rows, cols, xint);
-    __syncthreads();
-    col_pass<C>(rb0, Syy, g, c, r0, y0, rows, yint);
-    row_pass<C, false>(Gx, Gt, rb1, g, tid, x0, y0, rows, cols, xint);
-    __syncthreads();
-    col_pass<C>(rb1, Sxt, g, c, r0, y0, rows, yint);
-    row_pass<C, false>(Gy, Gt, rb0, g, tid, x0, y0, rows, cols, xint);
-    __syncthreads();
-    col_pass<C>(rb0, Syt, g, c, r0, y0, rows, yint);
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int grp = lane >> 2, c0 = 4 * grp;
+        // sweep A: Ix^2, Ix*Iy, Iy^2  (windows of Ix, Iy read once)
+#pragma unroll
+        for (int it = 0; it < (GH + 15) / 16; it++) {
+            const int qy = it * 16 + wave * 4 + (lane & 3);
+            if (qy < GH) {
+                float wx[20], wy[20];
+                load_window<C>(Gx, qy, c0, wx);
+                load_window<C>(Gy, qy, c0, wy);
+                const int o = rb_off(qy, grp);
+                row_taps<C>(wx, wx, g, rb0 + o);
+                row_taps<C>(wx, wy, g, rb1 + o);
+                row_taps<C>(wy, wy, g, rb2 + o);
+            }
+        }
+        __syncthreads();
+        col_pass<C>(rb0, Sxx, g, c, r0);
+        col_pass<C>(rb1, Sxy, g, c, r0);
+        col_pass<C>(rb2, Syy, g, c, r0);
+        __syncthreads();
+        // sweep B: Ix*It, Iy*It
+#pragma unroll
+        for (int it = 0; it < (GH + 15) / 16; it++) {
+            const int qy = it * 16 + wave * 4 + (lane & 3);
+            if (qy < GH) {
+                float wx[20], wy[20], wt[20];
+                load_window<C>(Gx, qy, c0, wx);
+                load_window<C>(Gy, qy, c0, wy);
+                load_window<C>(Gt, qy, c0, wt);
+                const int o = rb_off(qy, grp);
+                row_taps<C>(wx, wt, g, rb0 + o);
+                row_taps<C>(wy, wt, g, rb1 + o);
+            }
+        }
+        __syncthreads();
+        col_pass<C>(rb0, Sxt, g, c, r0);
+        col_pass<C>(rb1, Syt, g, c, r0);
+    }
     MICV_STAMP(4)
 
     // ---- phase 5: solve + store ----------------------------------------------------------------
@@ -501,8 +544,10 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
     const int tiles_x = (a.cols + C::TW - 1) / C::TW;
     const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
     const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
-    const bool interior = rx0 - 2 >= 0 && rx0 + C::RW + 2 <= a.cols && ry0 - 2 >= 0 &&
-                          ry0 + C::RH + 2 <= a.rows;
+    // interior: tile + halo + the staged `next` margin (>= the pyrUp support) inside the image
+    constexpr int E = C::M > 2 ? C::M : 2;
+    const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
+                          ry0 + C::RH + E <= a.rows;
     if (interior)
         lk_tile<R, MODE, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
     else

@@ -113,6 +113,68 @@ __global__ __launch_bounds__(256) void resize_linear_kernel(const float *__restr
     dst[(size_t)dy * dstride + dx] = h0 * b0 + h1 * b1;
 }
 
+// OpticalFlow.cpp:139-151 for levels whose size is not twice the coarser one: du = 2*pyrUp(du),
+// then cv::resize(du, du, level size).  One launch for the whole batch and both flow fields
+// (blockIdx.z = 2*pair + field); every output evaluates the four expanded samples it blends
+// from the coarse field directly (same fmaf chains as pyr_up_rows/cols_kernel, same blend as
+// resize_linear_kernel), so no intermediate image is written.
+__global__ __launch_bounds__(256) void flow_expand_resize_kernel(
+    const float *__restrict__ src_u, const float *__restrict__ src_v, int fr, int fc,
+    size_t src_pair, float *__restrict__ dst_u, float *__restrict__ dst_v, int drows, int dcols,
+    size_t dst_pair, double scale_x, double scale_y) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dcols || dy >= drows) return;
+    const int pair = blockIdx.z >> 1;
+    const float *__restrict__ src = ((blockIdx.z & 1) ? src_v : src_u) + pair * src_pair;
+    float *__restrict__ dst = ((blockIdx.z & 1) ? dst_v : dst_u) + pair * dst_pair;
+    const int ur = 2 * fr, uc = 2 * fc;  // size of the expanded field
+    const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    auto expanded = [&](int y, int x) -> float {  // 2 * pyrUp(src)(y, x)
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float *s = src + (size_t)(reflect101(y + k - 2, ur) >> 1) * fc;
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; j++) r = fmaf(s[reflect101(x + j - 2, uc) >> 1], g5[j], r);
+            acc = fmaf(r, g5[k], acc);
+        }
+        return acc * 2.f;
+    };
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= uc - 1) { fx = 0.f; sx = uc - 1; }
+    const float a0 = 1.f - fx, a1 = fx;
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= sy;
+    const float b0 = 1.f - fy, b1 = fy;
+    const int y0 = clampi(sy, 0, ur - 1), y1 = clampi(sy + 1, 0, ur - 1);
+    float h0, h1;
+    if (sx + 1 >= uc) {
+        h0 = expanded(y0, sx) * 1.f;
+        h1 = expanded(y1, sx) * 1.f;
+    } else {
+        h0 = expanded(y0, sx) * a0 + expanded(y0, sx + 1) * a1;
+        h1 = expanded(y1, sx) * a0 + expanded(y1, sx + 1) * a1;
+    }
+    dst[(size_t)dy * dcols + dx] = h0 * b0 + h1 * b1;
+}
+
+int launch_flow_expand_resize(hipStream_t s, const float *src_u, const float *src_v, int fr, int fc,
+                              size_t src_pair, float *dst_u, float *dst_v, int drows, int dcols,
+                              size_t dst_pair, int batch) {
+    const double scale_x = 1. / ((double)dcols / (2 * fc));
+    const double scale_y = 1. / ((double)drows / (2 * fr));
+    flow_expand_resize_kernel<<<dim3(cdiv(dcols, 64), cdiv(drows, 4), 2 * batch), 256, 0, s>>>(
+        src_u, src_v, fr, fc, src_pair, dst_u, dst_v, drows, dcols, dst_pair, scale_x, scale_y);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
 // cv::cvtColor(COLOR_RGB2GRAY) on CV_8UC3 (R2Y=4899, G2Y=9617, B2Y=1868, shift 14, round) then
 // convertTo(CV_32F).
 __global__ __launch_bounds__(256) void rgb8_to_gray_kernel(const uint8_t *__restrict__ rgb,
