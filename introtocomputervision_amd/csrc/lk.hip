@@ -207,6 +207,7 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
             a.img_pair = (k == 0) ? pair_elems : lvl_elems;
             a.out_u = out_u; a.out_v = out_v; a.out_stride = out_stride; a.out_pair = out_pair;
             a.add_base = 1;
+            a.row_begin = 0; a.row_end = R;
             a.stamps = (k == 0) ? ctx->stamps : nullptr;  // phase stamps: level 0 only
             if (level == 0) {
                 a.mode = LK_FLOW_NONE;
@@ -325,6 +326,7 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
         a.flow_u = a.flow_v = nullptr; a.flow_rows = a.flow_cols = 0; a.flow_pair = 0;
         a.out_u = u; a.out_v = v; a.out_stride = (int)(ostride / 4); a.out_pair = 0;
         a.add_base = 0;
+        a.row_begin = 0; a.row_end = rows;
         return launch_lk_level_fused(s, a);
     }
     void *scratch;
@@ -332,6 +334,66 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
     return lk_level_generic(s, prev, (int)(stride / 4), next, (int)(stride / 4), rows, cols, win,
                             nullptr, nullptr, 0, u, v, (int)(ostride / 4),
                             static_cast<float *>(scratch));
+}
+
+int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                      size_t stride, int win, const float *flow_u, const float *flow_v,
+                      int flow_rows, int flow_cols, int row_begin, int row_end, float *u, float *v,
+                      size_t ostride, micv_stream stream) {
+    MICV_TRY(check_lk_args("micv_lk_level", ctx, prev, next, u, v, rows, cols, stride, ostride, win));
+    MICV_REQUIRE((flow_u == nullptr) == (flow_v == nullptr), "micv_lk_level: give both flow fields or none");
+    MICV_REQUIRE(!flow_u || (flow_rows > 0 && flow_cols > 0), "micv_lk_level: bad coarse flow size");
+    MICV_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= rows,
+                 "micv_lk_level: bad row band [%d, %d)", row_begin, row_end);
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)rows * cols;
+    const bool doubles = flow_u && 2 * flow_rows == rows && 2 * flow_cols == cols;
+    const bool fused = lk_fused_supports(win) && !getenv("MICV_FORCE_GENERIC");
+    void *scratch;
+    MICV_TRY(ctx->reserve(Carver::need(n, 4) * 4 + Carver::need(lk_generic_scratch(rows, cols), 4) +
+                              (flow_u ? Carver::need((size_t)flow_rows * flow_cols * 2, 4) : 0),
+                          &scratch));
+    Carver carve(scratch);
+    float *bu = carve.take<float>(n), *bv = carve.take<float>(n);
+    float *warped = carve.take<float>(n), *tmp = carve.take<float>(n);
+    float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
+    if (fused) {
+        LkLevelArgs a;
+        a.rows = rows; a.cols = cols; a.batch = 1; a.win = win;
+        a.prev = prev; a.next = next; a.img_stride = (int)(stride / 4); a.img_pair = 0;
+        a.out_u = u; a.out_v = v; a.out_stride = (int)(ostride / 4); a.out_pair = 0;
+        a.add_base = 1;
+        a.row_begin = row_begin; a.row_end = row_end;
+        a.flow_pair = 0;
+        if (!flow_u) {
+            a.mode = LK_FLOW_NONE;
+            a.flow_u = a.flow_v = nullptr; a.flow_rows = a.flow_cols = 0;
+        } else if (doubles) {
+            a.mode = LK_FLOW_COARSE;
+            a.flow_u = flow_u; a.flow_v = flow_v; a.flow_rows = flow_rows; a.flow_cols = flow_cols;
+        } else {
+            MICV_TRY(launch_flow_expand_resize(s, flow_u, flow_v, flow_rows, flow_cols, 0, bu, bv, rows,
+                                               cols, 0, 1));
+            a.mode = LK_FLOW_FULL;
+            a.flow_u = bu; a.flow_v = bv; a.flow_rows = rows; a.flow_cols = cols;
+        }
+        return launch_lk_level_fused(s, a);
+    }
+    // generic kernels compute the whole level; rows outside the band are simply not needed
+    if (!flow_u) {
+        MICV_HIP(hipMemsetAsync(bu, 0, n * 4, s));
+        MICV_HIP(hipMemsetAsync(bv, 0, n * 4, s));
+    } else if (doubles) {
+        MICV_TRY(launch_pyr_up(s, flow_u, flow_rows, flow_cols, flow_cols, bu, cols, 2.f, tmp));
+        MICV_TRY(launch_pyr_up(s, flow_v, flow_rows, flow_cols, flow_cols, bv, cols, 2.f, tmp));
+    } else {
+        MICV_TRY(launch_flow_expand_resize(s, flow_u, flow_v, flow_rows, flow_cols, 0, bu, bv, rows, cols,
+                                           0, 1));
+    }
+    MICV_TRY(launch_warp(s, next, (int)(stride / 4), bu, bv, cols, rows, cols, warped, cols));
+    return lk_level_generic(s, prev, (int)(stride / 4), warped, cols, rows, cols, win, bu, bv, cols, u, v,
+                            (int)(ostride / 4), gen);
 }
 
 int micv_lk_warp_dev(micv_ctx *ctx, const float *src, size_t sstride, const float *du,

@@ -515,7 +515,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int gy = y0 + r0 + j;
-            if (INT || gy < rows) {
+            if (gy >= a.row_begin && gy < a.row_end) {
                 float uu, vv;
                 lk_solve(Sxx[j], Sxy[j], Syy[j], Sxt[j], Syt[j], uu, vv);
                 if (a.add_base) {
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int t = xcd * per + (xcd < rem ? xcd : rem) + idx;
     const int tiles_x = (a.cols + C::TW - 1) / C::TW;
-    const int tile_y = t / tiles_x, tile_x = t - tile_y * tiles_x;
+    const int tile_y = a.row_begin / C::TH + t / tiles_x, tile_x = t % tiles_x;
     const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
     // interior: tile + halo + the staged `next` margin (>= the pyrUp support) inside the image
     constexpr int E = C::M > 2 ? C::M : 2;
@@ -584,7 +584,12 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             done_dev = dev;
         }
     }
-    const dim3 grid(cdiv(a.cols, C::TW) * cdiv(a.rows, C::TH), a.batch);
+    if (a.row_begin < 0 || a.row_end > a.rows || a.row_begin >= a.row_end) {
+        set_error("lk fused: bad row band [%d, %d) for %d rows", a.row_begin, a.row_end, a.rows);
+        return MICV_EINVAL;
+    }
+    const int tile_rows = cdiv(a.row_end, C::TH) - a.row_begin / C::TH;
+    const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
     switch (a.mode) {
         case LK_FLOW_NONE:
             lk_level_kernel<R, 0><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);

@@ -23,6 +23,8 @@ struct LkLevelArgs {
     int out_stride;
     size_t out_pair;
     int add_base;  // 1: out = base + flow (OpticalFlow.cpp:161-162); 0: out = flow (:100-101)
+    // Output rows [row_begin, row_end) only (row-sharded execution); 0 / rows = everything.
+    int row_begin = 0, row_end = 0;
     // Diagnostic only (micv_profile_lk_phases): when non-null, wave 0 of every workgroup adds the
     // s_memtime ticks it spent in each phase to stamps[phase].  Null in normal runs.
     unsigned long long *stamps = nullptr;

@@ -1,0 +1,331 @@
+// micv_shim.hpp -- header-only drop-in for the reference's cv::Mat-in / cv::Mat-out functions,
+// implemented on the C ABI of libmicv.so (include/mi_cv.h).
+//
+// Same namespaces, names, argument order, defaults and ownership rules as the reference:
+//   lk::      ProblemSets/ps5_cpp/include/OpticalFlow.h:5-19
+//   pyr::     ProblemSets/ps5_cpp/include/Pyramids.h:7-12
+//   harris::  ProblemSets/ps4_cpp/include/Harris.h:18-96   (cpu:: and gpu:: are the same code here)
+//   sift::    ProblemSets/ps4_cpp/include/Descriptors.h:8-23
+//   cuda:: / serial::  ps2_cpp/include/DisparitySSD.h:18-43, DisparityNCorr.h:19-44,
+//                      ps1_cpp/src/Hough.h:22-84
+// Inputs are const references and never retained; outputs are (re)allocated by the callee like
+// the reference does (Mat::create / assignment of a fresh Mat).  Errors: the reference asserts or
+// exit(-1)s (CudaCommon.cuh:13-22); the shim throws std::runtime_error carrying micv_last_error().
+//
+// With -DMICV_SHIM_WITH_OPENCV the functions take real cv::Mat / cv::KeyPoint; without it they
+// take the minimal micv::Mat of micv_mat.hpp (this image has no OpenCV).
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/mi_cv.h"
+
+#ifdef MICV_SHIM_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+#include <opencv2/core/types.hpp>
+namespace micv_shim {
+using Mat = cv::Mat;
+using KeyPoint = cv::KeyPoint;
+enum { F32 = CV_32F, S8 = CV_8S, U8 = CV_8U, S32 = CV_32S };
+}  // namespace micv_shim
+#else
+#include "micv_mat.hpp"
+namespace micv_shim {
+using Mat = micv::Mat;
+using KeyPoint = micv::KeyPoint;
+enum { F32 = micv::CV_32F, S8 = micv::CV_8S, U8 = micv::CV_8U, S32 = micv::CV_32S };
+}  // namespace micv_shim
+#endif
+
+namespace micv_shim {
+
+inline micv_ctx *context() {  // one context per thread, like the reference's per-call streams
+    thread_local micv_ctx *ctx = nullptr;
+    if (!ctx && micv_ctx_create(0, &ctx) != MICV_OK)
+        throw std::runtime_error(std::string("micv: ") + micv_last_error());
+    return ctx;
+}
+inline void check(int rc) {
+    if (rc != MICV_OK) throw std::runtime_error(std::string("micv: ") + micv_last_error());
+}
+inline void require(bool ok, const char *what) {
+    if (!ok) throw std::invalid_argument(what);
+}
+// The reference converts with Mat::convertTo(CV_32F) (OpticalFlow.cpp:51-52); the shim accepts
+// CV_32F and CV_8U single-channel input and widens 8-bit on the host.
+inline Mat to_f32(const Mat &m) {
+    if (m.type() == F32) return m;
+    require(m.type() == U8, "micv shim: only CV_32FC1 / CV_8UC1 inputs are supported");
+    Mat f(m.rows, m.cols, F32);
+    for (int y = 0; y < m.rows; y++) {
+        const unsigned char *s = m.ptr<unsigned char>(y);
+        float *d = f.ptr<float>(y);
+        for (int x = 0; x < m.cols; x++) d[x] = static_cast<float>(s[x]);
+    }
+    return f;
+}
+
+}  // namespace micv_shim
+
+namespace lk {
+using micv_shim::Mat;
+
+inline void calcOpticalFlow(const Mat &prevImg, const Mat &nextImg, Mat &u, Mat &v,
+                            const size_t winSize = 21) {
+    micv_shim::require(prevImg.rows == nextImg.rows && prevImg.cols == nextImg.cols &&
+                           prevImg.type() == nextImg.type(),
+                       "lk::calcOpticalFlow: size/type mismatch");  // OpticalFlow.cpp:47
+    micv_shim::require(winSize % 2 == 1, "lk::calcOpticalFlow: winSize must be odd");  // :48
+    const Mat p = micv_shim::to_f32(prevImg), n = micv_shim::to_f32(nextImg);
+    micv_shim::require(p.step == n.step, "lk::calcOpticalFlow: inputs need equal row pitch");
+    u.create(p.rows, p.cols, micv_shim::F32);  // :53-54
+    v.create(p.rows, p.cols, micv_shim::F32);
+    micv_shim::check(micv_lk_flow_host(micv_shim::context(), p.ptr<float>(), n.ptr<float>(), p.rows,
+                                       p.cols, p.step, static_cast<int>(winSize), u.ptr<float>(),
+                                       v.ptr<float>(), u.step));
+}
+
+inline void warp(const Mat &src, const Mat &du, const Mat &dv, Mat &dst) {
+    micv_shim::require(du.rows == dv.rows && du.cols == dv.cols && src.rows == du.rows &&
+                           src.cols == du.cols,
+                       "lk::warp: size mismatch");  // OpticalFlow.cpp:107
+    micv_shim::require(du.type() == micv_shim::F32 && dv.type() == micv_shim::F32 &&
+                           src.type() == micv_shim::F32 && du.step == dv.step,
+                       "lk::warp: CV_32F expected");  // :108
+    Mat out(src.rows, src.cols, micv_shim::F32);
+    micv_shim::check(micv_lk_warp_host(micv_shim::context(), src.ptr<float>(), src.step,
+                                       du.ptr<float>(), dv.ptr<float>(), du.step, src.rows, src.cols,
+                                       out.ptr<float>(), out.step));
+    dst = out;
+}
+
+// `levels` exposes the depth the reference hard-codes (pyrDepth = 4, OpticalFlow.cpp:127).
+inline void calcOpticalFlowPyr(const Mat &prevImg, const Mat &nextImg, Mat &u, Mat &v,
+                               const size_t winSize = 21, const size_t levels = 4) {
+    micv_shim::require(prevImg.rows == nextImg.rows && prevImg.cols == nextImg.cols,
+                       "lk::calcOpticalFlowPyr: size mismatch");
+    const Mat p = micv_shim::to_f32(prevImg), n = micv_shim::to_f32(nextImg);
+    micv_shim::require(p.step == n.step, "lk::calcOpticalFlowPyr: inputs need equal row pitch");
+    Mat uu(p.rows, p.cols, micv_shim::F32), vv(p.rows, p.cols, micv_shim::F32);
+    micv_shim::check(micv_lk_flow_pyr_host(micv_shim::context(), p.ptr<float>(), n.ptr<float>(),
+                                           p.rows, p.cols, p.step, static_cast<int>(winSize),
+                                           static_cast<int>(levels), uu.ptr<float>(),
+                                           vv.ptr<float>(), uu.step));
+    u = uu;  // :165-166
+    v = vv;
+}
+}  // namespace lk
+
+namespace pyr {
+using micv_shim::Mat;
+
+inline void pyrDown(const Mat &src, Mat &dst) {
+    micv_shim::require(src.type() == micv_shim::F32, "pyr::pyrDown: CV_32F expected");  // Pyramids.cu:35
+    Mat out(src.rows / 2, src.cols / 2, micv_shim::F32);
+    micv_shim::check(micv_pyr_down_host(micv_shim::context(), src.ptr<float>(), src.rows, src.cols,
+                                        src.step, out.ptr<float>(), out.step));
+    dst = out;
+}
+inline void pyrUp(const Mat &src, Mat &dst) {
+    micv_shim::require(src.type() == micv_shim::F32, "pyr::pyrUp: CV_32F expected");  // Pyramids.cu:95
+    Mat out(src.rows * 2, src.cols * 2, micv_shim::F32);  // may alias src: written after the read
+    micv_shim::check(micv_pyr_up_host(micv_shim::context(), src.ptr<float>(), src.rows, src.cols,
+                                      src.step, out.ptr<float>(), out.step));
+    dst = out;
+}
+inline std::vector<Mat> makeGaussianPyramid(const Mat &src, const size_t levels) {
+    const Mat grey = micv_shim::to_f32(src);  // Pyramids.cpp:9-15 (colour input: convert before calling)
+    std::vector<Mat> pyramid;
+    std::vector<float *> ptrs;
+    for (size_t l = 0; l < levels; l++) {
+        pyramid.emplace_back(grey.rows >> l, grey.cols >> l, micv_shim::F32);
+        ptrs.push_back(pyramid.back().ptr<float>());
+    }
+    micv_shim::check(micv_gaussian_pyramid_host(micv_shim::context(), grey.ptr<float>(), grey.rows,
+                                                grey.cols, grey.step, static_cast<int>(levels),
+                                                ptrs.data()));
+    return pyramid;
+}
+}  // namespace pyr
+
+namespace harris {
+using micv_shim::Mat;
+
+inline void getGradients(const Mat &in, int kernelSize, Mat &diffX, Mat &diffY) {
+    micv_shim::require(kernelSize == 1 || kernelSize == 3 || kernelSize == 5 || kernelSize == 7,
+                       "harris::getGradients: kernelSize must be 1, 3, 5 or 7");  // Harris.cpp:16
+    micv_shim::require(in.type() == micv_shim::F32, "harris::getGradients: CV_32F expected");  // :17
+    diffX.create(in.rows, in.cols, micv_shim::F32);
+    diffY.create(in.rows, in.cols, micv_shim::F32);
+    micv_shim::check(micv_sobel_host(micv_shim::context(), in.ptr<float>(), in.rows, in.cols, in.step,
+                                     kernelSize, 1.f, diffX.ptr<float>(), diffY.ptr<float>(),
+                                     diffX.step));
+}
+
+namespace detail {
+inline void response(const Mat &gradX, const Mat &gradY, const size_t windowSize,
+                     const double gaussianSigma, const float harrisScore, Mat &cornerResponse) {
+    micv_shim::require(gradX.rows == gradY.rows && gradX.cols == gradY.cols &&
+                           gradX.type() == micv_shim::F32 && gradY.type() == micv_shim::F32 &&
+                           gradX.step == gradY.step,
+                       "harris::getCornerResponse: gradient mismatch");  // Harris.cpp:49-50
+    micv_shim::require(windowSize % 2 == 1, "harris::getCornerResponse: windowSize must be odd");
+    Mat out(gradX.rows, gradX.cols, micv_shim::F32);
+    micv_shim::check(micv_harris_response_host(micv_shim::context(), gradX.ptr<float>(),
+                                               gradY.ptr<float>(), gradX.rows, gradX.cols, gradX.step,
+                                               static_cast<int>(windowSize), gaussianSigma,
+                                               harrisScore, out.ptr<float>(), out.step));
+    cornerResponse = out;
+}
+inline void refine(const Mat &cornerResponse, const double threshold, const int minDistance,
+                   Mat &corners, std::vector<std::pair<int, int>> &cornerLocs, bool append) {
+    micv_shim::require(cornerResponse.type() == micv_shim::F32,
+                       "harris::refineCorners: CV_32F expected");  // Harris.cpp:105
+    Mat out(cornerResponse.rows, cornerResponse.cols, micv_shim::F32);
+    const int64_t cap = static_cast<int64_t>(cornerResponse.rows) * cornerResponse.cols;
+    std::vector<int32_t> locs(static_cast<size_t>(cap) * 2);
+    int64_t n = 0;
+    micv_shim::check(micv_harris_refine_host(micv_shim::context(), cornerResponse.ptr<float>(),
+                                             cornerResponse.rows, cornerResponse.cols,
+                                             cornerResponse.step, threshold, minDistance,
+                                             out.ptr<float>(), out.step, locs.data(), cap, &n));
+    corners = out;
+    if (!append) cornerLocs.clear();  // gpu:: resizes (Harris.cu:324), cpu:: appends (Harris.cpp:138)
+    for (int64_t i = 0; i < n; i++) cornerLocs.emplace_back(locs[2 * i], locs[2 * i + 1]);
+}
+}  // namespace detail
+
+namespace cpu {
+inline void getCornerResponse(const Mat &gradX, const Mat &gradY, const size_t windowSize,
+                              const double gaussianSigma, const float harrisScore,
+                              Mat &cornerResponse) {
+    detail::response(gradX, gradY, windowSize, gaussianSigma, harrisScore, cornerResponse);
+}
+inline void refineCorners(const Mat &cornerResponse, const double threshold, const int minDistance,
+                          Mat &corners, std::vector<std::pair<int, int>> &cornerLocs) {
+    detail::refine(cornerResponse, threshold, minDistance, corners, cornerLocs, true);
+}
+}  // namespace cpu
+namespace gpu {
+inline void getCornerResponse(const Mat &gradX, const Mat &gradY, const size_t windowSize,
+                              const double gaussianSigma, const float harrisScore,
+                              Mat &cornerResponse) {
+    detail::response(gradX, gradY, windowSize, gaussianSigma, harrisScore, cornerResponse);
+}
+inline void refineCorners(const Mat &cornerResponse, const double threshold, const int minDistance,
+                          Mat &corners, std::vector<std::pair<int, int>> &cornerLocs) {
+    detail::refine(cornerResponse, threshold, minDistance, corners, cornerLocs, false);
+}
+}  // namespace gpu
+}  // namespace harris
+
+namespace sift {
+using micv_shim::KeyPoint;
+using micv_shim::Mat;
+
+inline void getAnglesFromGradients(const Mat &gradX, const Mat &gradY, Mat &angles) {
+    micv_shim::require(gradX.rows == gradY.rows && gradX.cols == gradY.cols &&
+                           gradX.type() == micv_shim::F32 && gradY.type() == micv_shim::F32 &&
+                           gradX.step == gradY.step,
+                       "sift::getAnglesFromGradients: gradient mismatch");  // Descriptors.cpp:9-10
+    angles.create(gradX.rows, gradX.cols, micv_shim::F32);
+    micv_shim::check(micv_sift_angles_host(micv_shim::context(), gradX.ptr<float>(),
+                                           gradY.ptr<float>(), gradX.rows, gradX.cols, gradX.step,
+                                           angles.ptr<float>(), angles.step));
+}
+inline void getKeypoints(const Mat &gradX, const Mat &gradY,
+                         const std::vector<std::pair<int, int>> &cornerLocs, const size_t size,
+                         std::vector<KeyPoint> &keypoints) {
+    keypoints.clear();  // Descriptors.cpp:36
+    std::vector<int32_t> locs;
+    for (const auto &c : cornerLocs) {
+        locs.push_back(c.first);
+        locs.push_back(c.second);
+    }
+    std::vector<float> kp(cornerLocs.size() * 4);
+    micv_shim::check(micv_sift_keypoints_host(micv_shim::context(), gradX.ptr<float>(),
+                                              gradY.ptr<float>(), gradX.rows, gradX.cols, gradX.step,
+                                              locs.data(), static_cast<int64_t>(cornerLocs.size()),
+                                              static_cast<float>(size), kp.data()));
+    for (size_t i = 0; i < cornerLocs.size(); i++)
+        keypoints.emplace_back(kp[4 * i], kp[4 * i + 1], kp[4 * i + 2], kp[4 * i + 3], 0.f);  // :45
+}
+}  // namespace sift
+
+namespace micv_shim {
+inline void disparity(bool ncc, const Mat &left, const Mat &right, const size_t windowRad,
+                      const int minDisparity, const int maxDisparity, int flags, Mat &disparity) {
+    require(left.type() == F32 && right.type() == F32 && left.rows == right.rows &&
+                left.cols == right.cols && left.step == right.step,
+            "disparity: CV_32FC1 pair of equal size expected");  // DisparitySSD.cpp:15
+    disparity.create(left.rows, left.cols, S8);                   // :32
+    auto fn = ncc ? micv_disparity_ncorr_host : micv_disparity_ssd_host;
+    check(fn(context(), left.ptr<float>(), right.ptr<float>(), left.rows, left.cols, left.step,
+             static_cast<int>(windowRad), minDisparity, maxDisparity, flags,
+             disparity.ptr<int8_t>(), disparity.step));
+}
+}  // namespace micv_shim
+
+// `cuda::` = the CUDA kernels as written (2r-column window, 5e6 cut-off); `serial::` = the CPU
+// functions as written.  micv_disparity_*(flags = 0) is the corrected (2r+1)^2 definition.
+namespace cuda {
+using micv_shim::Mat;
+inline void disparitySSD(const Mat &left, const Mat &right, const size_t windowRad,
+                         const int minDisparity, const int maxDisparity, Mat &disparity) {
+    micv_shim::disparity(false, left, right, windowRad, minDisparity, maxDisparity,
+                         MICV_STEREO_COLS_2R | MICV_STEREO_MIN_SSD_5E6, disparity);
+}
+inline void disparityNCorr(const Mat &left, const Mat &right, const size_t windowRad,
+                           const int minDisparity, const int maxDisparity, Mat &disparity) {
+    micv_shim::disparity(true, left, right, windowRad, minDisparity, maxDisparity,
+                         MICV_STEREO_COLS_2R, disparity);
+}
+inline void houghLinesAccumulate(const Mat &edgeMask, const unsigned int rhoBinSize,
+                                 const unsigned int thetaBinSize, Mat &accumulator) {
+    micv_shim::require(edgeMask.type() == micv_shim::U8, "cuda::houghLinesAccumulate: CV_8UC1 expected");
+    int rb = 0, tb = 0;
+    micv_shim::check(micv_hough_lines_dims(edgeMask.rows, edgeMask.cols, rhoBinSize, thetaBinSize, &rb, &tb));
+    Mat acc(rb, tb, micv_shim::S32);
+    micv_shim::check(micv_hough_lines_host(micv_shim::context(), edgeMask.ptr<uint8_t>(), edgeMask.rows,
+                                           edgeMask.cols, edgeMask.step, rhoBinSize, thetaBinSize,
+                                           acc.ptr<int32_t>()));
+    accumulator = acc;
+}
+inline void houghCirclesAccumulate(const Mat &edgeMask, const size_t radius, Mat &accumulator) {
+    micv_shim::require(edgeMask.type() == micv_shim::U8, "cuda::houghCirclesAccumulate: CV_8UC1 expected");
+    Mat acc(edgeMask.rows, edgeMask.cols, micv_shim::S32);
+    micv_shim::check(micv_hough_circles_host(micv_shim::context(), edgeMask.ptr<uint8_t>(),
+                                             edgeMask.rows, edgeMask.cols, edgeMask.step,
+                                             static_cast<unsigned>(radius), acc.ptr<int32_t>()));
+    accumulator = acc;
+}
+inline void findLocalMaxima(const Mat &accumulator, const unsigned int numPeaks, const int threshold,
+                            std::vector<std::pair<unsigned int, unsigned int>> &localMaxima) {
+    micv_shim::require(accumulator.type() == micv_shim::S32 && accumulator.isContinuous(),
+                       "cuda::findLocalMaxima: continuous CV_32SC1 expected");
+    std::vector<uint32_t> peaks(static_cast<size_t>(numPeaks) * 2 + 2);
+    int64_t n = 0;
+    micv_shim::check(micv_hough_peaks_host(micv_shim::context(), accumulator.ptr<int32_t>(),
+                                           accumulator.rows, accumulator.cols, numPeaks, threshold,
+                                           peaks.data(), &n));
+    for (int64_t i = 0; i < n; i++) localMaxima.emplace_back(peaks[2 * i], peaks[2 * i + 1]);  // appended, Hough.cu:413
+}
+}  // namespace cuda
+
+namespace serial {
+using micv_shim::Mat;
+inline void disparitySSD(const Mat &left, const Mat &right, const size_t windowRad,
+                         const int minDisparity, const int maxDisparity, Mat &disparity) {
+    micv_shim::disparity(false, left, right, windowRad, minDisparity, maxDisparity,
+                         MICV_STEREO_SERIAL, disparity);
+}
+// serial::disparityNCorr calls cv::matchTemplate per pixel (DisparityNCorr.cpp:60-64), whose
+// arithmetic is OpenCV's; the shim routes it to the (2r+1)^2 NCC defined in DESIGN.md.
+inline void disparityNCorr(const Mat &left, const Mat &right, const size_t windowRad,
+                           const int minDisparity, const int maxDisparity, Mat &disparity) {
+    micv_shim::disparity(true, left, right, windowRad, minDisparity, maxDisparity, 0, disparity);
+}
+}  // namespace serial

@@ -1,0 +1,131 @@
+"""Row-sharded pyramidal LK (introtocomputervision_amd/shard.py): bit-identical to the unsharded
+result.  CPU: the sharding / halo logic with the oracle as the per-band compute, in one process
+("virtual shards") and across 2 real ranks over gloo.  GPU: virtual shards on one device through
+micv_lk_level_dev (the same entry point the RCCL path uses)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+from introtocomputervision_amd import shard, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def oracle_level_fn(win):
+    """One iteration of OpticalFlow.cpp:135-163 on full level arrays (rows outside the band valid
+    only where their inputs were)."""
+    def fn(prev_l, next_l, fu, fv, a, b):
+        rows, cols = prev_l.shape
+        if fu is None:
+            du = np.zeros((rows, cols), np.float32)
+            dv = np.zeros((rows, cols), np.float32)
+        else:
+            du = 2.0 * orc.pyr_up(fu)
+            dv = 2.0 * orc.pyr_up(fv)
+            if du.shape != (rows, cols):
+                du = orc.resize_linear(du, rows, cols)
+                dv = orc.resize_linear(dv, rows, cols)
+        warped = orc.lk_warp(next_l, du, dv)
+        dx, dy = orc.lk_flow(prev_l, warped, win)
+        return du + dx, dv + dy
+    return fn
+
+
+def test_plan_geometry():
+    p = shard.RowShardPlan(1080, 1920, 5, 8)
+    assert p.dims == [(1080, 1920), (540, 960), (270, 480), (135, 240), (67, 120)]
+    for l in range(5):
+        assert p.cuts[l][0] == 0 and p.cuts[l][-1] == p.dims[l][0]
+        assert all(p.cuts[l][g] < p.cuts[l][g + 1] for g in range(8))
+    for l in range(4):  # a band is the pyrUp image of the coarser band
+        assert all(p.cuts[l][g] == 2 * p.cuts[l + 1][g] for g in range(8))
+    # level 1 -> 0 halo: <= 8 rows x 960 cols x 2 fields x 4 B from each neighbour
+    assert p.halo_bytes(1, 3) == 2 * 8 * 960 * 8
+    assert p.halo_bytes(1, 0) == 8 * 960 * 8
+    with pytest.raises(ValueError):
+        shard.RowShardPlan(64, 64, 5, 8)
+
+
+@pytest.mark.parametrize("rows,cols,levels,world", [(135, 120, 3, 2), (135, 96, 4, 3), (270, 96, 5, 8), (101, 77, 3, 4)])
+def test_virtual_shards_match_unsharded_oracle(rows, cols, levels, world):
+    prev, nxt = synth.lk_pair(31 + world, rows, cols, 3, -2)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, 7, levels)
+    plan = shard.RowShardPlan(rows, cols, levels, world)
+    u, v = shard.lk_pyr_virtual(orc.gaussian_pyramid(prev, levels), orc.gaussian_pyramid(nxt, levels),
+                                plan, 7, oracle_level_fn(7))
+    assert np.array_equal(u, eu) and np.array_equal(v, ev)
+
+
+def test_halo_is_actually_needed():
+    """With the halo exchange removed the bands no longer match: the test above is not vacuous."""
+    prev, nxt = synth.lk_pair(5, 135, 96, 3, -2)
+    eu, _ = orc.lk_flow_pyr(prev, nxt, 7, 3)
+    plan = shard.RowShardPlan(135, 96, 3, 2)
+    plan.transfers = lambda level: []
+    u, _ = shard.lk_pyr_virtual(orc.gaussian_pyramid(prev, 3), orc.gaussian_pyramid(nxt, 3), plan, 7,
+                                oracle_level_fn(7))
+    assert not np.array_equal(u, eu)
+
+
+def _gloo_worker(rank, world, port, rows, cols, levels, out_dir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prev, nxt = synth.lk_pair(77, rows, cols, 3, -2)
+    plan = shard.RowShardPlan(rows, cols, levels, world)
+    base = oracle_level_fn(7)
+
+    def level_fn(p, n, fu, fv, a, b):  # torch tensors <-> oracle (numpy)
+        u, v = base(p, n, None if fu is None else fu.numpy(), None if fv is None else fv.numpy(), a, b)
+        return torch.from_numpy(u), torch.from_numpy(v)
+
+    u, v = shard.lk_pyr_band(orc.gaussian_pyramid(prev, levels), orc.gaussian_pyramid(nxt, levels), plan,
+                             rank, 7, level_fn, shard.DistComm(rank, world), poison=12345.0)
+    a, b = plan.band(0, rank)
+    np.save(os.path.join(out_dir, f"u{rank}.npy"), u[a:b].numpy())
+    np.save(os.path.join(out_dir, f"v{rank}.npy"), v[a:b].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    rows, cols, levels, world = 135, 96, 3, 2
+    mp.spawn(_gloo_worker, args=(world, port, rows, cols, levels, str(tmp_path)), nprocs=world, join=True)
+    prev, nxt = synth.lk_pair(77, rows, cols, 3, -2)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, 7, levels)
+    u = np.concatenate([np.load(tmp_path / f"u{r}.npy") for r in range(world)])
+    v = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)])
+    assert np.array_equal(u, eu) and np.array_equal(v, ev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,levels,world,win", [(270, 480, 5, 8, 15), (540, 960, 5, 4, 15), (135, 240, 4, 3, 9)])
+def test_virtual_shards_on_gpu(rows, cols, levels, world, win):
+    import torch
+    from introtocomputervision_amd import lk, pyr
+    from introtocomputervision_amd._capi import Context
+    ctx = Context(0)
+    prev, nxt = synth.lk_pair(1234, rows, cols, 3, -2)
+    dp, dn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
+    gu, gv = lk.calcOpticalFlowPyr(dp, dn, win, levels, ctx=ctx)
+    plan = shard.RowShardPlan(rows, cols, levels, world)
+    u, v = shard.lk_pyr_virtual(pyr.makeGaussianPyramid(dp, levels, ctx=ctx),
+                                pyr.makeGaussianPyramid(dn, levels, ctx=ctx), plan, win,
+                                shard.gpu_level_fn(ctx, win))
+    assert torch.equal(u, gu) and torch.equal(v, gv)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, win, levels)
+    assert np.array_equal(u.cpu().numpy(), eu) and np.array_equal(v.cpu().numpy(), ev)

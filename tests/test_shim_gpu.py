@@ -1,0 +1,67 @@
+"""The header-only C++ shim (the reference's namespaces and signatures on top of the C ABI):
+compile tests/cpp/shim_demo.cpp with g++, run it the way a psN driver would call its library,
+and compare every output with the CPU oracle (bit-exact; keypoint angles within 1e-3 deg)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_demo(tmp):
+    exe = os.path.join(tmp, "shim_demo")
+    lib = os.path.join(ROOT, "introtocomputervision_amd")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"),
+                    "-o", exe, "-L" + lib, "-lmicv", "-Wl,-rpath," + lib], check=True)
+    return exe
+
+
+def test_shim_compiles_on_cpu(tmp_path):
+    build_demo(str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_shim_matches_oracle(tmp_path):
+    from introtocomputervision_amd import synth
+    d = str(tmp_path)
+    exe = build_demo(d)
+    rows, cols = 96, 160
+    prev, nxt = synth.lk_pair(0x5EED0005, rows, cols, 3, -2)
+    chk = synth.checkerboard(rows, cols, square=20, seed=0x5EED0001)
+    left, right, _ = synth.stereo_pair(0x5EED0002, rows, cols)
+    mask, lines, _ = synth.hough_mask(rows, cols, n_lines=4, radii=())
+    for name, a in (("prev.f32", prev), ("next.f32", nxt), ("chk.f32", chk), ("left.f32", left),
+                    ("right.f32", right), ("mask.u8", mask)):
+        a.tofile(os.path.join(d, name))
+    r = subprocess.run([exe, d, str(rows), str(cols)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+    def rd(name, dtype, shape=None):
+        a = np.fromfile(os.path.join(d, name), dtype=dtype)
+        return a.reshape(shape) if shape else a
+
+    eu, ev = orc.lk_flow_pyr(prev, nxt, 15, 4)
+    assert np.array_equal(rd("lkpyr_u.f32", np.float32, (rows, cols)), eu)
+    assert np.array_equal(rd("lkpyr_v.f32", np.float32, (rows, cols)), ev)
+    assert np.array_equal(rd("lk_u.f32", np.float32, (rows, cols)), orc.lk_flow(prev, nxt, 15)[0])
+    assert np.array_equal(rd("warped.f32", np.float32, (rows, cols)), orc.lk_warp(nxt, eu, ev))
+    p3 = orc.gaussian_pyramid(prev, 4)[3]
+    assert np.array_equal(rd("pyr3.f32", np.float32, p3.shape), p3)
+    assert np.array_equal(rd("pyr3_up.f32", np.float32, (2 * p3.shape[0], 2 * p3.shape[1])), orc.pyr_up(p3))
+    gx, gy = orc.sobel(chk, 3, 1.0)
+    R = orc.harris_response(gx, gy, 5, 1.5, 0.04)
+    assert np.array_equal(rd("harris_R.f32", np.float32, (rows, cols)), R)
+    _, locs = orc.harris_refine(R, 5e8, 5)
+    assert len(locs) > 5 and np.array_equal(rd("harris_locs.i32", np.int32).reshape(-1, 2), locs)
+    kp = rd("kps.f32", np.float32).reshape(-1, 4)
+    ekp = orc.sift_keypoints(gx, gy, locs, 10)
+    assert np.array_equal(kp[:, :3], ekp[:, :3]) and np.allclose(kp[:, 3], ekp[:, 3], atol=1e-3, rtol=0)
+    assert np.array_equal(rd("disp_cuda.i8", np.int8, (rows, cols)), orc.disparity_ssd(left, right, 5, -30, 0, 3))
+    assert np.array_equal(rd("disp_serial.i8", np.int8, (rows, cols)), orc.disparity_ssd_serial(left, right, 5, -30, 0))
+    acc = orc.hough_lines(mask, 1, 1)
+    assert np.array_equal(rd("acc.i32", np.int32, acc.shape), acc)
+    assert np.array_equal(rd("peaks.u32", np.uint32).reshape(-1, 2), orc.hough_peaks(acc, 10, 40))
