@@ -197,6 +197,7 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
         const int out_stride = last ? ostride : C;
 
         MICV_TRY(ctx->prof_begin(k, s));
+        bool out_in_cur = false;
         if (fused) {
             LkLevelArgs a;
             a.rows = R; a.cols = C; a.batch = batch; a.win = win;
@@ -225,8 +226,12 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
                 a.mode = LK_FLOW_FULL;
                 a.flow_u = full_u; a.flow_v = full_v;
                 a.flow_rows = R; a.flow_cols = C; a.flow_pair = lvl_elems;
-                if (!last) {  // in-place update of the base buffers is safe (same thread, same pixel)
-                    a.out_u = full_u; a.out_v = full_v;
+                // The tiled kernel reads the base flow of its halo pixels, which other workgroups
+                // own: the output must NOT alias the base.  The coarse buffers are dead after the
+                // expand launch, so the result goes there and the ping-pong index stays put.
+                if (!last) {
+                    a.out_u = fu[cur]; a.out_v = fv[cur];
+                    out_in_cur = true;
                 }
             }
             MICV_TRY(launch_lk_level_fused(s, a));
@@ -260,7 +265,7 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
             }
         }
         MICV_TRY(ctx->prof_end(k, s));
-        cur ^= 1;
+        if (!out_in_cur) cur ^= 1;
         fr = R;
         fc = C;
     }

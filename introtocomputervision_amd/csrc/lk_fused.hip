@@ -30,6 +30,9 @@
 
 namespace micv {
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_cvoid;
+
 template <int N>
 struct TapsN {
     float k[N];
@@ -161,43 +164,85 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     }
 
     // ---- phase 0: stage prev (+ next / its window) and the coarse flow block -----------------
+    // Interior tiles issue ALL their global loads into registers first and write LDS afterwards,
+    // so the loads overlap each other (a load -> ds_write loop would serialise on every wait).
     int cx0 = 0, cy0 = 0;
+    constexpr int NC = (CH * CW + NT - 1) / NT;
+    float rcu[NC], rcv[NC];
     if (MODE == LK_FLOW_COARSE) {
         const float *__restrict__ fu = a.flow_u + pair * a.flow_pair;
         const float *__restrict__ fv = a.flow_v + pair * a.flow_pair;
         const int fr = a.flow_rows, fc = a.flow_cols;
         cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
         cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
-        for (int i = tid; i < CH * CW; i += NT) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+            // unconditional loads from clamped (always valid) addresses: no branch, so the
+            // compiler keeps every load in flight instead of waiting inside each predicated block
+            const int i = tid + k * NT < CH * CW ? tid + k * NT : CH * CW - 1;
             const int cy = i / CW, cx = i - cy * CW;
-            if (cy0 + cy < fr && cx0 + cx < fc) {
-                Cu[i] = fu[(size_t)(cy0 + cy) * fc + cx0 + cx];
-                Cv[i] = fv[(size_t)(cy0 + cy) * fc + cx0 + cx];
-            }
+            const int yy = cy0 + cy < fr ? cy0 + cy : fr - 1, xx = cx0 + cx < fc ? cx0 + cx : fc - 1;
+            rcu[k] = fu[(size_t)yy * fc + xx];
+            rcv[k] = fv[(size_t)yy * fc + xx];
         }
     }
     const bool vec_ok = INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
-    if (INT && vec_ok) {
-        constexpr int V = RW / 4;
-        for (int i = tid; i < RH * V; i += NT) {
-            const int ly = i / V, lv = i - ly * V;
-            const size_t goff = (size_t)(ry0 + ly) * istride + rx0 + 4 * lv;
-            *reinterpret_cast<float4 *>(P + ly * PS + 4 * lv) =
-                *reinterpret_cast<const float4 *>(prev + goff);
-            if (MODE == LK_FLOW_NONE)
-                *reinterpret_cast<float4 *>(Wp + ly * PS + 4 * lv) =
-                    *reinterpret_cast<const float4 *>(next + goff);
+    constexpr bool DMA_OK = ((RH * (RW / 4)) % 64 == 0) && ((NH * (NW / 4)) % 64 == 0);  // whole waves
+    if (INT && DMA_OK && vec_ok) {
+        // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip
+        // and no ds_write; every transfer of the tile is in flight at once.  The LDS images are
+        // dense (P: 80-float rows, window: 96-float rows), so element i of the tile lives at
+        // float4 slot i and one wave-instruction covers slots [i0, i0 + 64).
+        constexpr int V = RW / 4, NP = (RH * V + NT - 1) / NT;
+        constexpr int VN = NW / 4, NN = (NH * VN + NT - 1) / NT;
+        const int lane = tid & 63;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int i = tid + k * NT;
+            if (i < RH * V) {
+                const int ly = i / V, lv = i - ly * V;
+                const size_t goff = (size_t)(ry0 + ly) * istride + rx0 + 4 * lv;
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)(prev + goff), (lds_void *)(P + 4 * (i - lane)),
+                                                 16, 0, 0);
+                if (MODE == LK_FLOW_NONE)
+                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(next + goff),
+                                                     (lds_void *)(Wp + 4 * (i - lane)), 16, 0, 0);
+            }
         }
         if (STAGED) {
-            constexpr int VN = NW / 4;
-            for (int i = tid; i < NH * VN; i += NT) {
-                const int ly = i / VN, lv = i - ly * VN;
-                *reinterpret_cast<float4 *>(Nx + ly * NW + 4 * lv) = *reinterpret_cast<const float4 *>(
-                    next + (size_t)(ry0 - M + ly) * istride + rx0 - M + 4 * lv);
+#pragma unroll
+            for (int k = 0; k < NN; k++) {
+                const int i = tid + k * NT;
+                if (i < NH * VN) {
+                    const int ly = i / VN, lv = i - ly * VN;
+                    __builtin_amdgcn_global_load_lds(
+                        (glb_cvoid *)(next + (size_t)(ry0 - M + ly) * istride + rx0 - M + 4 * lv),
+                        (lds_void *)(Nx + 4 * (i - lane)), 16, 0, 0);
+                }
+            }
+        }
+        if (MODE == LK_FLOW_COARSE) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int i = tid + k * NT;
+                if (i < CH * CW) {
+                    Cu[i] = rcu[k];
+                    Cv[i] = rcv[k];
+                }
             }
         }
     } else {
+        if (MODE == LK_FLOW_COARSE) {
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int i = tid + k * NT;
+                if (i < CH * CW) {
+                    Cu[i] = rcu[k];
+                    Cv[i] = rcv[k];
+                }
+            }
+        }
         for (int i = tid; i < RH * RW; i += NT) {
             const int ly = i / RW, lx = i - ly * RW;
             const int gy = ry0 + ly, gx = rx0 + lx;
