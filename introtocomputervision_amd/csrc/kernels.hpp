@@ -27,6 +27,10 @@ int launch_pyr_up(hipStream_t s, const float *src, int rows, int cols, int sstri
 // input). dst[l] == nullptr skips a level; image b of level l lands at dst[l] + b*rows_l*cols_l.
 int launch_pyr_build(hipStream_t s, const float *src, size_t img_elems, int sstride, int rows,
                      int cols, int levels, float *const *dst, int batch);
+// Two image sets (prev / next) in one launch; dst_a[l] == nullptr skips level l in both.
+int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, size_t img_elems,
+                      int sstride, int rows, int cols, int levels, float *const *dst_a,
+                      float *const *dst_b, int batch);
 int launch_resize_linear(hipStream_t s, const float *src, int srows, int scols, int sstride,
                          float *dst, int drows, int dcols, int dstride);
 // du = resize(2 * pyrUp(du_coarse), drows x dcols) for `batch` pairs and both fields, one launch.

@@ -171,8 +171,7 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
             pd[l] = ppyr + plan.lvl_off[l] * batch;
             nd[l] = npyr + plan.lvl_off[l] * batch;
         }
-        MICV_TRY(launch_pyr_build(s, prev, pair_elems, stride, rows, cols, levels, pd, batch));
-        MICV_TRY(launch_pyr_build(s, next, pair_elems, stride, rows, cols, levels, nd, batch));
+        MICV_TRY(launch_pyr_build2(s, prev, next, pair_elems, stride, rows, cols, levels, pd, nd, batch));
     }
     auto level_img = [&](const float *img0, float *pyr, int l, int b, int *st) -> const float * {
         if (l == 0) {

@@ -26,9 +26,13 @@ struct PyrLevels {
 // One block = 64x4 output pixels of some level; blockIdx.x indexes tiles over all levels,
 // blockIdx.y = image in the batch.  Level 0 is a plain copy (the reference clones the input,
 // Pyramids.cpp:9,18) and is only emitted when dst[0] != nullptr.
-__global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict__ src,
+__global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict__ src_a,
+                                                         const float *__restrict__ src_b,
                                                          size_t img_elems, int sstride,
-                                                         PyrLevels L) {
+                                                         PyrLevels La, PyrLevels Lb) {
+    // blockIdx.z selects the image set (prev / next pyramids are built by one launch)
+    const float *__restrict__ src = blockIdx.z ? src_b : src_a;
+    const PyrLevels &L = blockIdx.z ? Lb : La;
     int l = 0;
     const int bid = blockIdx.x;
     while (l + 1 < L.n && bid >= L.tiles_before[l + 1]) l++;
@@ -222,23 +226,36 @@ int launch_resize_linear(hipStream_t s, const float *src, int srows, int scols, 
 
 // Builds levels [first..n) of `batch` images in one launch. dst[l] holds the batch densely:
 // image b of level l at dst[l] + b*rows_l*cols_l.
-int launch_pyr_build(hipStream_t s, const float *src, size_t img_elems, int sstride, int rows,
-                     int cols, int levels, float *const *dst, int batch) {
-    PyrLevels L;
-    L.n = levels;
+int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, size_t img_elems,
+                      int sstride, int rows, int cols, int levels, float *const *dst_a,
+                      float *const *dst_b, int batch) {
+    PyrLevels L[2];
     int total = 0;
-    for (int l = 0; l < levels; l++) {
-        L.rows[l] = rows >> l;
-        L.cols[l] = cols >> l;
-        L.dst[l] = dst[l];
-        L.tiles_before[l] = total;
-        if (dst[l]) total += cdiv(L.cols[l], 64) * cdiv(L.rows[l], 4);
+    for (int k = 0; k < 2; k++) {
+        float *const *dst = k ? dst_b : dst_a;
+        L[k].n = levels;
+        total = 0;
+        for (int l = 0; l < levels; l++) {
+            L[k].rows[l] = rows >> l;
+            L[k].cols[l] = cols >> l;
+            L[k].dst[l] = dst ? dst[l] : nullptr;
+            L[k].tiles_before[l] = total;
+            // both sets use the same tiling (a skipped level must be skipped in both)
+            if (dst_a[l]) total += cdiv(L[k].cols[l], 64) * cdiv(L[k].rows[l], 4);
+        }
+        L[k].tiles_before[levels] = total;
     }
-    L.tiles_before[levels] = total;
     if (total == 0) return MICV_OK;
-    pyr_build_kernel<<<dim3(total, batch), 256, 0, s>>>(src, img_elems, sstride, L);
+    pyr_build_kernel<<<dim3(total, batch, src_b ? 2 : 1), 256, 0, s>>>(src_a, src_b, img_elems, sstride,
+                                                                      L[0], L[1]);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
+}
+
+int launch_pyr_build(hipStream_t s, const float *src, size_t img_elems, int sstride, int rows,
+                     int cols, int levels, float *const *dst, int batch) {
+    return launch_pyr_build2(s, src, nullptr, img_elems, sstride, rows, cols, levels, dst, nullptr,
+                             batch);
 }
 
 }  // namespace micv

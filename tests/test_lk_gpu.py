@@ -188,3 +188,65 @@ def test_bad_arguments(mods):
         lk.calcOpticalFlowPyr(a, a, 15, 7)  # 32 >> 6 == 0
     with pytest.raises(ValueError):
         lk.calcOpticalFlow(a, dev(np.zeros((16, 32), np.float32)), 15)
+
+
+@pytest.mark.parametrize("rows,cols,levels,win", [
+    (1, 1, 1, 15), (2, 3, 1, 15), (5, 200, 1, 15), (200, 5, 1, 15), (9, 9, 3, 15), (33, 65, 5, 15),
+    (16, 16, 5, 7), (31, 17, 2, 1), (40, 130, 3, 21), (64, 64, 7, 15)])
+def test_lk_pyr_tiny_and_ragged(mods, rows, cols, levels, win):
+    """Edge cases: images smaller than the window / the tile, 1-pixel coarsest levels, window 1."""
+    lk, pyr = mods
+    rng = np.random.default_rng(rows * 131 + cols)
+    prev = (rng.random((rows, cols)) * 255).astype(np.float32)
+    nxt = np.roll(prev, 1, axis=1) if cols > 1 else prev.copy()
+    eu, ev = orc.lk_flow_pyr(prev, nxt, win, levels)
+    gu, gv = lk.calcOpticalFlowPyr(dev(prev), dev(nxt), win, levels)
+    assert np.array_equal(host(gu), eu) and np.array_equal(host(gv), ev)
+    e1u, e1v = orc.lk_flow(prev, nxt, win)
+    g1u, g1v = lk.calcOpticalFlow(dev(prev), dev(nxt), win)
+    assert np.array_equal(host(g1u), e1u) and np.array_equal(host(g1v), e1v)
+
+
+def test_lk_pitched_views(mods):
+    """cv::Mat ROIs: row pitch larger than the width, for inputs and outputs of the host flavour."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    big_p, big_n = synth.lk_pair(8, 100, 300, 2, -1)
+    prev, nxt = big_p[10:90, 20:220], big_n[10:90, 20:220]  # pitch 300 floats, width 200
+    assert not prev.flags.c_contiguous
+    eu, ev = orc.lk_flow_pyr(np.ascontiguousarray(prev), np.ascontiguousarray(nxt), 15, 3)
+    gu, gv = lk.calcOpticalFlowPyr(prev, nxt, 15, 3)
+    assert np.array_equal(gu, eu) and np.array_equal(gv, ev)
+    dprev, dnxt = dev(big_p)[10:90, 20:220], dev(big_n)[10:90, 20:220]  # device views, same pitch
+    du, dv = lk.calcOpticalFlowPyr(dprev, dnxt, 15, 3)
+    assert np.array_equal(host(du), eu) and np.array_equal(host(dv), ev)
+    su, sv = lk.calcOpticalFlow(dprev, dnxt, 15)
+    e1 = orc.lk_flow(np.ascontiguousarray(prev), np.ascontiguousarray(nxt), 15)
+    assert np.array_equal(host(su), e1[0]) and np.array_equal(host(sv), e1[1])
+
+
+def test_lk_pyr_repeated_runs_are_identical(mods):
+    """Race detector: odd-sized levels (base flow expanded + resized) and a multi-pair batch, run
+    many times -- every run must reproduce the oracle (an output aliasing its own halo input showed
+    up here as a rare mismatch)."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    pairs = [synth.lk_pair(900 + i, 270, 480, 3, -2) for i in range(4)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    exp = [orc.lk_flow_pyr(prev[i], nxt[i], 15, 5) for i in range(4)]
+    dp, dn = dev(prev), dev(nxt)
+    for _ in range(25):
+        gu, gv = lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5)
+        for i in range(4):
+            assert np.array_equal(host(gu[i]), exp[i][0]) and np.array_equal(host(gv[i]), exp[i][1])
+
+
+def test_large_flow_leaves_the_staged_window(mods):
+    """Flows beyond the 8-px margin of the LDS `next` window take the global-memory fallback."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(55, 256, 384, 37, -21)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, 15, 4)
+    gu, gv = lk.calcOpticalFlowPyr(dev(prev), dev(nxt), 15, 4)
+    assert np.array_equal(host(gu), eu) and np.array_equal(host(gv), ev)
+    assert np.abs(eu).max() > 12  # the fallback really ran

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Times the non-LK kernels of the path on their BASELINE configs (device-resident inputs,
+HIP-event timing through micv_timer) and prints one JSON line each with the algorithmic GB/s of
+DESIGN.md §5.  Usage on the GPU box: python tools/bench_kernels.py"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from introtocomputervision_amd import harris, hough, lk, pyr, stereo, synth
+from introtocomputervision_amd._capi import Context, Timer
+
+ctx = Context(0)
+stream = torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = Timer()
+    t.start(stream)
+    for _ in range(iters):
+        fn()
+    t.stop(stream)
+    return t.elapsed_ms() / iters
+
+
+def line(name, ms, px, bytes_per_px, extra=None):
+    d = {"kernel": name, "ms": round(ms, 4), "Mpix_per_s": round(px / ms / 1e3, 1),
+         "algorithmic_GBps": round(px * bytes_per_px / ms / 1e6, 1),
+         "frac_of_8TBps": round(px * bytes_per_px / ms / 1e6 / 8000, 4)}
+    if extra:
+        d.update(extra)
+    print(json.dumps(d))
+
+
+# C3: stereo SSD, 1080p, 11x11 window, 128 disparities
+left, right, _ = synth.stereo_pair(0x5EED0002, 1080, 1920)
+L, R = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+ms = timeit(lambda: stereo.disparitySSD(L, R, 5, -127, 0, ctx=ctx), iters=10)
+line("stereo SSD 1080p r=5 d=128 (C3)", ms, 1080 * 1920, 9, {"Gpixdisp_per_s": round(1080 * 1920 * 128 / ms / 1e6, 1)})
+ms = timeit(lambda: stereo.disparityNCorr(L, R, 5, -127, 0, ctx=ctx), iters=10)
+line("stereo NCC 1080p r=5 d=128", ms, 1080 * 1920, 9)
+# reference's own published case: 640x511, r=7, 96 disparities (19.3 ms on a GTX 1080)
+l2, r2, _ = synth.stereo_pair(3, 511, 640)
+L2, R2 = torch.from_numpy(l2).cuda(), torch.from_numpy(r2).cuda()
+ms = timeit(lambda: stereo.disparitySSD(L2, R2, 7, -95, 0, stereo.AS_WRITTEN_CUDA, ctx=ctx), iters=10)
+line("stereo SSD 640x511 r=7 d=96 as-written (ref: 19.28 ms GTX1080)", ms, 640 * 511, 9)
+
+# C5: 4K Harris (Sobel -> response -> NMS + list) and C1 size
+for rows, cols in ((2160, 3840), (480, 640)):
+    img = torch.from_numpy(synth.checkerboard(rows, cols, 40, seed=0x5EED0004)).cuda()
+    gx, gy = harris.getGradients(img, 3, ctx=ctx)
+    ms_s = timeit(lambda: harris.getGradients(img, 3, ctx=ctx))
+    ms_r = timeit(lambda: harris.getCornerResponse(gx, gy, 5, 1.5, 0.04, ctx=ctx))
+    Rr = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04, ctx=ctx)
+    ms_n = timeit(lambda: harris.refineCorners(Rr, 5e8, 5, capacity=1 << 16, ctx=ctx))
+    line(f"sobel3 pair {cols}x{rows}", ms_s, rows * cols, 12)
+    line(f"harris response 5x5 {cols}x{rows} (ref 480x640: 0.80 ms GTX1080)", ms_r, rows * cols, 12)
+    line(f"harris NMS + ordered list {cols}x{rows} (ref 480x640: 0.59 ms)", ms_n, rows * cols, 8)
+
+# Hough on a 1080p mask
+mask, lines_, circles = synth.hough_mask(1080, 1920)
+Mk = torch.from_numpy(mask).cuda()
+n_edge = int((mask > 0).sum())
+ms = timeit(lambda: hough.houghLinesAccumulate(Mk, 1, 1, ctx=ctx))
+acc = hough.houghLinesAccumulate(Mk, 1, 1, ctx=ctx)
+line("hough lines 1080p 1x1 bins", ms, 1080 * 1920, 1, {"edge_points": n_edge, "Mvotes_per_s": round(n_edge * 180 / ms / 1e3, 1)})
+ms = timeit(lambda: hough.houghCirclesAccumulate(Mk, 30, ctx=ctx))
+line("hough circles 1080p r=30", ms, 1080 * 1920, 5, {"Mvotes_per_s": round(n_edge * 360 / ms / 1e3, 1)})
+ms = timeit(lambda: hough.findLocalMaxima(acc, 10, 300, ctx=ctx))
+line("hough peaks top-10 of 4406x180", ms, 4406 * 180, 4)
+
+# single-level LK and pyramid pieces at 1080p
+prev, nxt = synth.lk_pair(0x5EED0005, 1080, 1920)
+P, N = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
+ms = timeit(lambda: lk.calcOpticalFlow(P, N, 15, ctx=ctx))
+line("lk::calcOpticalFlow 1080p win 15 (fused)", ms, 1080 * 1920, 16)
+ms = timeit(lambda: lk.calcOpticalFlow(P, N, 43, ctx=ctx), iters=5)
+line("lk::calcOpticalFlow 1080p win 43 (generic path)", ms, 1080 * 1920, 16)
+ms = timeit(lambda: pyr.makeGaussianPyramid(P, 5, ctx=ctx))
+line("makeGaussianPyramid 1080p 5 levels", ms, 1080 * 1920, 4 + 4 * 0.333 + 4)
