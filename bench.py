@@ -180,14 +180,15 @@ def main():
             lvl_ms.append(ms / max(n, 1))
         ctx.profile(False)
         ctx.profile_reset()
-        k_bytes = level0_kernel_bytes_pair(ROWS, COLS, LEVELS) * B
+        pairs_per_launch = ctx.profile_lk_pairs() or B  # the library splits the batch into stream groups
+        k_bytes = level0_kernel_bytes_pair(ROWS, COLS, LEVELS) * pairs_per_launch
         achieved = k_bytes / (lvl_ms[0] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from rocprofv3 --pmc runs
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("pairs_per_launch") == B:
+                if tj.get("pairs_per_launch") == pairs_per_launch:
                     traffic = tj.get("level0_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -195,7 +196,7 @@ def main():
             "bound": "hbm", "kernel": "lk_level_kernel<7,COARSE> (pyramid level 0)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "bytes_per_launch": k_bytes, "avg_launch_ms": lvl_ms[0],
+            "bytes_per_launch": k_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": lvl_ms[0],
             "level_ms": lvl_ms,
             "note": "kernel is f32-VALU/LDS-bound (5 x 15-tap separable window sums), not HBM-bound",
         }

@@ -70,6 +70,10 @@ void micv_timer_destroy(micv_timer *t);
 int micv_profile_enable(micv_ctx *ctx, int on);
 int micv_profile_reset(micv_ctx *ctx);
 int micv_profile_lk_level(micv_ctx *ctx, int level, double *total_ms, int64_t *launches);
+/* Frame pairs covered by each profiled level launch: micv_lk_flow_pyr_batch_dev splits a batch
+ * into groups that run on separate streams (env MICV_LK_GROUPS, default 2); the events bracket
+ * the launches of the first group. */
+int micv_profile_lk_pairs(micv_ctx *ctx, int *pairs_per_launch);
 /* In-kernel phase stamps of the fused LK level kernel (diagnostic builds of a timing study, never
  * on in a timed run): while enabled, wave 0 of every workgroup adds the s_memtime ticks it spent
  * in each phase to 16 device counters ([0..5] interior tiles, [8..13] border tiles: stage, pyrUp

@@ -48,6 +48,7 @@ SIGNATURES = {
     "micv_profile_enable": (i32, [vp, i32]),
     "micv_profile_reset": (i32, [vp]),
     "micv_profile_lk_level": (i32, [vp, i32, C.POINTER(f64), C.POINTER(i64)]),
+    "micv_profile_lk_pairs": (i32, [vp, C.POINTER(i32)]),
     "micv_profile_lk_phases": (i32, [vp, i32, vp]),
     "micv_warmup": (i32, [vp, vp]),
     "micv_div_round_up": (sz, [sz, sz]),
@@ -146,6 +147,11 @@ class Context:
         ms, n = f64(), i64()
         check(lib.micv_profile_lk_level(self._h, int(level), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_lk_pairs(self):
+        n = i32()
+        check(lib.micv_profile_lk_pairs(self._h, C.byref(n)))
+        return n.value
 
     def profile_lk_phases(self, enable):
         """Read + reset the 16 in-kernel phase counters, then enable/disable stamping."""

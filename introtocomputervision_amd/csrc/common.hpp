@@ -97,6 +97,13 @@ struct micv_ctx {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[16];
     unsigned long long *stamps = nullptr;  // 16 device counters (micv_profile_lk_phases)
+    int prof_pairs = 0;                    // frame pairs per profiled level launch
+    // Up to 3 auxiliary streams for group-parallel pyramid chains (lk.hip); fork makes them wait
+    // for everything enqueued on `s` so far, join makes `s` wait for them.
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_stagger = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int fork(hipStream_t s, int n);
+    int join(hipStream_t s, int n);
     int prof_begin(int level, hipStream_t s);
     int prof_end(int level, hipStream_t s);
     // Returns scratch of at least `bytes` (256-B aligned). Growing synchronises the device.

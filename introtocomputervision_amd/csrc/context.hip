@@ -99,6 +99,28 @@ int micv_ctx::prof_begin(int level, hipStream_t s) {
     MICV_HIP(hipEventRecord(a, s));
     return MICV_OK;
 }
+int micv_ctx::fork(hipStream_t s, int n) {
+    if (!ev_fork) {
+        MICV_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        MICV_HIP(hipEventCreateWithFlags(&ev_stagger, hipEventDisableTiming));
+    }
+    MICV_HIP(hipEventRecord(ev_fork, s));
+    for (int i = 0; i < n; i++) {
+        if (!aux_stream[i]) {
+            MICV_HIP(hipStreamCreateWithFlags(&aux_stream[i], hipStreamNonBlocking));
+            MICV_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        }
+        MICV_HIP(hipStreamWaitEvent(aux_stream[i], ev_fork, 0));
+    }
+    return MICV_OK;
+}
+int micv_ctx::join(hipStream_t s, int n) {
+    for (int i = 0; i < n; i++) {
+        MICV_HIP(hipEventRecord(ev_join[i], aux_stream[i]));
+        MICV_HIP(hipStreamWaitEvent(s, ev_join[i], 0));
+    }
+    return MICV_OK;
+}
 int micv_ctx::prof_end(int level, hipStream_t s) {
     if (!profile) return MICV_OK;
     MICV_HIP(hipEventRecord(prof[level].back().second, s));
@@ -142,6 +164,12 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)micv_profile_reset(ctx);
     if (ctx->stamps) (void)hipFree(ctx->stamps);
+    for (int i = 0; i < 3; i++) {
+        if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]);
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_stagger) (void)hipEventDestroy(ctx->ev_stagger);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
@@ -184,6 +212,12 @@ int micv_profile_reset(micv_ctx *ctx) {
         }
         v.clear();
     }
+    return MICV_OK;
+}
+
+int micv_profile_lk_pairs(micv_ctx *ctx, int *pairs_per_launch) {
+    MICV_REQUIRE(ctx && pairs_per_launch, "micv_profile_lk_pairs: null argument");
+    *pairs_per_launch = ctx->prof_pairs;
     return MICV_OK;
 }
 
