@@ -14,6 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- \
     "${BENCH[@]}" --steps 20 --warmup 5 > "$out/bench_trace.log" 2>&1
 echo "trace rc=$?"
 
+# PMC passes: one stream group, so each level-0 dispatch covers the whole batch (the launch the
+# roofline line of bench.py is about); counters serialise dispatches anyway.
+export MICV_LK_GROUPS=1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \

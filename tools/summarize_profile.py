@@ -37,7 +37,10 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
 dur = defaultdict(list)
 for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        g = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+        if "Grid_Size_X" in r:  # total work-items = X * Y * Z (batch index is grid.y)
+            g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        else:
+            g = int(r.get("Grid_Size", 0) or 0)
         dur[(short(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 if dur:
     print("== mean duration per (kernel, grid threads)")
