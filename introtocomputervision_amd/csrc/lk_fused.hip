@@ -50,6 +50,8 @@ struct LkCfg {
     // Row stride of the gradient planes: 16-B aligned.  With GS/4 = 4 (mod 16) (GS = 80 for
     // R = 7) the row pass's ds_read_b128 pattern (4 rows x 16 groups per wave) is conflict-free.
     static constexpr int GS = (GW + 3) & ~3;
+    static constexpr int WV = (4 + 2 * R + 3) / 4;          // float4 loads per row-pass window
+    static_assert(4 * (TW / 4 - 1) + 4 * WV <= GS, "row-pass window reads stay inside a plane row");
     static constexpr int RBS = TW;                          // row-buffer stride (XOR-swizzled chunks)
     static constexpr int CW = RW / 2 + 3, CH = RH / 2 + 3;  // coarse flow block
     static constexpr int M = 8;                             // margin of the staged `next` window
@@ -79,11 +81,11 @@ struct LkCfg {
 __device__ __forceinline__ int rb_off(int q, int chunk) { return q * 64 + 4 * (chunk ^ (2 * (q & 3))); }
 
 template <typename C>
-__device__ __forceinline__ void load_window(const float *__restrict__ A, int qy, int c0, float (&w)[20]) {
+__device__ __forceinline__ void load_window(const float *__restrict__ A, int qy, int c0,
+                                            float (&w)[4 * C::WV]) {
     const float4 *a4 = reinterpret_cast<const float4 *>(A + qy * C::GS + c0);
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-        if (4 * i >= 4 + 2 * C::R) break;
+    for (int i = 0; i < C::WV; i++) {
         const float4 v = a4[i];
         w[4 * i + 0] = v.x;
         w[4 * i + 1] = v.y;
@@ -94,7 +96,7 @@ __device__ __forceinline__ void load_window(const float *__restrict__ A, int qy,
 
 // Four adjacent outputs of the (2R+1)-tap row pass of the product field a*b.
 template <typename C>
-__device__ __forceinline__ void row_taps(const float (&a)[20], const float (&b)[20],
+__device__ __forceinline__ void row_taps(const float (&a)[4 * C::WV], const float (&b)[4 * C::WV],
                                          const TapsN<C::W> &g, float *__restrict__ out) {
     float p[4 + 2 * C::R];
 #pragma unroll
@@ -518,7 +520,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         for (int it = 0; it < (GH + 15) / 16; it++) {
             const int qy = it * 16 + wave * 4 + (lane & 3);
             if (qy < GH) {
-                float wx[20], wy[20];
+                float wx[4 * C::WV], wy[4 * C::WV];
                 load_window<C>(Gx, qy, c0, wx);
                 load_window<C>(Gy, qy, c0, wy);
                 const int o = rb_off(qy, grp);
@@ -537,7 +539,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         for (int it = 0; it < (GH + 15) / 16; it++) {
             const int qy = it * 16 + wave * 4 + (lane & 3);
             if (qy < GH) {
-                float wx[20], wy[20], wt[20];
+                float wx[4 * C::WV], wy[4 * C::WV], wt[4 * C::WV];
                 load_window<C>(Gx, qy, c0, wx);
                 load_window<C>(Gy, qy, c0, wy);
                 load_window<C>(Gt, qy, c0, wt);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
         lk_tile<R, MODE, false>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
-bool lk_fused_supports(int win) { return win == 15 || win == 7; }
+bool lk_fused_supports(int win) { return win == 15 || win == 7 || win == 21 || win == 11; }
 
 template <int R>
 static int launch_r(hipStream_t s, const LkLevelArgs &a) {
@@ -662,6 +664,8 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a) {
     switch (a.win) {
         case 15: return launch_r<7>(s, a);
         case 7: return launch_r<3>(s, a);
+        case 21: return launch_r<10>(s, a);  // the reference's default winSize (OpticalFlow.h:9,18)
+        case 11: return launch_r<5>(s, a);
         default:
             set_error("lk fused: window %d has no tiled instantiation", a.win);
             return MICV_EUNSUPPORTED;

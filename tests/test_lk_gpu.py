@@ -125,7 +125,7 @@ def test_lk_host_flavour(mods):
     assert np.array_equal(gu, eu) and np.array_equal(gv, ev)
 
 
-@pytest.mark.parametrize("win", [15, 9])
+@pytest.mark.parametrize("win", [15, 9, 21, 11, 7])
 @pytest.mark.parametrize("rows,cols,levels", [(270, 480, 5), (135, 240, 4), (128, 192, 3), (101, 203, 4), (64, 64, 1)])
 def test_lk_pyr(mods, rows, cols, levels, win):
     lk, pyr = mods
