@@ -101,7 +101,7 @@ struct micv_ctx {
     // Up to 3 auxiliary streams for group-parallel pyramid chains (lk.hip); fork makes them wait
     // for everything enqueued on `s` so far, join makes `s` wait for them.
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_stagger = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     int fork(hipStream_t s, int n);
     int join(hipStream_t s, int n);
     int prof_begin(int level, hipStream_t s);

@@ -100,10 +100,7 @@ int micv_ctx::prof_begin(int level, hipStream_t s) {
     return MICV_OK;
 }
 int micv_ctx::fork(hipStream_t s, int n) {
-    if (!ev_fork) {
-        MICV_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        MICV_HIP(hipEventCreateWithFlags(&ev_stagger, hipEventDisableTiming));
-    }
+    if (!ev_fork) MICV_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     MICV_HIP(hipEventRecord(ev_fork, s));
     for (int i = 0; i < n; i++) {
         if (!aux_stream[i]) {
@@ -169,7 +166,6 @@ void micv_ctx_destroy(micv_ctx *ctx) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_stagger) (void)hipEventDestroy(ctx->ev_stagger);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;

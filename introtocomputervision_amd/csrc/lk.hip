@@ -131,8 +131,127 @@ static void make_plan(int rows, int cols, int levels, PyrPlan *p) {
     p->pyr_elems = off;
 }
 
-// lk::calcOpticalFlowPyr over a batch of pairs.  use_fused selects the LDS-tiled kernel
-// (win must be instantiated there); otherwise the generic kernels run pair by pair.
+// Everything one coarse-to-fine chain needs: a contiguous run of pairs, its stream, and its private
+// flow ping-pong buffers.
+struct LkChain {
+    hipStream_t s;
+    const float *prev, *next;  // level-0 images of the chain's first pair
+    size_t pair_elems;
+    int stride;
+    const float *ppyr[16], *npyr[16];  // levels >= 1 of the chain's first pair (dense, pairs contiguous)
+    int nb;                            // pairs in the chain
+    float *fu[2], *fv[2];              // flow ping-pong (level-0 size per pair)
+    float *u, *v;                      // outputs of the chain's first pair
+    size_t opair_elems;
+    int ostride;
+    bool profile;                      // bracket level launches with events (group 0 only)
+};
+
+// Fused path: OpticalFlow.cpp:135-163 for all pairs of the chain, one launch per level.
+static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, int win) {
+    int cur = 0;         // ping-pong index holding the flow of the previous (coarser) level
+    int fr = 0, fc = 0;  // its dims
+    for (int level = 0; level < plan.levels; level++) {
+        const int k = plan.levels - 1 - level;
+        const int R = plan.rows[k], C = plan.cols[k];
+        const bool last = (k == 0);
+        const size_t lvl_elems = (size_t)R * C;
+        LkLevelArgs a;
+        a.rows = R; a.cols = C; a.batch = c.nb; a.win = win;
+        a.prev = last ? c.prev : c.ppyr[k];
+        a.next = last ? c.next : c.npyr[k];
+        a.img_stride = last ? c.stride : C;
+        a.img_pair = last ? c.pair_elems : lvl_elems;
+        // this level's flow goes to the user's u/v at the finest level
+        a.out_u = last ? c.u : c.fu[cur ^ 1];
+        a.out_v = last ? c.v : c.fv[cur ^ 1];
+        a.out_pair = last ? c.opair_elems : lvl_elems;
+        a.out_stride = last ? c.ostride : C;
+        a.add_base = 1;
+        a.row_begin = 0; a.row_end = R;
+        a.stamps = (last && c.profile) ? ctx->stamps : nullptr;  // phase stamps: level 0 only
+        bool out_in_cur = false;
+        if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
+        if (level == 0) {
+            a.mode = LK_FLOW_NONE;  // du = dv = 0 (:132-133)
+            a.flow_u = a.flow_v = nullptr; a.flow_rows = a.flow_cols = 0; a.flow_pair = 0;
+        } else if (2 * fr == R && 2 * fc == C) {
+            a.mode = LK_FLOW_COARSE;  // pyrUp + x2 fused into the level kernel
+            a.flow_u = c.fu[cur]; a.flow_v = c.fv[cur];
+            a.flow_rows = fr; a.flow_cols = fc; a.flow_pair = (size_t)fr * fc;
+        } else {
+            // :139-151 odd sizes -> pyrUp, x2, cv::resize; one launch for all pairs, both fields
+            float *full_u = c.fu[cur ^ 1], *full_v = c.fv[cur ^ 1];  // this level's base flow
+            MICV_TRY(launch_flow_expand_resize(c.s, c.fu[cur], c.fv[cur], fr, fc, (size_t)fr * fc, full_u,
+                                               full_v, R, C, lvl_elems, c.nb));
+            a.mode = LK_FLOW_FULL;
+            a.flow_u = full_u; a.flow_v = full_v;
+            a.flow_rows = R; a.flow_cols = C; a.flow_pair = lvl_elems;
+            // The tiled kernel reads the base flow of its halo pixels, which other workgroups own:
+            // the output must NOT alias the base.  The coarse buffers are dead after the expand
+            // launch, so the result goes there and the ping-pong index stays put.
+            if (!last) {
+                a.out_u = c.fu[cur]; a.out_v = c.fv[cur];
+                out_in_cur = true;
+            }
+        }
+        MICV_TRY(launch_lk_level_fused(c.s, a));
+        if (c.profile) MICV_TRY(ctx->prof_end(k, c.s));
+        if (!out_in_cur) cur ^= 1;
+        fr = R;
+        fc = C;
+    }
+    return MICV_OK;
+}
+
+// Generic path (any odd window): the same chain with the one-thread-per-pixel kernels, pair by pair.
+static int lk_chain_generic(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, int win, float *warped,
+                            float *gen, float *tmp_a, float *tmp_b) {
+    hipStream_t s = c.s;
+    int cur = 0, fr = 0, fc = 0;
+    for (int level = 0; level < plan.levels; level++) {
+        const int k = plan.levels - 1 - level;
+        const int R = plan.rows[k], C = plan.cols[k];
+        const bool last = (k == 0);
+        const size_t lvl_elems = (size_t)R * C;
+        if (c.profile) MICV_TRY(ctx->prof_begin(k, s));
+        for (int b = 0; b < c.nb; b++) {
+            const float *pk = last ? c.prev + b * c.pair_elems : c.ppyr[k] + b * lvl_elems;
+            const float *nk = last ? c.next + b * c.pair_elems : c.npyr[k] + b * lvl_elems;
+            const int ist = last ? c.stride : C;
+            float *bu = c.fu[cur ^ 1] + b * lvl_elems, *bv = c.fv[cur ^ 1] + b * lvl_elems;
+            if (level == 0) {
+                MICV_HIP(hipMemsetAsync(bu, 0, lvl_elems * 4, s));  // OpticalFlow.cpp:132-133
+                MICV_HIP(hipMemsetAsync(bv, 0, lvl_elems * 4, s));
+            } else {
+                const float *cu = c.fu[cur] + b * (size_t)fr * fc;
+                const float *cv = c.fv[cur] + b * (size_t)fr * fc;
+                if (2 * fr == R && 2 * fc == C) {
+                    MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, bu, C, 2.f, tmp_b));
+                    MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, bv, C, 2.f, tmp_b));
+                } else {
+                    MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
+                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bu, R, C, C));
+                    MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
+                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bv, R, C, C));
+                }
+            }
+            MICV_TRY(launch_warp(s, nk, ist, bu, bv, C, R, C, warped, C));  // :155
+            // in place is fine here: lk_solve_kernel reads and writes the same pixel in one thread
+            float *ou = last ? c.u + b * c.opair_elems : bu;
+            float *ov = last ? c.v + b * c.opair_elems : bv;
+            MICV_TRY(lk_level_generic(s, pk, ist, warped, C, R, C, win, bu, bv, C, ou, ov,
+                                      last ? c.ostride : C, gen));  // :159-162
+        }
+        if (c.profile) MICV_TRY(ctx->prof_end(k, s));
+        cur ^= 1;
+        fr = R;
+        fc = C;
+    }
+    return MICV_OK;
+}
+
+// lk::calcOpticalFlowPyr over a batch of pairs.
 static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const float *next,
                         int batch, size_t pair_elems, int rows, int cols, int stride, int win,
                         int levels, float *u, float *v, size_t opair_elems, int ostride,
@@ -141,15 +260,11 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     make_plan(rows, cols, levels, &plan);
     const bool fused = allow_fused && lk_fused_supports(win);
     const size_t n0 = (size_t)rows * cols;
-    // Scratch: pyramids (levels >= 1) of both images for the whole batch, two flow
-    // ping-pong pairs at level-0 size per pair, and per-path temporaries.
+    // Scratch: pyramids (levels >= 1) of both images for the whole batch, two flow ping-pong pairs
+    // at level-0 size per pair, and the generic path's temporaries.
     const size_t flow_elems = (n0 + 63) & ~size_t(63);
-    size_t total = 0;
-    total += Carver::need(plan.pyr_elems * batch, 4) * 2;
-    total += Carver::need(flow_elems * batch, 4) * 4;
-    // generic: warped + 10 fields (one pair at a time) ; both paths: pyrUp tmp + resize tmp
-    total += Carver::need(n0, 4) + Carver::need(lk_generic_scratch(rows, cols), 4);
-    total += Carver::need(n0, 4) * 2;
+    size_t total = Carver::need(plan.pyr_elems * batch, 4) * 2 + Carver::need(flow_elems * batch, 4) * 4;
+    if (!fused) total += Carver::need(n0, 4) * 3 + Carver::need(lk_generic_scratch(rows, cols), 4);
     void *base;
     MICV_TRY(ctx->reserve(total, &base));
     Carver carve(base);
@@ -157,13 +272,10 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     float *npyr = carve.take<float>(plan.pyr_elems * batch);
     float *fu[2] = {carve.take<float>(flow_elems * batch), carve.take<float>(flow_elems * batch)};
     float *fv[2] = {carve.take<float>(flow_elems * batch), carve.take<float>(flow_elems * batch)};
-    float *warped = carve.take<float>(n0);
-    float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
-    float *tmp_a = carve.take<float>(n0);
-    float *tmp_b = carve.take<float>(n0);
 
-    // Pyramids: one launch per image set (Pyramids.cpp:19-23; every level is a direct
-    // decimation of level 0).  Level l of image b sits at pyr + lvl_off[l]*batch + b*rows_l*cols_l.
+    // Pyramids (Pyramids.cpp:19-23): every level is a direct decimation of level 0, so ONE launch
+    // builds all levels of both images of every pair.  Level l of pair b sits at
+    // pyr + lvl_off[l]*batch + b*rows_l*cols_l.
     if (levels > 1) {
         float *pd[16], *nd[16];
         pd[0] = nd[0] = nullptr;
@@ -173,149 +285,62 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
         }
         MICV_TRY(launch_pyr_build2(s, prev, next, pair_elems, stride, rows, cols, levels, pd, nd, batch));
     }
-    auto level_img = [&](const float *img0, float *pyr, int l, int b, int *st) -> const float * {
-        if (l == 0) {
-            *st = stride;
-            return img0 + b * pair_elems;
+    auto make_chain = [&](hipStream_t cs, int b0, int nb, bool profile) {
+        LkChain c;
+        c.s = cs;
+        c.prev = prev + b0 * pair_elems;
+        c.next = next + b0 * pair_elems;
+        c.pair_elems = pair_elems;
+        c.stride = stride;
+        for (int l = 1; l < levels; l++) {
+            const size_t off = plan.lvl_off[l] * batch + (size_t)b0 * plan.rows[l] * plan.cols[l];
+            c.ppyr[l] = ppyr + off;
+            c.npyr[l] = npyr + off;
         }
-        *st = plan.cols[l];
-        return pyr + plan.lvl_off[l] * batch + (size_t)b * plan.rows[l] * plan.cols[l];
+        c.nb = nb;
+        for (int i = 0; i < 2; i++) {
+            c.fu[i] = fu[i] + flow_elems * b0;
+            c.fv[i] = fv[i] + flow_elems * b0;
+        }
+        c.u = u + b0 * opair_elems;
+        c.v = v + b0 * opair_elems;
+        c.opair_elems = opair_elems;
+        c.ostride = ostride;
+        c.profile = profile;
+        return c;
     };
 
-    // Fused path: the batch is split into groups of pairs that run their coarse-to-fine chains on
-    // separate HIP streams.  The coarse levels of one group are tiny, latency-bound launches; run
-    // beside another group's big level-0 launch they fill CUs that would otherwise idle
-    // (+21 % at 8 pairs on MI355X).  Groups share nothing but the read-only pyramids.
+    if (!fused) {
+        float *warped = carve.take<float>(n0), *tmp_a = carve.take<float>(n0), *tmp_b = carve.take<float>(n0);
+        float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
+        ctx->prof_pairs = batch;
+        return lk_chain_generic(ctx, plan, make_chain(s, 0, batch, true), win, warped, gen, tmp_a, tmp_b);
+    }
+
+    // Fused path: the batch is split into groups of pairs whose chains run on forked HIP streams and
+    // are joined on the caller's stream.  A chain's coarse levels are tiny, latency-bound launches;
+    // beside another group's launches they fill CUs that would otherwise idle (0.713 -> 0.671 ms per
+    // 8-pair step on MI355X).  Groups share nothing but the read-only pyramids.
     int groups = 1;
-    if (fused && batch >= 2) {
+    if (batch >= 2) {
         const char *e = getenv("MICV_LK_GROUPS");
         groups = e ? atoi(e) : 2;
-        if (groups < 1) groups = 1;
-        if (groups > 4) groups = 4;
+        groups = groups < 1 ? 1 : (groups > 4 ? 4 : groups);
         if (groups > batch) groups = batch;
     }
-    // level index at which group 0 releases the other groups (-1 = no stagger)
-    int stagger_k = -1;
-    if (groups > 1) {
-        const char *e = getenv("MICV_LK_STAGGER");
-        stagger_k = e ? atoi(e) : -1;  // measured on MI355X: staggering loses, lock-step groups win
-        if (stagger_k >= levels) stagger_k = -1;
-    }
     if (groups > 1) MICV_TRY(ctx->fork(s, groups - 1));
-    int rc_all = MICV_OK;
-    for (int grp = 0; grp < groups && rc_all == MICV_OK; grp++) {
-    const int b0 = (int)((long long)batch * grp / groups), nb = (int)((long long)batch * (grp + 1) / groups) - b0;
-    hipStream_t sg = grp == 0 ? s : ctx->aux_stream[grp - 1];
-    // this group's private slice of the flow ping-pong buffers
-    float *gfu[2] = {fu[0] + flow_elems * b0, fu[1] + flow_elems * b0};
-    float *gfv[2] = {fv[0] + flow_elems * b0, fv[1] + flow_elems * b0};
-    float *gu = u + b0 * opair_elems, *gv = v + b0 * opair_elems;
-    if (grp == 0) ctx->prof_pairs = nb;
-    auto run_group = [&]() -> int {
-    float *const *fu = gfu, *const *fv = gfv;  // shadow the batch-wide buffers
-    float *u = gu, *v = gv;
-    hipStream_t s = sg;
-    const int batch = nb;
-    int cur = 0;         // ping-pong index holding the flow of the previous (coarser) level
-    int fr = 0, fc = 0;  // its dims
-    // Stagger: later groups start when group 0 has issued its coarse levels, so their own coarse
-    // (latency-bound) launches run beside group 0's big ones instead of in lock-step with them.
-    if (groups > 1 && grp > 0 && stagger_k >= 0) MICV_HIP(hipStreamWaitEvent(s, ctx->ev_stagger, 0));
-    for (int level = 0; level < levels; level++) {
-        const int k = levels - 1 - level;
-        const int R = plan.rows[k], C = plan.cols[k];
-        const bool last = (k == 0);
-        const size_t lvl_elems = (size_t)R * C;
-        if (groups > 1 && grp == 0 && k == stagger_k) MICV_HIP(hipEventRecord(ctx->ev_stagger, s));
-        // Where this level's flow is written: the user's u/v at the finest level.
-        float *out_u = last ? u : fu[cur ^ 1];
-        float *out_v = last ? v : fv[cur ^ 1];
-        const size_t out_pair = last ? opair_elems : lvl_elems;
-        const int out_stride = last ? ostride : C;
-
-        if (grp == 0) MICV_TRY(ctx->prof_begin(k, s));
-        bool out_in_cur = false;
-        if (fused) {
-            LkLevelArgs a;
-            a.rows = R; a.cols = C; a.batch = batch; a.win = win;
-            int ps, ns;
-            a.prev = level_img(prev, ppyr, k, b0, &ps);
-            a.next = level_img(next, npyr, k, b0, &ns);
-            a.img_stride = ps;
-            a.img_pair = (k == 0) ? pair_elems : lvl_elems;
-            a.out_u = out_u; a.out_v = out_v; a.out_stride = out_stride; a.out_pair = out_pair;
-            a.add_base = 1;
-            a.row_begin = 0; a.row_end = R;
-            a.stamps = (k == 0) ? ctx->stamps : nullptr;  // phase stamps: level 0 only
-            if (level == 0) {
-                a.mode = LK_FLOW_NONE;
-                a.flow_u = a.flow_v = nullptr; a.flow_rows = a.flow_cols = 0; a.flow_pair = 0;
-            } else if (2 * fr == R && 2 * fc == C) {
-                a.mode = LK_FLOW_COARSE;  // pyrUp + x2 fused into the level kernel
-                a.flow_u = fu[cur]; a.flow_v = fv[cur];
-                a.flow_rows = fr; a.flow_cols = fc; a.flow_pair = (size_t)fr * fc;
-            } else {
-                // OpticalFlow.cpp:139-151: odd sizes -> pyrUp, x2, cv::resize; one launch for
-                // the whole batch and both fields.
-                float *full_u = fu[cur ^ 1], *full_v = fv[cur ^ 1];  // becomes this level's base
-                MICV_TRY(launch_flow_expand_resize(s, fu[cur], fv[cur], fr, fc, (size_t)fr * fc,
-                                                   full_u, full_v, R, C, lvl_elems, batch));
-                a.mode = LK_FLOW_FULL;
-                a.flow_u = full_u; a.flow_v = full_v;
-                a.flow_rows = R; a.flow_cols = C; a.flow_pair = lvl_elems;
-                // The tiled kernel reads the base flow of its halo pixels, which other workgroups
-                // own: the output must NOT alias the base.  The coarse buffers are dead after the
-                // expand launch, so the result goes there and the ping-pong index stays put.
-                if (!last) {
-                    a.out_u = fu[cur]; a.out_v = fv[cur];
-                    out_in_cur = true;
-                }
-            }
-            MICV_TRY(launch_lk_level_fused(s, a));
-        } else {
-            for (int b = 0; b < batch; b++) {
-                int ps, ns;
-                const float *pk = level_img(prev, ppyr, k, b, &ps);
-                const float *nk = level_img(next, npyr, k, b, &ns);
-                float *bu = fu[cur ^ 1] + b * lvl_elems, *bv = fv[cur ^ 1] + b * lvl_elems;
-                if (level == 0) {
-                    MICV_HIP(hipMemsetAsync(bu, 0, lvl_elems * 4, s));  // OpticalFlow.cpp:132-133
-                    MICV_HIP(hipMemsetAsync(bv, 0, lvl_elems * 4, s));
-                } else {
-                    const float *cu = fu[cur] + b * (size_t)fr * fc;
-                    const float *cv = fv[cur] + b * (size_t)fr * fc;
-                    if (2 * fr == R && 2 * fc == C) {
-                        MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, bu, C, 2.f, tmp_b));
-                        MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, bv, C, 2.f, tmp_b));
-                    } else {
-                        MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
-                        MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bu, R, C, C));
-                        MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
-                        MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bv, R, C, C));
-                    }
-                }
-                MICV_TRY(launch_warp(s, nk, ns, bu, bv, C, R, C, warped, C));  // :155
-                float *ou = last ? u + b * opair_elems : bu;
-                float *ov = last ? v + b * opair_elems : bv;
-                MICV_TRY(lk_level_generic(s, pk, ps, warped, C, R, C, win, bu, bv, C, ou, ov,
-                                          out_stride, gen));  // :159-162
-            }
-        }
-        if (grp == 0) MICV_TRY(ctx->prof_end(k, s));
-        if (!out_in_cur) cur ^= 1;
-        fr = R;
-        fc = C;
+    int rc = MICV_OK;
+    for (int g = 0; g < groups && rc == MICV_OK; g++) {
+        const int b0 = (int)((long long)batch * g / groups);
+        const int nb = (int)((long long)batch * (g + 1) / groups) - b0;
+        if (g == 0) ctx->prof_pairs = nb;
+        rc = lk_chain_fused(ctx, plan, make_chain(g == 0 ? s : ctx->aux_stream[g - 1], b0, nb, g == 0), win);
     }
-    return MICV_OK;
-    };  // run_group
-    rc_all = run_group();
-    }
-    // always re-join the forked streams, also after an error, so nothing is left dangling
-    if (groups > 1) {
+    if (groups > 1) {  // always re-join, also after an error, so no stream is left dangling
         const int rcj = ctx->join(s, groups - 1);
-        if (rc_all == MICV_OK) rc_all = rcj;
+        if (rc == MICV_OK) rc = rcj;
     }
-    return rc_all;
+    return rc;
 }
 
 }  // namespace micv
