@@ -244,6 +244,23 @@ int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
 int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
                           unsigned num_peaks, int threshold, uint32_t *peaks_rc, int64_t *count);
 
+/* ----------------------------------- ps7: motion history ----- */
+
+/* mhi::frameDifference, ps7_cpp/lib/MotionHistory.cpp:26-77, for single-channel CV_8U frames:
+ * Gaussian blur (blur_size odd <= 31, blur_sigma > 0), saturating f2 - f1, AbsThreshold -> {0,1},
+ * 7x7 elliptical morphological open.  diff is rows x cols u8. */
+int micv_mhi_frame_difference_dev(micv_ctx *ctx, const uint8_t *f1, const uint8_t *f2, int rows,
+                                  int cols, size_t stride, double thresh, int blur_size,
+                                  double blur_sigma, uint8_t *diff, size_t dstride,
+                                  micv_stream stream);
+/* thresholdDifference / AbsThreshold<uint8_t>, ps7_cpp/lib/MotionHistory.cu:17-48. */
+int micv_mhi_threshold_dev(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t sstride,
+                           double thresh, uint8_t *dst, size_t dstride, micv_stream stream);
+/* mhi::calcMotionHistory -> motionHistoryKernel, MotionHistory.cu:52-83: in place,
+ * history = mask == 1 ? tau : max(history - 1, 0). */
+int micv_mhi_update_dev(micv_ctx *ctx, uint8_t *history, size_t hstride, const uint8_t *mask,
+                        size_t mstride, int rows, int cols, int tau, micv_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

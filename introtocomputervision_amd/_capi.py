@@ -98,6 +98,10 @@ SIGNATURES = {
     "micv_hough_circles_host": (i32, [vp, vp, i32, i32, sz, u32, vp]),
     "micv_hough_peaks_dev": (i32, [vp, vp, i32, i32, u32, i32, vp, vp, vp]),
     "micv_hough_peaks_host": (i32, [vp, vp, i32, i32, u32, i32, vp, vp]),
+    # ps7
+    "micv_mhi_frame_difference_dev": (i32, [vp, vp, vp, i32, i32, sz, f64, i32, f64, vp, sz, vp]),
+    "micv_mhi_threshold_dev": (i32, [vp, vp, i32, i32, sz, f64, vp, sz, vp]),
+    "micv_mhi_update_dev": (i32, [vp, vp, sz, vp, sz, i32, i32, i32, vp]),
 }
 
 MISSING = []

@@ -162,6 +162,19 @@ int64_t orc_hough_peaks(const int32_t *acc, int rows, int cols, unsigned num_pea
 /* The float cos/sin table (degrees -90..269) shared by the oracle's Hough functions. */
 void orc_hough_trig_table(float *cos360, float *sin360);
 
+/* ---- ps7: motion history ---- */
+
+/* thresholdDifference (MotionHistory.cu:17-48), mhi::frameDifference (MotionHistory.cpp:26-77,
+ * single-channel CV_8U), mhi::calcMotionHistory (MotionHistory.cu:52-66), mhi::energyFromHistory
+ * (MotionHistory.cpp:98-105). */
+void orc_mhi_threshold(const uint8_t *src, size_t n, double thresh, uint8_t *dst);
+int orc_mhi_frame_difference(const uint8_t *f1, const uint8_t *f2, int rows, int cols, size_t stride,
+                             double thresh, int ksize, double sigma, uint8_t *diff, size_t dstride);
+void orc_mhi_update(uint8_t *history, size_t hstride, const uint8_t *mask, size_t mstride, int rows,
+                    int cols, int tau);
+void orc_mhi_energy(const uint8_t *mhi, size_t n, uint8_t *mei);
+void orc_ellipse7(uint8_t m[7][7]);
+
 #ifdef __cplusplus
 }
 #endif

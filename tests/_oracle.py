@@ -276,6 +276,36 @@ def hough_peaks(acc, num_peaks, threshold):
     return peaks[:n].copy()
 
 
+_mhi_fd = _sig("orc_mhi_frame_difference", i32, [vp, vp, i32, i32, sz, f64, i32, f64, vp, sz])
+_mhi_thr = _sig("orc_mhi_threshold", None, [vp, sz, f64, vp])
+_mhi_upd = _sig("orc_mhi_update", None, [vp, sz, vp, sz, i32, i32, i32])
+
+
+def mhi_frame_difference(f1, f2, thresh, ksize=3, sigma=1.0):
+    f1 = np.ascontiguousarray(f1, dtype=np.uint8); f2 = np.ascontiguousarray(f2, dtype=np.uint8)
+    r, c = f1.shape
+    out = np.empty((r, c), np.uint8)
+    rc = _mhi_fd(_p(f1), _p(f2), r, c, c, float(thresh), ksize, float(sigma), _p(out), c)
+    if rc:
+        raise ValueError(f"orc_mhi_frame_difference rc={rc}")
+    return out
+
+
+def mhi_threshold(src, thresh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    out = np.empty_like(src)
+    _mhi_thr(_p(src), src.size, float(thresh), _p(out))
+    return out
+
+
+def mhi_update(history, mask, tau):
+    h = np.ascontiguousarray(history, dtype=np.uint8).copy()
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    r, c = h.shape
+    _mhi_upd(_p(h), c, _p(m), c, r, c, tau)
+    return h
+
+
 def rgb8_to_gray(rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     r, c, _ = rgb.shape

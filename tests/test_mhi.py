@@ -1,0 +1,50 @@
+"""ps7 motion-history path: oracle sanity on CPU, HIP parity on GPU
+(byte outputs: bit-exact)."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+
+def moving_square(rows, cols, x0, seed=3):
+    rng = np.random.default_rng(seed)
+    f = rng.integers(90, 110, (rows, cols)).astype(np.uint8)
+    f[rows // 3: rows // 3 + 30, x0:x0 + 30] = 230
+    return f
+
+
+def test_oracle_frame_difference_finds_the_leading_edge():
+    f1, f2 = moving_square(120, 160, 40), moving_square(120, 160, 52)
+    d = orc.mhi_frame_difference(f1, f2, 20, 5, 1.5)
+    assert set(np.unique(d)) <= {0, 1}
+    ys, xs = np.nonzero(d)
+    assert len(xs) > 100 and xs.min() >= 64 and xs.max() <= 88 and ys.min() >= 35 and ys.max() <= 75
+    # saturating subtract: the trailing edge (f2 < f1) produces nothing
+    assert not d[:, :60].any()
+    h = np.zeros((120, 160), np.uint8)
+    for _ in range(3):
+        h = orc.mhi_update(h, d, 25)
+    assert set(np.unique(h)) == {0, 25}
+    h2 = orc.mhi_update(h, np.zeros_like(d), 25)
+    assert set(np.unique(h2)) == {0, 24}
+    assert np.array_equal(orc.mhi_threshold(np.arange(256, dtype=np.uint8).reshape(16, 16), 1.7).ravel(),
+                          (np.arange(256) >= 2).astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,ksize,sigma,thr", [(120, 160, 5, 1.5, 20), (97, 131, 31, 10.0, 1.7),
+                                                       (33, 40, 3, 1.0, 5), (480, 640, 31, 10.0, 1.7)])
+def test_mhi_gpu_matches_oracle(rows, cols, ksize, sigma, thr):
+    import torch
+    from introtocomputervision_amd import mhi
+    f1, f2 = moving_square(rows, cols, cols // 4), moving_square(rows, cols, cols // 4 + 7, seed=4)
+    exp = orc.mhi_frame_difference(f1, f2, thr, ksize, sigma)
+    d1, d2 = torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda()
+    got = mhi.frameDifference(d1, d2, thr, ksize, sigma)
+    assert np.array_equal(got.cpu().numpy(), exp)
+    hist = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (rows, cols)).astype(np.uint8)).cuda()
+    eh = orc.mhi_update(hist.cpu().numpy(), exp, 25)
+    mhi.calcMotionHistory(hist, got, 25)
+    assert np.array_equal(hist.cpu().numpy(), eh)
+    assert np.array_equal(mhi.thresholdDifference(d1, thr).cpu().numpy(), orc.mhi_threshold(f1, thr))
+    assert np.array_equal(mhi.energyFromHistory(hist).cpu().numpy(), (eh > 0).astype(np.uint8))
