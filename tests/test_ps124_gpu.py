@@ -248,3 +248,35 @@ def test_hough_1080p_peaks_find_the_drawn_lines(M):
     found = {(int(round(p[0] - diag)), int(p[1]) - 90) for p in peaks}
     for rho, theta in lines:
         assert any(abs(fr - rho) <= 2 and abs(ft - theta) <= 1 for fr, ft in found), (rho, theta)
+
+
+def test_c5_4k_harris_keypoints_lk(M):
+    """BASELINE config C5 at full size (3840x2160): Harris -> corner list -> keypoint angles -> 5-level
+    LK sampled at the corners.  Harris response / corner list / flow are compared bit-for-bit with
+    the oracle at this size; the flow at the corners must be the known translation."""
+    harris, stereo, hough, synth = M
+    from introtocomputervision_amd import lk
+    rows, cols = 2160, 3840
+    tex = synth.smooth_noise(0x5EED0004, rows, cols)
+    chk = synth.checkerboard(rows, cols, square=40)
+    prev = np.round(tex * (chk / 192.0)).astype(np.float32)      # corners + texture, integer valued
+    nxt = np.ascontiguousarray(np.roll(prev, shift=(-2, 3), axis=(0, 1)))
+    dp, dn = dev(prev), dev(nxt)
+    gx, gy = harris.getGradients(dp, 3)
+    R = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04)
+    corners, locs = harris.refineCorners(R, 5e8, 5, capacity=1 << 20)
+    egx, egy = orc.sobel(prev, 3, 1.0)
+    eR = orc.harris_response(egx, egy, 5, 1.5, 0.04)
+    _, el = orc.harris_refine(eR, 5e8, 5)
+    assert np.array_equal(host(R), eR)
+    assert np.array_equal(host(locs), el) and len(el) > 1000
+    kp = host(harris.getKeypoints(gx, gy, locs, 10))
+    ekp = orc.sift_keypoints(egx, egy, el, 10)
+    assert np.array_equal(kp[:, :3], ekp[:, :3]) and np.allclose(kp[:, 3], ekp[:, 3], atol=1e-3, rtol=0)
+    u, v = lk.calcOpticalFlowPyr(dp, dn, 15, 5)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, 15, 5)
+    assert np.array_equal(host(u), eu) and np.array_equal(host(v), ev)
+    inner = el[(el[:, 0] > 100) & (el[:, 0] < rows - 100) & (el[:, 1] > 100) & (el[:, 1] < cols - 100)]
+    fu, fv = eu[inner[:, 0], inner[:, 1]], ev[inner[:, 0], inner[:, 1]]
+    # the checker edges bias LK at the corners themselves (the oracle gives (2.99, -2.55) here)
+    assert abs(np.median(fu) - 3.0) < 0.3 and abs(np.median(fv) + 2.0) < 0.75
