@@ -32,12 +32,14 @@ struct TrigTable {
 };
 
 // degToRad (Hough.cu:20-24): float theta * double PI / 180.f -> float.
-static void build_trig(int theta0, TrigTable *t) {
+static TrigTable make_trig(int theta0) {
+    TrigTable t;
     for (int i = 0; i < 360; i++) {
         const float rad = (float)((double)(float)(theta0 + i) * 3.14159265 / 180.f);
-        t->c[i] = (float)std::cos((double)rad);
-        t->s[i] = (float)std::sin((double)rad);
+        t.c[i] = (float)std::cos((double)rad);
+        t.s[i] = (float)std::sin((double)rad);
     }
+    return t;
 }
 
 // grid (theta bins, chunks); dynamic LDS = rho_bins ints.
@@ -244,12 +246,7 @@ int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols,
     char *extra;
     MICV_TRY(hough_points(ctx, s, mask, rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
     TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
-    static TrigTable ht;
-    static bool ht_ok = false;
-    if (!ht_ok) {
-        build_trig(-90, &ht);
-        ht_ok = true;
-    }
+    static const TrigTable ht = make_trig(-90);  // thread-safe one-time initialisation
     MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
     MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rb * tb * sizeof(int32_t), s));
     const float diag = (float)hough_diag(rows, cols);
@@ -279,12 +276,7 @@ int micv_hough_circles_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int col
     char *extra;
     MICV_TRY(hough_points(ctx, s, mask, rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
     TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
-    static TrigTable ht;
-    static bool ht_ok = false;
-    if (!ht_ok) {
-        build_trig(0, &ht);  // theta = 0..359, Hough.cu:85
-        ht_ok = true;
-    }
+    static const TrigTable ht = make_trig(0);  // theta = 0..359, Hough.cu:85
     MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
     MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rows * cols * sizeof(int32_t), s));  // ref forgets, :318
     hough_circles_kernel<<<2048, 256, 0, s>>>(pts, npts, rows, cols, dt->c, dt->s, (float)radius, acc);
