@@ -244,6 +244,21 @@ int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
 int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
                           unsigned num_peaks, int threshold, uint32_t *peaks_rc, int64_t *count);
 
+/* --------------------------- ps4: descriptor matching ----------- */
+
+/* cv::BFMatcher::create()->knnMatch(query, train, matches, 2), ps4_cpp/src/Solution.cpp:172-179:
+ * NORM_L2, no cross-check.  query is nq x dim, train nt x dim (f32, strides in bytes, nt >= 2).
+ * idx2 [nq][2] = train indices of the nearest and second nearest, dist2 [nq][2] their distances,
+ * ordered by (distance, index). */
+int micv_bf_knn2_dev(micv_ctx *ctx, const float *query, int nq, size_t qstride, const float *train,
+                     int nt, size_t tstride, int dim, int32_t *idx2, float *dist2,
+                     micv_stream stream);
+/* The ratio test of Solution.cpp:180-184: keep query q when dist0 < ratio * dist1.  matches_qt
+ * [cap][2] = (queryIdx, trainIdx) in query order, distances [cap]; *count (device) = number kept. */
+int micv_bf_ratio_filter_dev(micv_ctx *ctx, const int32_t *idx2, const float *dist2, int nq,
+                             double ratio, int32_t *matches_qt, float *distances, int64_t cap,
+                             int64_t *count, micv_stream stream);
+
 /* ----------------------------------- ps7: motion history ----- */
 
 /* mhi::frameDifference, ps7_cpp/lib/MotionHistory.cpp:26-77, for single-channel CV_8U frames:

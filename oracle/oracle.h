@@ -162,6 +162,14 @@ int64_t orc_hough_peaks(const int32_t *acc, int rows, int cols, unsigned num_pea
 /* The float cos/sin table (degrees -90..269) shared by the oracle's Hough functions. */
 void orc_hough_trig_table(float *cos360, float *sin360);
 
+/* ---- ps4: descriptor matching ---- */
+
+/* cv::BFMatcher (NORM_L2) knnMatch k = 2 and the ratio test, ps4_cpp/src/Solution.cpp:172-184. */
+void orc_bf_knn2(const float *query, int nq, size_t qstride, const float *train, int nt, size_t tstride,
+                 int dim, int32_t *idx2, float *dist2);
+int64_t orc_bf_ratio_filter(const int32_t *idx2, const float *dist2, int nq, double ratio,
+                            int32_t *matches_qt, float *distances, int64_t cap);
+
 /* ---- ps7: motion history ---- */
 
 /* thresholdDifference (MotionHistory.cu:17-48), mhi::frameDifference (MotionHistory.cpp:26-77,
