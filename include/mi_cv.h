@@ -244,6 +244,17 @@ int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
 int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
                           unsigned num_peaks, int threshold, uint32_t *peaks_rc, int64_t *count);
 
+/* ------------------------------ ps1: edge front-end ------------ */
+
+/* sol::generateEdge, ps1_cpp/src/Solution.cpp:21-47, on a single-channel 8-bit image: Gaussian
+ * blur (cv::cuda::createGaussianFilter, odd size <= 31; size 1 = identity) then Canny with Sobel
+ * aperture 3 and the L1 gradient norm; edges = 255 / 0.  The hysteresis pass reads one device
+ * flag per round, so this entry point SYNCHRONISES `stream` (OpenCV's CUDA Canny does the same
+ * with its queue counter). */
+int micv_generate_edge_dev(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t stride,
+                           int gauss_size, double gauss_sigma, double low_thresh, double high_thresh,
+                           uint8_t *edges, size_t estride, micv_stream stream);
+
 /* --------------------------- ps4: descriptor matching ----------- */
 
 /* cv::BFMatcher::create()->knnMatch(query, train, matches, 2), ps4_cpp/src/Solution.cpp:172-179:

@@ -98,6 +98,8 @@ SIGNATURES = {
     "micv_hough_circles_host": (i32, [vp, vp, i32, i32, sz, u32, vp]),
     "micv_hough_peaks_dev": (i32, [vp, vp, i32, i32, u32, i32, vp, vp, vp]),
     "micv_hough_peaks_host": (i32, [vp, vp, i32, i32, u32, i32, vp, vp]),
+    # ps1 edge front-end
+    "micv_generate_edge_dev": (i32, [vp, vp, i32, i32, sz, i32, f64, f64, f64, vp, sz, vp]),
     # ps4 matching
     "micv_bf_knn2_dev": (i32, [vp, vp, i32, sz, vp, i32, sz, i32, vp, vp, vp]),
     "micv_bf_ratio_filter_dev": (i32, [vp, vp, vp, i32, f64, vp, vp, i64, vp, vp]),

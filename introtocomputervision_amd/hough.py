@@ -72,3 +72,19 @@ def findLocalMaxima(accumulator, numPeaks, threshold, ctx=None):
     check(lib.micv_hough_peaks_host(c.handle, B.ptr(accumulator), rows, cols, k, int(threshold),
                                     peaks.ctypes.data, C.byref(cnt)))
     return peaks[:cnt.value]
+
+
+def generateEdge(image, gaussianSize, gaussianSigma, lowerThreshold, upperThreshold, ctx=None):
+    """sol::generateEdge (ps1_cpp/src/Solution.cpp:21-47) on a 2-D uint8 CUDA tensor -> 255/0 edge
+    mask (Gaussian blur + Canny, aperture 3)."""
+    import torch
+    if not (B.is_dev(image) and image.is_cuda and image.dim() == 2 and image.dtype == torch.uint8
+            and image.stride(1) == 1):
+        raise ValueError("image: need a 2-D uint8 CUDA tensor with unit column stride")
+    rows, cols = image.shape
+    edges = torch.empty((rows, cols), dtype=torch.uint8, device=image.device)
+    check(lib.micv_generate_edge_dev(_ctx_for(image, ctx).handle, image.data_ptr(), rows, cols,
+                                     image.stride(0), int(gaussianSize), float(gaussianSigma),
+                                     float(lowerThreshold), float(upperThreshold), edges.data_ptr(), cols,
+                                     B.stream_of(image)))
+    return edges

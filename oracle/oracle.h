@@ -162,6 +162,18 @@ int64_t orc_hough_peaks(const int32_t *acc, int rows, int cols, unsigned num_pea
 /* The float cos/sin table (degrees -90..269) shared by the oracle's Hough functions. */
 void orc_hough_trig_table(float *cos360, float *sin360);
 
+/* ---- ps1: edge front-end ---- */
+
+/* cv::cuda Gaussian blur on CV_8U, Canny (aperture 3, L1 norm), sol::generateEdge
+ * (ps1_cpp/src/Solution.cpp:21-47). */
+void orc_gauss_u8(const uint8_t *src, int rows, int cols, size_t stride, int ksize, double sigma,
+                  uint8_t *dst, size_t dstride);
+int orc_canny(const uint8_t *src, int rows, int cols, size_t stride, double low_thresh,
+              double high_thresh, uint8_t *edges, size_t estride);
+int orc_generate_edge(const uint8_t *src, int rows, int cols, size_t stride, int gauss_size,
+                      double gauss_sigma, double low_thresh, double high_thresh, uint8_t *edges,
+                      size_t estride);
+
 /* ---- ps4: descriptor matching ---- */
 
 /* cv::BFMatcher (NORM_L2) knnMatch k = 2 and the ratio test, ps4_cpp/src/Solution.cpp:172-184. */
