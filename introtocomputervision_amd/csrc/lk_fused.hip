@@ -24,6 +24,7 @@
 // generic kernels in lk.hip and to the CPU oracle: every body produces the same bits.
 #include "lk_fused.hpp"
 
+#include <cstdlib>
 #include <mutex>
 
 #include "lk_device.hpp"
@@ -38,11 +39,11 @@ struct TapsN {
     float k[N];
 };
 
-template <int R_>
+template <int R_, int NT_ = 256>
 struct LkCfg {
     static constexpr int R = R_;
     static constexpr int W = 2 * R + 1;
-    static constexpr int TW = 64, TH = 32, NT = 256;
+    static constexpr int TW = 64, TH = 32, NT = NT_;
     static constexpr int H = R + 1;                         // image halo (Sobel + window)
     static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;  // image region
     static constexpr int PS = RW;                           // LDS row stride of P / Wp
@@ -56,7 +57,7 @@ struct LkCfg {
     static constexpr int CW = RW / 2 + 3, CH = RH / 2 + 3;  // coarse flow block
     static constexpr int M = 8;                             // margin of the staged `next` window
     static constexpr int NW = RW + 2 * M, NH = RH + 2 * M;
-    static constexpr int ROWS_PER_THREAD = TH / (NT / TW);  // 8
+    static constexpr int RPT = TH / (NT / TW);  // output rows per thread: 8 (256 threads) or 4 (512)
     static constexpr int ROWBUF_F = 3 * GH * RBS;
     static constexpr int IMG_F = (2 * RH * PS > ROWBUF_F ? 2 * RH * PS : ROWBUF_F);
     static constexpr int C_F = (2 * CH * CW + 3) & ~3;         // coarse block, both fields, 16-B padded
@@ -66,11 +67,11 @@ struct LkCfg {
     static constexpr int X_F = (FLOW_F > GRAD_F ? FLOW_F : GRAD_F) > STAGE_F
                                    ? (FLOW_F > GRAD_F ? FLOW_F : GRAD_F)
                                    : STAGE_F;
-    static_assert(ROWS_PER_THREAD == 8, "column pass is written for 8 rows per thread");
+    static_assert(RPT == 8 || RPT == 4, "256 or 512 threads per 64x32 tile");
     static constexpr int LDS_FLOATS = IMG_F + X_F;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
     // The marching body of phase 2 is written for 8-row segments and 16-B rows.
-    static constexpr bool FAST = (H % 8 == 0) && (RW % 4 == 0);
+    static constexpr bool FAST = (H % RPT == 0) && (RW % 4 == 0);
 };
 
 // ---- phase 4 building blocks ------------------------------------------------------------------
@@ -114,14 +115,14 @@ __device__ __forceinline__ void row_taps(const float (&a)[4 * C::WV], const floa
 
 // Column pass: thread (c, r0) produces 8 vertically adjacent window sums from one row buffer.
 template <typename C>
-__device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S)[8],
+__device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S)[C::RPT],
                                          const TapsN<C::W> &g, int c, int r0) {
     constexpr int R = C::R;
-    float v[8 + 2 * R];
+    float v[C::RPT + 2 * R];
 #pragma unroll
-    for (int i = 0; i < 8 + 2 * R; i++) v[i] = rb[rb_off(r0 + i, c >> 2) + (c & 3)];
+    for (int i = 0; i < C::RPT + 2 * R; i++) v[i] = rb[rb_off(r0 + i, c >> 2) + (c & 3)];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < C::RPT; j++) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < C::W; k++) acc = fmaf(v[j + k], g.k[k], acc);
@@ -131,10 +132,11 @@ __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S
 
 // ---- the tile body ---------------------------------------------------------------------------
 
-template <int R, int MODE, bool INT>
+template <int R, int MODE, bool INT, int NTV>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
                                         float *lds, int tile_x, int tile_y, int pair) {
-    using C = LkCfg<R>;
+    using C = LkCfg<R, NTV>;
+    constexpr int RPT = C::RPT;
     constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
     constexpr int GW = C::GW, GH = C::GH, GS = C::GS, CW = C::CW, CH = C::CH, NT = C::NT;
     constexpr int M = C::M, NW = C::NW, NH = C::NH;
@@ -260,9 +262,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             }
         }
     }
-    float base_u[8], base_v[8];
+    float base_u[RPT], base_v[RPT];
 #pragma unroll
-    for (int j = 0; j < 8; j++) base_u[j] = base_v[j] = 0.f;
+    for (int j = 0; j < RPT; j++) base_u[j] = base_v[j] = 0.f;
     if (MODE != LK_FLOW_NONE) __syncthreads();
     MICV_STAMP(0)
 
@@ -276,13 +278,13 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // field, built from 3 coarse columns each, serve all 8 rows.
             auto march = [&](int lx, int ly0, float *bu8, float *bv8) {
                 const int gx = rx0 + lx, gy0 = ry0 + ly0;
-                float ru[6], rv[6];
+                float ru[RPT / 2 + 2], rv[RPT / 2 + 2];
                 if (MODE == LK_FLOW_COARSE) {
                     const int cyb = ((gy0 >> 1) - 1) - cy0;
                     const int ccb = ((gx >> 1) - 1) - cx0;
                     const bool odd = gx & 1;
 #pragma unroll
-                    for (int i = 0; i < 6; i++) {
+                    for (int i = 0; i < RPT / 2 + 2; i++) {
                         const float *cu = Cu + (cyb + i) * CW + ccb, *cv = Cv + (cyb + i) * CW + ccb;
                         const float u0 = cu[0], u1 = cu[1], u2 = cu[2];
                         const float v0 = cv[0], v1 = cv[1], v2 = cv[2];
@@ -301,7 +303,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     }
                 }
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
+                for (int p = 0; p < RPT / 2; p++) {
 #pragma unroll
                     for (int o = 0; o < 2; o++) {
                         const int j = 2 * p + o;
@@ -326,28 +328,31 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         }
                         bu8[j] = bu;
                         bv8[j] = bv;
+                        // warp right away: the flow pair's live range ends here
+                        Wp[(ly0 + j) * PS + lx] = warp_sample_staged<NW, NH>(
+                            Nx, rx0 - M, ry0 - M, next, rows, cols, istride, gx, gy0 + j, bu, bv);
+                        // 512-thread tiles run at a 128-VGPR budget: keep the rows from interleaving
+                        if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    Wp[(ly0 + j) * PS + lx] = warp_sample_staged<NW, NH>(
-                        Nx, rx0 - M, ry0 - M, next, rows, cols, istride, gx, gy0 + j, bu8[j], bv8[j]);
             };
-            march(H + (tid & (TW - 1)), H + 8 * (tid / TW), base_u, base_v);  // own outputs
-            // halo jobs: top / bottom bands (RW columns each), left / right bands (H columns x TH/8)
-            constexpr int NJ = 2 * RW + 2 * H * (TH / 8);
+            march(H + (tid & (TW - 1)), H + RPT * (tid / TW), base_u, base_v);  // own outputs
+            // halo jobs: top / bottom bands (H/RPT segments x RW columns each), left / right bands
+            // (H columns each x TH/RPT segments)
+            constexpr int BS = H / RPT, NJ = 2 * BS * RW + 2 * H * (TH / RPT);
             for (int n = tid; n < NJ; n += NT) {
                 int lx, ly0;
-                if (n < 2 * RW) {
-                    lx = n < RW ? n : n - RW;
-                    ly0 = n < RW ? 0 : H + TH;
+                if (n < 2 * BS * RW) {
+                    const int band = n / RW;
+                    lx = n - band * RW;
+                    ly0 = band < BS ? band * RPT : H + TH + (band - BS) * RPT;
                 } else {
-                    const int m = n - 2 * RW;
+                    const int m = n - 2 * BS * RW;
                     const int seg = m / (2 * H), cc = m - seg * (2 * H);
                     lx = cc < H ? cc : TW + cc;
-                    ly0 = H + 8 * seg;
+                    ly0 = H + RPT * seg;
                 }
-                float tu[8], tv[8];
+                float tu[RPT], tv[RPT];
                 march(lx, ly0, tu, tv);
             }
         } else {
@@ -394,7 +399,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             {
                 const int c = tid & (TW - 1), grp = tid / TW;
 #pragma unroll
-                for (int j = 0; j < 8; j++) do_px(H + 8 * grp + j, H + c, base_u[j], base_v[j]);
+                for (int j = 0; j < RPT; j++) do_px(H + RPT * grp + j, H + c, base_u[j], base_v[j]);
             }
             constexpr int NHALO = 2 * H * RW + TH * 2 * H;
             for (int n = tid; n < NHALO; n += NT) {
@@ -424,7 +429,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // Marching job: gradient column qx, a run of gradient rows.  Row pass of the Sobel
             // pair (tx = right - left, ty = [s,2s,s]) is computed once per image row and kept in
             // a 3-row register window; the column pass finishes one output per step.
-            constexpr int SEG = 16, NSEG = (GH + SEG - 1) / SEG;
+            constexpr int SEG = NT >= 512 ? 8 : 16, NSEG = (GH + SEG - 1) / SEG;
             for (int n = tid; n < GW * NSEG; n += NT) {
                 const int seg = n / GW, qx = n - seg * GW;
                 const int q0 = seg * SEG, q1 = q0 + SEG < GH ? q0 + SEG : GH;
@@ -510,15 +515,16 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     MICV_STAMP(3)
 
     // ---- phase 4: five window sums, two sweeps ----------------------------------------------
-    const int c = tid & (TW - 1), r0 = 8 * (tid / TW);
-    float Sxx[8], Sxy[8], Syy[8], Sxt[8], Syt[8];
+    const int c = tid & (TW - 1), r0 = RPT * (tid / TW);
+    float Sxx[RPT], Sxy[RPT], Syy[RPT], Sxt[RPT], Syt[RPT];
+    constexpr int RPI = 4 * (NT / 64);  // gradient rows one row-pass iteration covers
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int grp = lane >> 2, c0 = 4 * grp;
         // sweep A: Ix^2, Ix*Iy, Iy^2  (windows of Ix, Iy read once)
-#pragma unroll
-        for (int it = 0; it < (GH + 15) / 16; it++) {
-            const int qy = it * 16 + wave * 4 + (lane & 3);
+#pragma unroll(NT >= 512 ? 1 : 4)
+        for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
+            const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
                 float wx[4 * C::WV], wy[4 * C::WV];
                 load_window<C>(Gx, qy, c0, wx);
@@ -535,9 +541,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         col_pass<C>(rb2, Syy, g, c, r0);
         __syncthreads();
         // sweep B: Ix*It, Iy*It
-#pragma unroll
-        for (int it = 0; it < (GH + 15) / 16; it++) {
-            const int qy = it * 16 + wave * 4 + (lane & 3);
+#pragma unroll(NT >= 512 ? 1 : 4)
+        for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
+            const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
                 float wx[4 * C::WV], wy[4 * C::WV], wt[4 * C::WV];
                 load_window<C>(Gx, qy, c0, wx);
@@ -560,7 +566,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     const int gx = x0 + c;
     if (INT || gx < cols) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < RPT; j++) {
             const int gy = y0 + r0 + j;
             if (gy >= a.row_begin && gy < a.row_end) {
                 float uu, vv;
@@ -578,9 +584,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
 #undef MICV_STAMP
 }
 
-template <int R, int MODE>
-__global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
-    using C = LkCfg<R>;
+template <int R, int MODE, int NTV>
+__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+    using C = LkCfg<R, NTV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
     // and b+8 share an L2.  Give each XCD a contiguous run of row-major tiles, so neighbouring
@@ -596,16 +602,16 @@ __global__ __launch_bounds__(256, 2) void lk_level_kernel(LkLevelArgs a, TapsN<2
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
     if (interior)
-        lk_tile<R, MODE, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, true, NTV>(a, g, lds, tile_x, tile_y, blockIdx.y);
     else
-        lk_tile<R, MODE, false>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, false, NTV>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
 bool lk_fused_supports(int win) { return win == 15 || win == 7 || win == 21 || win == 11; }
 
-template <int R>
+template <int R, int NTV>
 static int launch_r(hipStream_t s, const LkLevelArgs &a) {
-    using C = LkCfg<R>;
+    using C = LkCfg<R, NTV>;
     static TapsN<2 * R + 1> taps;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -619,13 +625,13 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         int dev = 0;
         MICV_HIP(hipGetDevice(&dev));
         if (done_dev != dev) {
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0, NTV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1, NTV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2, NTV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
             done_dev = dev;
@@ -639,7 +645,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
     switch (a.mode) {
         case LK_FLOW_NONE:
-            lk_level_kernel<R, 0><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 0, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
             break;
         case LK_FLOW_COARSE:
             if (a.rows != 2 * a.flow_rows || a.cols != 2 * a.flow_cols) {
@@ -647,10 +653,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
                           a.flow_cols, a.rows, a.cols);
                 return MICV_EINVAL;
             }
-            lk_level_kernel<R, 1><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 1, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
             break;
         case LK_FLOW_FULL:
-            lk_level_kernel<R, 2><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 2, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
             break;
         default:
             set_error("lk fused: bad mode %d", a.mode);
@@ -662,10 +668,16 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
 
 int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a) {
     switch (a.win) {
-        case 15: return launch_r<7>(s, a);
-        case 7: return launch_r<3>(s, a);
-        case 21: return launch_r<10>(s, a);  // the reference's default winSize (OpticalFlow.h:9,18)
-        case 11: return launch_r<5>(s, a);
+        case 15: {
+            // 512 threads per tile (4 waves per SIMD at 2 workgroups per CU) vs 256 (2 waves per SIMD)
+            // Measured on MI355X (8 pairs of 1080p): 512 threads 0.377 ms per level-0 launch vs 0.406 ms,
+            // and the latency-bound coarse levels gain more.  MICV_LK_NT=256 selects the narrow form.
+            static const bool wide = [] { const char *e = getenv("MICV_LK_NT"); return !(e && atoi(e) == 256); }();
+            return wide ? launch_r<7, 512>(s, a) : launch_r<7, 256>(s, a);
+        }
+        case 7: return launch_r<3, 256>(s, a);
+        case 21: return launch_r<10, 256>(s, a);  // the reference's default winSize (OpticalFlow.h:9,18)
+        case 11: return launch_r<5, 256>(s, a);
         default:
             set_error("lk fused: window %d has no tiled instantiation", a.win);
             return MICV_EUNSUPPORTED;
