@@ -158,12 +158,14 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     const float *__restrict__ next = a.next + pair * a.img_pair;
     const int istride = a.img_stride;
     const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};  // Pyramids.cu:19
+    // wave-uniform on purpose: the running stamp then lives in SGPRs, not in a (spilled) VGPR pair
+    const bool stamp_wave = a.stamps != nullptr && __builtin_amdgcn_readfirstlane(tid) < 64;
     unsigned long long t_prev = 0;
-    if (a.stamps && tid == 0) t_prev = __builtin_amdgcn_s_memtime();
+    if (stamp_wave) t_prev = __builtin_amdgcn_s_memtime();
 #define MICV_STAMP(k)                                                        \
-    if (a.stamps && tid == 0) {                                              \
+    if (stamp_wave) {                                                        \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();       \
-        atomicAdd(&a.stamps[(k) + (INT ? 0 : 8)], t_now - t_prev);           \
+        if (tid == 0) atomicAdd(&a.stamps[(k) + (INT ? 0 : 8)], t_now - t_prev); \
         t_prev = t_now;                                                      \
     }
 
@@ -545,13 +547,15 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
             const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
-                float wx[4 * C::WV], wy[4 * C::WV], wt[4 * C::WV];
+                float wx[4 * C::WV], wt[4 * C::WV];
                 load_window<C>(Gx, qy, c0, wx);
-                load_window<C>(Gy, qy, c0, wy);
                 load_window<C>(Gt, qy, c0, wt);
                 const int o = rb_off(qy, grp);
                 row_taps<C>(wx, wt, g, rb0 + o);
-                row_taps<C>(wy, wt, g, rb1 + o);
+                // 128-VGPR budget at 512 threads: the Iy window reuses the Ix window's registers
+                if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
+                load_window<C>(Gy, qy, c0, wx);
+                row_taps<C>(wx, wt, g, rb1 + o);
             }
         }
         __syncthreads();

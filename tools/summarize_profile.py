@@ -71,7 +71,7 @@ for (k, g), d in sorted(pmc.items(), key=lambda kv: -kv[0][1]):
         print(f"      {c:26s} {v[0] / max(v[1], 1):18.1f}  (n={v[1]})")
 res["pmc_mean_per_dispatch"] = summ
 
-lvl0 = [kg for kg in pmc if "lk_level_kernel<7, 1>" in kg[0]]
+lvl0 = [kg for kg in pmc if "lk_level_kernel<7, 1" in kg[0]]
 if lvl0:
     kg = max(lvl0, key=lambda t: t[1])
     d = pmc[kg]
