@@ -236,6 +236,16 @@ int micv_hough_circles_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int col
                            unsigned radius, int32_t *acc, micv_stream stream);
 int micv_hough_circles_host(micv_ctx *ctx, const uint8_t *mask, int rows, int cols,
                             size_t mstride, unsigned radius, int32_t *acc);
+/* Row-sharded forms: `mask` points at row `row0` of a `rows`-row image and holds
+ * `band_rows` rows; votes of those edge points go into a full-size (zeroed here) accumulator.
+ * Integer sums of the per-shard accumulators (RCCL all-reduce) equal the unsharded accumulator
+ * bit for bit.  The unsharded entry points are these with row0 = 0, band_rows = rows. */
+int micv_hough_lines_band_dev(micv_ctx *ctx, const uint8_t *mask, int band_rows, int cols,
+                              size_t mstride, int row0, int rows, unsigned rho_bin,
+                              unsigned theta_bin, int32_t *acc, micv_stream stream);
+int micv_hough_circles_band_dev(micv_ctx *ctx, const uint8_t *mask, int band_rows, int cols,
+                                size_t mstride, int row0, int rows, unsigned radius, int32_t *acc,
+                                micv_stream stream);
 /* cuda::findLocalMaxima, Hough.cu:366-426 (a16): peaks_rc receives up to num_peaks (row,col)
  * pairs ordered by votes descending (stable); *count = number written. */
 int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,

@@ -96,6 +96,8 @@ SIGNATURES = {
     "micv_hough_lines_host": (i32, [vp, vp, i32, i32, sz, u32, u32, vp]),
     "micv_hough_circles_dev": (i32, [vp, vp, i32, i32, sz, u32, vp, vp]),
     "micv_hough_circles_host": (i32, [vp, vp, i32, i32, sz, u32, vp]),
+    "micv_hough_lines_band_dev": (i32, [vp, vp, i32, i32, sz, i32, i32, u32, u32, vp, vp]),
+    "micv_hough_circles_band_dev": (i32, [vp, vp, i32, i32, sz, i32, i32, u32, vp, vp]),
     "micv_hough_peaks_dev": (i32, [vp, vp, i32, i32, u32, i32, vp, vp, vp]),
     "micv_hough_peaks_host": (i32, [vp, vp, i32, i32, u32, i32, vp, vp]),
     # ps1 edge front-end

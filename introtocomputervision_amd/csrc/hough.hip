@@ -45,7 +45,8 @@ static TrigTable make_trig(int theta0) {
 // grid (theta bins, chunks); dynamic LDS = rho_bins ints.
 __global__ __launch_bounds__(256) void hough_lines_kernel(const int32_t *__restrict__ pts,
                                                            const int64_t *__restrict__ npts_p,
-                                                           int cols, const float *__restrict__ ct,
+                                                           int cols, int row0,
+                                                           const float *__restrict__ ct,
                                                            const float *__restrict__ st,
                                                            float diag, unsigned rho_bin,
                                                            unsigned theta_bin, int rho_bins,
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void hough_lines_kernel(const int32_t *__restr
     const int64_t lo = blockIdx.y * per, hi = lo + per < npts ? lo + per : npts;
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
         const int32_t p = pts[i];
-        const int y = p / cols, x = p - y * cols;
+        const int yl = p / cols, x = p - yl * cols, y = yl + row0;
         const float rho = roundf((float)x * c + (float)y * s) + diag;  // :54
         const int rhoBin = (int)roundf(rho / (float)rho_bin);            // :55
         if ((unsigned)rhoBin < (unsigned)rho_bins) atomicAdd(&hist[rhoBin], 1);
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void hough_lines_kernel(const int32_t *__restr
 
 // Fallback for accumulators whose rho axis does not fit LDS: global atomics per vote.
 __global__ __launch_bounds__(256) void hough_lines_global_kernel(
-    const int32_t *__restrict__ pts, const int64_t *__restrict__ npts_p, int cols,
+    const int32_t *__restrict__ pts, const int64_t *__restrict__ npts_p, int cols, int row0,
     const float *__restrict__ ct, const float *__restrict__ st, float diag, unsigned rho_bin,
     unsigned theta_bin, int rho_bins, int theta_bins, int32_t *__restrict__ acc) {
     const int64_t npts = *npts_p;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void hough_lines_global_kernel(
     if ((unsigned)thetaBin >= (unsigned)theta_bins) return;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < npts; i += (int64_t)gridDim.x * 256) {
         const int32_t p = pts[i];
-        const int y = p / cols, x = p - y * cols;
+        const int yl = p / cols, x = p - yl * cols, y = yl + row0;
         const float rho = roundf((float)x * c + (float)y * s) + diag;
         const int rhoBin = (int)roundf(rho / (float)rho_bin);
         if ((unsigned)rhoBin < (unsigned)rho_bins)
@@ -107,7 +108,7 @@ __device__ __forceinline__ unsigned f2u_sat(float v) {
 // One thread per (point, theta); Hough.cu:85-93.
 __global__ __launch_bounds__(256) void hough_circles_kernel(const int32_t *__restrict__ pts,
                                                              const int64_t *__restrict__ npts_p,
-                                                             int rows, int cols,
+                                                             int rows, int cols, int row0,
                                                              const float *__restrict__ ct,
                                                              const float *__restrict__ st,
                                                              float radius,
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void hough_circles_kernel(const int32_t *__res
         const int64_t i = w / 360;
         const int t = (int)(w - i * 360);
         const int32_t p = pts[i];
-        const int y = p / cols, x = p - y * cols;
+        const int yl = p / cols, x = p - yl * cols, y = yl + row0;
         const unsigned a = f2u_sat((float)x - radius * ct[t]);
         const unsigned b = f2u_sat((float)y - radius * st[t]);
         if (a < (unsigned)cols && b < (unsigned)rows && a > 0 && b > 0)
@@ -235,8 +236,17 @@ static int hough_points(micv_ctx *ctx, hipStream_t s, const uint8_t *mask, int r
 
 int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
                          unsigned rho_bin, unsigned theta_bin, int32_t *acc, micv_stream stream) {
+    return micv_hough_lines_band_dev(ctx, mask, rows, cols, mstride, 0, rows, rho_bin, theta_bin, acc,
+                                     stream);
+}
+
+int micv_hough_lines_band_dev(micv_ctx *ctx, const uint8_t *mask, int band_rows, int cols,
+                              size_t mstride, int row0, int rows, unsigned rho_bin,
+                              unsigned theta_bin, int32_t *acc, micv_stream stream) {
     MICV_REQUIRE(ctx && mask && acc, "micv_hough_lines: null argument");
     MICV_REQUIRE(mstride >= (size_t)cols, "micv_hough_lines: bad stride");
+    MICV_REQUIRE(band_rows > 0 && row0 >= 0 && row0 + band_rows <= rows,
+                 "micv_hough_lines: band [%d, %d) outside the %d-row image", row0, row0 + band_rows, rows);
     int rb, tb;
     MICV_TRY(micv_hough_lines_dims(rows, cols, rho_bin, theta_bin, &rb, &tb));
     MICV_HIP(hipSetDevice(ctx->device));
@@ -244,7 +254,7 @@ int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols,
     int32_t *pts;
     int64_t *npts;
     char *extra;
-    MICV_TRY(hough_points(ctx, s, mask, rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
+    MICV_TRY(hough_points(ctx, s, mask, band_rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
     TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
     static const TrigTable ht = make_trig(-90);  // thread-safe one-time initialisation
     MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
@@ -254,10 +264,10 @@ int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols,
     const int n_theta = (int)((180 + theta_bin - 1) / theta_bin);
     if ((size_t)rb * 4 <= 64 * 1024) {
         hough_lines_kernel<<<dim3(n_theta, 16), 256, (size_t)rb * 4, s>>>(
-            pts, npts, cols, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
+            pts, npts, cols, row0, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
     } else {
         hough_lines_global_kernel<<<dim3(64, n_theta), 256, 0, s>>>(
-            pts, npts, cols, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
+            pts, npts, cols, row0, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
     }
     MICV_LAUNCH_CHECK();
     return MICV_OK;
@@ -265,7 +275,15 @@ int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols,
 
 int micv_hough_circles_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
                            unsigned radius, int32_t *acc, micv_stream stream) {
+    return micv_hough_circles_band_dev(ctx, mask, rows, cols, mstride, 0, rows, radius, acc, stream);
+}
+
+int micv_hough_circles_band_dev(micv_ctx *ctx, const uint8_t *mask, int band_rows, int cols,
+                                size_t mstride, int row0, int rows, unsigned radius, int32_t *acc,
+                                micv_stream stream) {
     MICV_REQUIRE(ctx && mask && acc, "micv_hough_circles: null argument");
+    MICV_REQUIRE(band_rows > 0 && row0 >= 0 && row0 + band_rows <= rows,
+                 "micv_hough_circles: band [%d, %d) outside the %d-row image", row0, row0 + band_rows, rows);
     MICV_REQUIRE(rows > 0 && cols > 0 && rows <= 32767 && cols <= 32767,
                  "micv_hough_circles: bad size %dx%d", rows, cols);
     MICV_REQUIRE(mstride >= (size_t)cols, "micv_hough_circles: bad stride");
@@ -274,12 +292,12 @@ int micv_hough_circles_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int col
     int32_t *pts;
     int64_t *npts;
     char *extra;
-    MICV_TRY(hough_points(ctx, s, mask, rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
+    MICV_TRY(hough_points(ctx, s, mask, band_rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
     TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
     static const TrigTable ht = make_trig(0);  // theta = 0..359, Hough.cu:85
     MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
     MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rows * cols * sizeof(int32_t), s));  // ref forgets, :318
-    hough_circles_kernel<<<2048, 256, 0, s>>>(pts, npts, rows, cols, dt->c, dt->s, (float)radius, acc);
+    hough_circles_kernel<<<2048, 256, 0, s>>>(pts, npts, rows, cols, row0, dt->c, dt->s, (float)radius, acc);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
