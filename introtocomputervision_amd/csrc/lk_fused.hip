@@ -31,6 +31,7 @@
 
 namespace micv {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void glb_cvoid;
 
@@ -84,10 +85,14 @@ __device__ __forceinline__ int rb_off(int q, int chunk) { return q * 64 + 4 * (c
 template <typename C>
 __device__ __forceinline__ void load_window(const float *__restrict__ A, int qy, int c0,
                                             float (&w)[4 * C::WV]) {
-    const float4 *a4 = reinterpret_cast<const float4 *>(A + qy * C::GS + c0);
+    // Native vector type on purpose: HIP's float4 is a struct, its copy decays into scalar loads
+    // that the SLP vectoriser re-pairs as <2 x float> align 4 -> ds_read2_b64, whose 32-bank,
+    // 16-contiguous-lane banking makes this access pattern 2-way conflicted (measured: 52 M of the
+    // launch's 57 M LDS conflict cycles).  <4 x float> align 16 -> ds_read_b128, conflict-free here.
+    const v4f *a4 = reinterpret_cast<const v4f *>(A + qy * C::GS + c0);
 #pragma unroll
     for (int i = 0; i < C::WV; i++) {
-        const float4 v = a4[i];
+        const v4f v = a4[i];
         w[4 * i + 0] = v.x;
         w[4 * i + 1] = v.y;
         w[4 * i + 2] = v.z;
@@ -167,7 +172,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();       \
         if (tid == 0) atomicAdd(&a.stamps[(k) + (INT ? 0 : 8)], t_now - t_prev); \
         t_prev = t_now;                                                      \
-    }
+    }                                                                        \
+    if (a.stop_after == (k)) return;
 
     // ---- phase 0: stage prev (+ next / its window) and the coarse flow block -----------------
     // Interior tiles issue ALL their global loads into registers first and write LDS afterwards,
@@ -538,10 +544,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             }
         }
         __syncthreads();
+        if (a.stop_after == 41) return;
         col_pass<C>(rb0, Sxx, g, c, r0);
         col_pass<C>(rb1, Sxy, g, c, r0);
         col_pass<C>(rb2, Syy, g, c, r0);
         __syncthreads();
+        if (a.stop_after == 42) return;
         // sweep B: Ix*It, Iy*It
 #pragma unroll(NT >= 512 ? 1 : 4)
         for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
@@ -559,6 +567,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             }
         }
         __syncthreads();
+        if (a.stop_after == 43) return;
         col_pass<C>(rb0, Sxt, g, c, r0);
         col_pass<C>(rb1, Syt, g, c, r0);
     }
@@ -670,7 +679,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     return MICV_OK;
 }
 
-int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a) {
+int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
+    static const int stop = [] { const char *e = getenv("MICV_LK_STOP"); return e ? atoi(e) : -1; }();
+    LkLevelArgs a = a_in;
+    a.stop_after = stop;
     switch (a.win) {
         case 15: {
             // 512 threads per tile (4 waves per SIMD at 2 workgroups per CU) vs 256 (2 waves per SIMD)

@@ -28,6 +28,9 @@ struct LkLevelArgs {
     // Diagnostic only (micv_profile_lk_phases): when non-null, wave 0 of every workgroup adds the
     // s_memtime ticks it spent in each phase to stamps[phase].  Null in normal runs.
     unsigned long long *stamps = nullptr;
+    // Diagnostics (env MICV_LK_STOP=k): leave the kernel after phase k, so PMC counters can be
+    // attributed to phases by differencing runs.  Results are garbage; -1 in normal runs.
+    int stop_after = -1;
 };
 
 bool lk_fused_supports(int win);
