@@ -6,14 +6,17 @@
 // with clamp-to-edge addressing of both images, every d in [minD, maxD] evaluated in ascending
 // order, strict compare (lowest d wins ties).
 //
-// Kernel shape: one wave64 owns a strip of 64 window-columns x 8 output rows.  A lane walks
-// down its column keeping the last 2r+1 per-pixel terms in registers (fully unrolled, so the
-// ring is static), re-adds them in the contract's order for every output row, and the
-// horizontal sum runs as a systolic chain of v_add_f32 with a DPP wave_shr:1 operand:
-//   acc <- shift_right_one_lane(acc) + colsum     (2r steps)
-// which is exactly the left -> right association and needs no LDS at all.  Running best
-// cost / disparity live in registers; nothing but the two images is read and only the int8
-// disparity is written (9 B/px algorithmic).
+// Kernel shape: one wave64 owns a strip of 64 window-columns x 8 (or 10) output rows.  The strip of
+// `right` that a chunk of 64 disparities slides over (128 columns x the strip's rows) is staged
+// once per chunk in wave-private LDS -- the disparity loop then reads it at lane + (d - d0):
+// consecutive lanes, conflict-free, no global load in the loop.  A lane walks down its column
+// keeping the last 2r+1 per-pixel terms in registers (fully unrolled, so the ring is static),
+// re-adds them in the contract's order for every output row, and the horizontal sum runs as a
+// systolic chain of v_add_f32 with a DPP wave_shr:1 operand:
+//   acc <- shift_right_one_lane(acc) + colsum     (2r steps, unrolled, rows interleaved)
+// which is exactly the left -> right association.  Running best cost / disparity live in
+// registers; only the int8 disparity is written (9 B/px algorithmic).  VALU-bound: ~220 VALU
+// instructions per wave per disparity at r = 5 (C3: 0.27 ms measured vs 0.24 ms issue bound).
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -29,6 +32,18 @@ __device__ __forceinline__ int dpp_shr1(int v) {
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false);
 }
 
+// Horizontal window sum, left -> right: acc <- shift_right_one_lane(acc) + colsum, (wcols - 1)
+// times.  wcols is W or W - 1 (COLS_2R); both chains are fully unrolled so the scheduler can
+// interleave the chains of different rows (a DPP read of a just-written VGPR costs wait states).
+template <int W, typename T>
+__device__ __forceinline__ T systolic_sum(T cs, bool full) {
+    T acc = cs;
+#pragma unroll
+    for (int k = 1; k < W - 1; k++) acc = dpp_shr1(acc) + cs;
+    if (full && W > 1) acc = dpp_shr1(acc) + cs;
+    return acc;
+}
+
 struct StereoArgs {
     const float *left, *right;
     int stride, rows, cols, min_d, max_d;
@@ -38,12 +53,19 @@ struct StereoArgs {
     int dstride;
 };
 
-template <int R, int MODE>
+// LDS budget of the staged right-image strip: DCH disparities per chunk -> SPAN columns per row.
+constexpr int ST_DCH_DEFAULT = 64;
+
+template <int R, int MODE, int RPW, int ST_DCH = ST_DCH_DEFAULT>
 __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
-    constexpr int W = 2 * R + 1, RPW = 8, STEPS = RPW + 2 * R, OUTW = 64 - 2 * R;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int W = 2 * R + 1, STEPS = RPW + 2 * R, OUTW = 64 - 2 * R, ST_SPAN = 64 + ST_DCH;
+    extern __shared__ float st_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar row addressing
+    const bool full = a.wcols == W;
     const int ys = blockIdx.y * (4 * RPW) + wave * RPW;
-    if (ys >= a.rows) return;
+    if (ys >= a.rows) return;  // whole wave; waves never synchronise with each other
+    float *Rs = st_lds + wave * (STEPS * ST_SPAN);
     const int x_base = blockIdx.x * OUTW - R;
     const int xc = x_base + lane;  // window column of this lane (unclamped)
     const int xl = clampi(xc, 0, a.cols - 1);
@@ -53,12 +75,10 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
                          xo < (blockIdx.x + 1) * OUTW && xo < a.cols;
 
     float Lv[STEPS];
-    const float *rrow[STEPS];
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
         const int yy = clampi(ys - R + s, 0, a.rows - 1);
         Lv[s] = a.left[(size_t)yy * a.stride + xl];
-        rrow[s] = a.right + (size_t)yy * a.stride;
     }
 
     using acc_t = typename std::conditional<MODE == ST_SSD_SERIAL, int, float>::type;
@@ -80,9 +100,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
                 float cs = 0.f;
 #pragma unroll
                 for (int k = 0; k < W; k++) cs += ring[(s - 2 * R + k) % W];
-                float acc = cs;
-                for (int k = 1; k < a.wcols; k++) acc = dpp_shr1(acc) + cs;
-                AT[s - 2 * R] = acc;
+                AT[s - 2 * R] = systolic_sum<W>(cs, full);
             }
         }
     }
@@ -90,43 +108,62 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
     const int d_lo = MODE == ST_SSD_SERIAL ? -(xo + R) : a.min_d;
     const int d_hi = MODE == ST_SSD_SERIAL ? a.cols - 1 + R - xo : a.max_d;
 
-    for (int d = a.min_d; d <= a.max_d; d++) {
-        const int xr = clampi(xc + d, 0, a.cols - 1);
-        const bool d_ok = d >= d_lo && d <= d_hi;
-        acc_t ring[W];
-        float ringB[W];
+    for (int d0 = a.min_d; d0 <= a.max_d; d0 += ST_DCH) {
+        // Stage the strip of `right` this chunk of disparities slides over: column i of the strip
+        // is image column clamp(x_base + d0 + i) (clamp-to-edge), rows as for Lv.  Every later
+        // read is an LDS read at lane + (d - d0): consecutive lanes, conflict-free.
+        __builtin_amdgcn_wave_barrier();  // the previous chunk's reads are done (in-order LDS)
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
-            const float rv = rrow[s][xr];
-            if (MODE == ST_NCC) {
-                ring[s % W] = (acc_t)(Lv[s] * rv);
-                ringB[s % W] = rv * rv;
-            } else {
-                const float diff = Lv[s] - rv;
-                const float sq = diff * diff;
-                ring[s % W] = MODE == ST_SSD_SERIAL ? (acc_t)(int)roundf(sq) : (acc_t)sq;
+            const int yy = clampi(ys - R + s, 0, a.rows - 1);
+            const float *rr = a.right + (size_t)yy * a.stride;
+#pragma unroll
+            for (int h = 0; h < (ST_SPAN + 63) / 64; h++) {
+                const int i = lane + 64 * h;
+                if (ST_SPAN % 64 == 0 || i < ST_SPAN)
+                    Rs[s * ST_SPAN + i] = rr[clampi(x_base + d0 + i, 0, a.cols - 1)];
             }
-            if (s >= 2 * R) {
-                const int j = s - 2 * R;
-                acc_t cs = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int d1 = d0 + ST_DCH - 1 < a.max_d ? d0 + ST_DCH - 1 : a.max_d;
+        for (int d = d0; d <= d1; d++) {
+            const float *rcol = Rs + lane + (d - d0);
+            const bool d_ok = MODE != ST_SSD_SERIAL || (d >= d_lo && d <= d_hi);
+            acc_t ring[W];
+            float ringB[W];
 #pragma unroll
-                for (int k = 0; k < W; k++) cs += ring[(s - 2 * R + k) % W];
-                acc_t acc = cs;
-                for (int k = 1; k < a.wcols; k++) acc = dpp_shr1(acc) + cs;
+            for (int s = 0; s < STEPS; s++) {
+                const float rv = rcol[s * ST_SPAN];
                 if (MODE == ST_NCC) {
-                    float csb = 0.f;
+                    ring[s % W] = (acc_t)(Lv[s] * rv);
+                    ringB[s % W] = rv * rv;
+                } else {
+                    const float diff = Lv[s] - rv;
+                    const float sq = diff * diff;
+                    ring[s % W] = MODE == ST_SSD_SERIAL ? (acc_t)(int)roundf(sq) : (acc_t)sq;
+                }
+                if (s >= 2 * R) {
+                    const int j = s - 2 * R;
+                    // 0 + x == x bit for bit when x is never -0 (x = diff^2, or an int): skip that add
+                    acc_t cs = MODE == ST_NCC ? (acc_t)0 : ring[(s - 2 * R) % W];
 #pragma unroll
-                    for (int k = 0; k < W; k++) csb += ringB[(s - 2 * R + k) % W];
-                    float accb = csb;
-                    for (int k = 1; k < a.wcols; k++) accb = dpp_shr1(accb) + csb;
-                    const float nc = (float)acc / sqrtf(AT[j] * accb);  // DisparityNCorr.cu:106
-                    if (nc > (float)best[j]) {                          // :108
-                        best[j] = (acc_t)nc;
+                    for (int k = MODE == ST_NCC ? 0 : 1; k < W; k++) cs += ring[(s - 2 * R + k) % W];
+                    const acc_t acc = systolic_sum<W>(cs, full);
+                    if (MODE == ST_NCC) {
+                        float csb = 0.f;
+#pragma unroll
+                        for (int k = 0; k < W; k++) csb += ringB[(s - 2 * R + k) % W];
+                        const float accb = systolic_sum<W>(csb, full);
+                        const float nc = (float)acc / sqrtf(AT[j] * accb);  // DisparityNCorr.cu:106
+                        if (nc > (float)best[j]) {                          // :108
+                            best[j] = (acc_t)nc;
+                            bestd[j] = d;
+                        }
+                    } else if (d_ok && acc < best[j]) {  // DisparitySSD.cu:88 / .cpp:54
+                        best[j] = acc;
                         bestd[j] = d;
                     }
-                } else if (d_ok && acc < best[j]) {  // DisparitySSD.cu:88 / .cpp:54
-                    best[j] = acc;
-                    bestd[j] = d;
                 }
             }
         }
@@ -188,9 +225,18 @@ __global__ __launch_bounds__(256) void stereo_generic_kernel(StereoArgs a, int r
 
 template <int MODE>
 static int launch_stereo(hipStream_t s, const StereoArgs &a, int r) {
+    // Rows per wave: 8, or 10 when that lets the whole grid be resident at once (4 waves/SIMD on
+    // 256 CUs = 4096 wave slots; 1080p r=5: 3888 waves instead of 4860 = one round, no tail).
+    static const int force_rpw = [] { const char *e = getenv("MICV_STEREO_RPW"); return e ? atoi(e) : 0; }();
+    const long waves8 = (long)cdiv(a.cols, 64 - 2 * (r < 1 ? 1 : r)) * cdiv(a.rows, 8);
+    const long waves10 = (long)cdiv(a.cols, 64 - 2 * (r < 1 ? 1 : r)) * cdiv(a.rows, 10);
+    const bool ten = force_rpw ? force_rpw == 10 : (waves8 > 4096 && (waves10 + 4095) / 4096 < (waves8 + 4095) / 4096);
+#define MICV_ST_LAUNCH(RR, RPW)                                                                    \
+    stereo_kernel<RR, MODE, RPW><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256,    \
+                                   4 * (RPW + 2 * RR) * (64 + ST_DCH_DEFAULT) * sizeof(float), s>>>(a)
 #define MICV_ST_CASE(RR)                                                                      \
     case RR:                                                                                  \
-        stereo_kernel<RR, MODE><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 32)), 256, 0, s>>>(a); \
+        if (ten) MICV_ST_LAUNCH(RR, 10); else MICV_ST_LAUNCH(RR, 8);                          \
         break;
     switch (r) {
         MICV_ST_CASE(1) MICV_ST_CASE(2) MICV_ST_CASE(3) MICV_ST_CASE(4) MICV_ST_CASE(5)
@@ -198,6 +244,7 @@ static int launch_stereo(hipStream_t s, const StereoArgs &a, int r) {
         default:
             stereo_generic_kernel<MODE><<<dim3(cdiv(a.cols, 64), cdiv(a.rows, 4)), 256, 0, s>>>(a, r);
     }
+#undef MICV_ST_LAUNCH
 #undef MICV_ST_CASE
     MICV_LAUNCH_CHECK();
     return MICV_OK;
