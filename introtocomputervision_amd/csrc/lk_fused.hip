@@ -310,6 +310,17 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         rv[i] = fmaf(v2, g5[4], t);
                     }
                 }
+                // FULL mode reads the (already expanded + resized) base flow from global memory:
+                // issue all the rows' loads up front, the per-row scheduling fence below would
+                // otherwise serialise them behind each row's warp
+                float fu_[RPT], fv_[RPT];
+                if (MODE == LK_FLOW_FULL) {
+#pragma unroll
+                    for (int j = 0; j < RPT; j++) {
+                        fu_[j] = a.flow_u[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
+                        fv_[j] = a.flow_v[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
+                    }
+                }
 #pragma unroll
                 for (int p = 0; p < RPT / 2; p++) {
 #pragma unroll
@@ -331,8 +342,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                             bu = au * 2.f;  // OpticalFlow.cpp:142,144
                             bv = av * 2.f;
                         } else {
-                            bu = a.flow_u[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
-                            bv = a.flow_v[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
+                            bu = fu_[j];
+                            bv = fv_[j];
                         }
                         bu8[j] = bu;
                         bv8[j] = bv;
@@ -601,17 +612,65 @@ template <int R, int MODE, int NTV>
 __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
     using C = LkCfg<R, NTV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
-    // and b+8 share an L2.  Give each XCD a contiguous run of row-major tiles, so neighbouring
-    // tiles (which share halo rows of prev / next / coarse flow) hit the same L2.  Speed only.
+    // Tile order.  (1) XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
+    // and b+8 share an L2; each XCD gets a contiguous run of row-major tiles, so neighbouring tiles
+    // (which share halo rows of prev / next / coarse flow) hit the same L2.  (2) Border tiles first:
+    // they take the bounds-checked body and run ~2x longer than interior tiles; dealt in plain
+    // row-major order the bottom image row would be the launch's tail.  Each XCD therefore runs
+    // its share of the border tiles first and then its contiguous run of interior tiles.  The
+    // interior tiles form a rectangle [ix0, ix1) x [iy0, iy1) (the predicate below is separable);
+    // the mapping is a bijection for ANY rectangle inside the grid, so a rectangle that disagreed
+    // with the predicate would cost speed only.
+    constexpr int E = C::M > 2 ? C::M : 2;
     const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int t = xcd * per + (xcd < rem ? xcd : rem) + idx;
     const int tiles_x = (a.cols + C::TW - 1) / C::TW;
-    const int tile_y = a.row_begin / C::TH + t / tiles_x, tile_x = t % tiles_x;
+    const int tiles_y = nb / tiles_x, ty_base = a.row_begin / C::TH;
+    int tile_x, tile_y;
+    {
+        constexpr int FX = C::TW + C::H + E, FY = C::TH + C::H + E;
+        int ix0 = (C::H + E + C::TW - 1) / C::TW, ix1 = a.cols >= FX ? (a.cols - FX) / C::TW + 1 : 0;
+        int iy0 = (C::H + E + C::TH - 1) / C::TH - ty_base, iy1 = (a.rows >= FY ? (a.rows - FY) / C::TH + 1 : 0) - ty_base;
+        ix1 = ix1 < tiles_x ? ix1 : tiles_x;
+        iy0 = iy0 > 0 ? iy0 : 0;
+        iy1 = iy1 < tiles_y ? iy1 : tiles_y;
+        const int iw = ix1 > ix0 ? ix1 - ix0 : 0, ih = iy1 > iy0 ? iy1 - iy0 : 0;
+        const int ni = iw * ih, nbd = nb - ni;
+        const int t_plain = xcd * per + (xcd < rem ? xcd : rem) + idx;
+        if (ni * 2 >= nb && nb >= 64) {
+            // this XCD: border tiles [b0, b1) of the border list, then interior tiles from i0 on
+            const int b0 = (int)(((long long)xcd * nbd) >> 3), b1 = (int)(((long long)(xcd + 1) * nbd) >> 3);
+            if (idx < b1 - b0) {
+                int b = b0 + idx;
+                const int n_top = iy0 * tiles_x, n_bot = (tiles_y - iy1) * tiles_x, side = tiles_x - iw;
+                if (b < n_top) {
+                    tile_y = b / tiles_x;
+                    tile_x = b - tile_y * tiles_x;
+                } else if (b < n_top + n_bot) {
+                    b -= n_top;
+                    tile_y = b / tiles_x;
+                    tile_x = b - tile_y * tiles_x;
+                    tile_y += iy1;
+                } else {
+                    b -= n_top + n_bot;
+                    const int r = b / side, c = b - r * side;
+                    tile_y = iy0 + r;
+                    tile_x = c < ix0 ? c : c + iw;
+                }
+            } else {
+                const int i = t_plain - b1;  // = interior tiles of lower XCDs + (idx - own border count)
+                const int r = i / iw;
+                tile_y = iy0 + r;
+                tile_x = ix0 + (i - r * iw);
+            }
+        } else {
+            tile_y = t_plain / tiles_x;
+            tile_x = t_plain - tile_y * tiles_x;
+        }
+        tile_y += ty_base;
+    }
     const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
     // interior: tile + halo + the staged `next` margin (>= the pyrUp support) inside the image
-    constexpr int E = C::M > 2 ? C::M : 2;
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
     if (interior)
