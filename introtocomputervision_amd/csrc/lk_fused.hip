@@ -255,12 +255,27 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 }
             }
         }
-        for (int i = tid; i < RH * RW; i += NT) {
-            const int ly = i / RW, lx = i - ly * RW;
-            const int gy = ry0 + ly, gx = rx0 + lx;
-            if (INT || ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols)) {
-                P[ly * PS + lx] = prev[(size_t)gy * istride + gx];
-                if (MODE == LK_FLOW_NONE) Wp[ly * PS + lx] = next[(size_t)gy * istride + gx];
+        // Batched, unconditional loads from clamped (always valid) addresses, stored afterwards:
+        // every load of the tile is in flight at once.  Cells outside the image receive edge
+        // replicas that nothing reads (the gradient phase reflects what it needs).
+        {
+            constexpr int NB = (RH * RW + NT - 1) / NT;
+            float rp[NB], rn[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int i = tid + k * NT < RH * RW ? tid + k * NT : RH * RW - 1;
+                const int ly = i / RW, lx = i - ly * RW;
+                const int gy = clampi(ry0 + ly, 0, rows - 1), gx = clampi(rx0 + lx, 0, cols - 1);
+                rp[k] = prev[(size_t)gy * istride + gx];
+                if (MODE == LK_FLOW_NONE) rn[k] = next[(size_t)gy * istride + gx];
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int i = tid + k * NT;
+                if (i < RH * RW) {
+                    P[i] = rp[k];
+                    if (MODE == LK_FLOW_NONE) Wp[i] = rn[k];
+                }
             }
         }
         if (STAGED) {
@@ -444,7 +459,26 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     // ---- phase 3: gradients --------------------------------------------------------------
     {
         const float s1 = 1.f / 9.f, s2 = 2.f * s1;  // OpticalFlow.cpp:19
-        if (INT) {
+        if (!INT) {
+            // BORDER_REFLECT_101 of the Sobel source: fill the one-pixel ring just outside the
+            // image (inside this region) of prev and of the warped image with the reflected
+            // values, so the marching code below serves border tiles too.  Gradient cells outside
+            // the image come out as garbage here and are overwritten by the reflected fill.
+            for (int i = tid; i < RH * RW; i += NT) {
+                const int ly = i / RW, lx = i - ly * RW;
+                const int gy = ry0 + ly, gx = rx0 + lx;
+                const bool oy = gy == -1 || gy == rows, ox = gx == -1 || gx == cols;
+                if ((oy || ox) && gy >= -1 && gy <= rows && gx >= -1 && gx <= cols) {
+                    const int sy = reflect101(gy, rows) - ry0, sx = reflect101(gx, cols) - rx0;
+                    if ((unsigned)sy < (unsigned)RH && (unsigned)sx < (unsigned)RW) {
+                        P[i] = P[sy * PS + sx];
+                        Wp[i] = Wp[sy * PS + sx];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        {
             // Marching job: gradient column qx, a run of gradient rows.  Row pass of the Sobel
             // pair (tx = right - left, ty = [s,2s,s]) is computed once per image row and kept in
             // a 3-row register window; the column pass finishes one output per step.
@@ -487,32 +521,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     }
                 }
             }
-        } else {
-            for (int i = tid; i < GH * GW; i += NT) {
-                const int qy = i / GW, qx = i - qy * GW;
-                const int gy = y0 - R + qy, gx = x0 - R + qx;
-                if ((unsigned)gy >= (unsigned)rows || (unsigned)gx >= (unsigned)cols) continue;
-                int ly[3], lx[3];
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    ly[j] = (reflect101(gy + j - 1, rows) - ry0) * PS;
-                    lx[j] = reflect101(gx + j - 1, cols) - rx0;
-                }
-                float Pn[3][3], Nn[3][3];
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        Pn[j][k] = P[ly[j] + lx[k]];
-                        Nn[j][k] = Wp[ly[j] + lx[k]];
-                    }
-                float pgx, pgy, ngx, ngy;
-                sobel3(Pn, s1, s2, pgx, pgy);
-                sobel3(Nn, s1, s2, ngx, ngy);
-                Gx[qy * GS + qx] = avg2(ngx, pgx);
-                Gy[qy * GS + qx] = avg2(ngy, pgy);
-                Gt[qy * GS + qx] = Nn[1][1] - Pn[1][1];
-            }
+        }
+        if (!INT) {
             // BORDER_REFLECT_101 of the window sums (cv::GaussianBlur default border) = the
             // product fields at reflected positions: fill the out-of-image cells once, so the
             // window sums below run the same straight-line code as interior tiles.  Cells whose
