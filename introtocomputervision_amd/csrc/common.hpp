@@ -98,6 +98,16 @@ struct micv_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[16];
     unsigned long long *stamps = nullptr;  // 16 device counters (micv_profile_lk_phases)
     int prof_pairs = 0;                    // frame pairs per profiled level launch
+    // Device blocks of the host-pointer entry points (host_api.hip), kept between calls so that a
+    // repeated call of the same shape does no hipMalloc / hipFree.  Freed with the context.
+    struct IoBlock {
+        void *p;
+        size_t bytes;
+        bool busy;
+    };
+    std::vector<IoBlock> io_cache;
+    void *io_acquire(size_t bytes);
+    void io_release(void *p);
     // Up to 3 auxiliary streams for group-parallel pyramid chains (lk.hip); fork makes them wait
     // for everything enqueued on `s` so far, join makes `s` wait for them.
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};

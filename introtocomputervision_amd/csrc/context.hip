@@ -128,6 +128,37 @@ struct micv_timer {
     hipEvent_t start, stop;
 };
 
+void *micv_ctx::io_acquire(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    IoBlock *best = nullptr;
+    for (auto &b : io_cache)
+        if (!b.busy && b.bytes >= bytes && b.bytes <= 2 * bytes && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) {
+        best->busy = true;
+        return best->p;
+    }
+    if (io_cache.size() >= 24) {  // shapes keep changing: drop what is idle
+        for (size_t i = 0; i < io_cache.size();) {
+            if (!io_cache[i].busy) {
+                (void)hipFree(io_cache[i].p);
+                io_cache.erase(io_cache.begin() + i);
+            } else {
+                i++;
+            }
+        }
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    io_cache.push_back({p, bytes, true});
+    return p;
+}
+
+void micv_ctx::io_release(void *p) {
+    for (auto &b : io_cache)
+        if (b.p == p) b.busy = false;
+}
+
 extern "C" {
 
 const char *micv_version(void) { return "micv 0.1 (gfx950)"; }
@@ -166,6 +197,7 @@ void micv_ctx_destroy(micv_ctx *ctx) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (auto &b : ctx->io_cache) (void)hipFree(b.p);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;

@@ -9,13 +9,15 @@
 namespace micv {
 
 // RAII device allocation; `ok()` reports failure through set_error.
+// Device block of a host-pointer call, taken from the context's cache (no hipMalloc / hipFree on a
+// repeated call of the same shape).  `io_ctx` is set by HOST_PROLOGUE.
+static thread_local micv_ctx *io_ctx = nullptr;
 struct DevBuf {
     void *p = nullptr;
-    explicit DevBuf(size_t bytes) {
-        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) p = nullptr;
-    }
+    micv_ctx *owner;
+    explicit DevBuf(size_t bytes) : owner(io_ctx) { p = owner ? owner->io_acquire(bytes) : nullptr; }
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p) owner->io_release(p);
     }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -51,6 +53,7 @@ using namespace micv;
 #define HOST_PROLOGUE(fn)                                    \
     MICV_REQUIRE(ctx != nullptr, fn ": ctx is null");        \
     MICV_HIP(hipSetDevice(ctx->device));                     \
+    ::micv::io_ctx = ctx;                                    \
     hipStream_t s = nullptr
 
 extern "C" {

@@ -618,25 +618,22 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
 #undef MICV_STAMP
 }
 
-template <int R, int MODE, int NTV>
-__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
-    using C = LkCfg<R, NTV>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // Tile order.  (1) XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
-    // and b+8 share an L2; each XCD gets a contiguous run of row-major tiles, so neighbouring tiles
-    // (which share halo rows of prev / next / coarse flow) hit the same L2.  (2) Border tiles first:
-    // they take the bounds-checked body and run ~2x longer than interior tiles; dealt in plain
-    // row-major order the bottom image row would be the launch's tail.  Each XCD therefore runs
-    // its share of the border tiles first and then its contiguous run of interior tiles.  The
-    // interior tiles form a rectangle [ix0, ix1) x [iy0, iy1) (the predicate below is separable);
-    // the mapping is a bijection for ANY rectangle inside the grid, so a rectangle that disagreed
-    // with the predicate would cost speed only.
+// Workgroup -> tile order.  (1) XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
+// and b+8 share an L2; each XCD gets a contiguous run of row-major tiles, so neighbouring tiles
+// (which share halo rows of prev / next / coarse flow) hit the same L2.  (2) Border tiles first:
+// they take the bounds-checked body and run ~2x longer than interior tiles; dealt in plain
+// row-major order the bottom image row would be the launch's tail.  Each XCD therefore runs
+// its share of the border tiles first and then its contiguous run of interior tiles.  The
+// interior tiles form a rectangle [ix0, ix1) x [iy0, iy1) (the predicate below is separable);
+// the mapping is a bijection for ANY rectangle inside the grid, so a rectangle that disagreed
+// with the predicate would cost speed only.
+template <typename C>
+__device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &tile_x, int &tile_y) {
     constexpr int E = C::M > 2 ? C::M : 2;
     const int nb = gridDim.x, per = nb >> 3, rem = nb & 7;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int xcd = bidx & 7, idx = bidx >> 3;
     const int tiles_x = (a.cols + C::TW - 1) / C::TW;
     const int tiles_y = nb / tiles_x, ty_base = a.row_begin / C::TH;
-    int tile_x, tile_y;
     {
         constexpr int FX = C::TW + C::H + E, FY = C::TH + C::H + E;
         int ix0 = (C::H + E + C::TW - 1) / C::TW, ix1 = a.cols >= FX ? (a.cols - FX) / C::TW + 1 : 0;
@@ -679,6 +676,15 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a,
         }
         tile_y += ty_base;
     }
+}
+
+template <int R, int MODE, int NTV>
+__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+    using C = LkCfg<R, NTV>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int E = C::M > 2 ? C::M : 2;
+    int tile_x, tile_y;
+    lk_tile_of<C>(a, blockIdx.x, tile_x, tile_y);
     const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
     // interior: tile + halo + the staged `next` margin (>= the pyrUp support) inside the image
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&

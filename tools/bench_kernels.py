@@ -83,3 +83,24 @@ ms = timeit(lambda: lk.calcOpticalFlow(P, N, 43, ctx=ctx), iters=5)
 line("lk::calcOpticalFlow 1080p win 43 (generic path)", ms, 1080 * 1920, 16)
 ms = timeit(lambda: pyr.makeGaussianPyramid(P, 5, ctx=ctx))
 line("makeGaussianPyramid 1080p 5 levels", ms, 1080 * 1920, 4 + 4 * 0.333 + 4)
+
+# Host-pointer flavours (the cv::Mat shim's path): wall clock including H2D / D2H over PCIe.
+import time
+
+
+def wall(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t0) * 1e3 / iters
+
+
+ms = wall(lambda: lk.calcOpticalFlowPyr(prev, nxt, 15, 5, ctx=ctx))
+line("HOST lk::calcOpticalFlowPyr 1080p 5 levels win 15 (33 MB over PCIe)", ms, 1080 * 1920, 32)
+ms = wall(lambda: stereo.disparitySSD(left, right, 5, -127, 0, ctx=ctx))
+line("HOST stereo SSD 1080p r=5 d=128", ms, 1080 * 1920, 9)
+img480 = synth.checkerboard(480, 640, 40, seed=1)
+ms = wall(lambda: harris.getGradients(img480, 3, ctx=ctx))
+line("HOST sobel3 pair 640x480", ms, 480 * 640, 12)
