@@ -67,6 +67,107 @@ int launch_filter_cols(hipStream_t s, const float *src, int sstride, size_t sfie
     return MICV_OK;
 }
 
+// ---- fused Sobel pair, ksize 3 / 5 / 7 --------------------------------------------------------
+// One pass over HBM (read the image once, write gx and gy: 12 B/px) instead of the four generic
+// launches with two temporaries.  64x32 output tile per 256-thread workgroup: the source tile
+// (+K/2 halo, BORDER_REFLECT_101 resolved while loading, every load in flight at once) goes to
+// LDS, the row pass of both filters reads it once and keeps both results in LDS, the column
+// pass finishes 8 rows per thread.  Each pass is the same fmaf chain from +0 as the generic
+// kernels above, with the float row-pass result as the intermediate: identical bits.
+template <int K>
+struct SobelTaps {
+    float row_dx[K], col_dx[K], row_dy[K], col_dy[K];
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void sobel_fused_kernel(const float *__restrict__ src, int sstride,
+                                                           int rows, int cols, SobelTaps<K> t,
+                                                           float *__restrict__ gx,
+                                                           float *__restrict__ gy, int gstride) {
+    constexpr int A = K / 2, TW = 64, TH = 32, RW = TW + 2 * A, RH = TH + 2 * A;
+    constexpr int SS = RW | 1;  // odd pitch: the column-strided staging stores spread over banks
+    __shared__ float S[RH * SS];
+    __shared__ float DX[RH * TW], DY[RH * TW];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    {
+        constexpr int NB = (RH * RW + 255) / 256;
+        float v[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * 256 < RH * RW ? threadIdx.x + k * 256 : RH * RW - 1;
+            const int ly = i / RW, lx = i - ly * RW;
+            const int yy = reflect101(y0 - A + ly, rows), xx = reflect101(x0 - A + lx, cols);
+            v[k] = src[(size_t)yy * sstride + xx];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * 256;
+            if (i < RH * RW) {
+                const int ly = i / RW, lx = i - ly * RW;
+                S[ly * SS + lx] = v[k];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RH * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        const float *sp = S + r * SS + c;
+        float ax = 0.f, ay = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const float v = sp[k];
+            ax = fmaf(v, t.row_dx[k], ax);
+            ay = fmaf(v, t.row_dy[k], ay);
+        }
+        DX[i] = ax;
+        DY[i] = ay;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, x = x0 + c;
+    if (x >= cols) return;
+    const int rb = (threadIdx.x >> 6) * (TH / 4);
+    // marching register window over the column: K + 7 reads per plane for 8 outputs
+    float wx[K + TH / 4 - 1], wy[K + TH / 4 - 1];
+#pragma unroll
+    for (int k = 0; k < K + TH / 4 - 1; k++) {
+        wx[k] = DX[(rb + k) * TW + c];
+        wy[k] = DY[(rb + k) * TW + c];
+    }
+#pragma unroll
+    for (int j = 0; j < TH / 4; j++) {
+        const int y = y0 + rb + j;
+        if (y >= rows) break;
+        float ax = 0.f, ay = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            ax = fmaf(wx[j + k], t.col_dx[k], ax);
+            ay = fmaf(wy[j + k], t.col_dy[k], ay);
+        }
+        gx[(size_t)y * gstride + x] = ax;
+        gy[(size_t)y * gstride + x] = ay;
+    }
+}
+
+template <int K>
+static int launch_sobel_fused(hipStream_t s, const float *src, int rows, int cols, int sstride,
+                              float scale, float *gx, float *gy, int gstride) {
+    Taps d, m;
+    sobel_taps(K, 1, &d);
+    sobel_taps(K, 0, &m);
+    SobelTaps<K> t;
+    for (int i = 0; i < K; i++) {
+        // d/dx: row kernel = derivative, column kernel = smoothing * scale;  d/dy: the transpose
+        t.row_dx[i] = d.k[i];
+        t.col_dx[i] = scale != 1.f ? m.k[i] * scale : m.k[i];
+        t.row_dy[i] = scale != 1.f ? m.k[i] * scale : m.k[i];
+        t.col_dy[i] = d.k[i];
+    }
+    sobel_fused_kernel<K><<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 256, 0, s>>>(src, sstride, rows, cols, t,
+                                                                            gx, gy, gstride);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
 // cv::cuda::createSobelFilter: `if (dx == 0) kx *= scale; else ky *= scale;` then a
 // separable filter, row kernel kx, column kernel ky.
 int sobel_dev(hipStream_t s, const float *src, int rows, int cols, int sstride, int ksize,
@@ -77,6 +178,12 @@ int sobel_dev(hipStream_t s, const float *src, int rows, int cols, int sstride, 
     if (sobel_taps(ksize, 1, &kx) < 0 || sobel_taps(ksize, 0, &ky) < 0) {
         set_error("sobel: kernel size %d not supported (1,3,5,7..31 odd)", ksize);
         return MICV_EINVAL;
+    }
+    static const bool force_generic = getenv("MICV_SOBEL_GENERIC") != nullptr;
+    if (!force_generic) {
+        if (ksize == 3) return launch_sobel_fused<3>(s, src, rows, cols, sstride, scale, gx, gy, gstride);
+        if (ksize == 5) return launch_sobel_fused<5>(s, src, rows, cols, sstride, scale, gx, gy, gstride);
+        if (ksize == 7) return launch_sobel_fused<7>(s, src, rows, cols, sstride, scale, gx, gy, gstride);
     }
     if (scale != 1.f)
         for (int i = 0; i < ky.n; i++) ky.k[i] *= scale;

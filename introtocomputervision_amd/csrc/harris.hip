@@ -50,6 +50,105 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float *__res
     }
 }
 
+// Windows 3 / 5 / 7 (the configuration uses 5): the three product fields Ix^2, IxIy, Iy^2 are
+// formed ONCE per staged cell (not once per tap) and kept in LDS; a thread owns 4 adjacent outputs
+// of one row and reads its (4 + 2r)-wide windows with ds_read_b128 (pitch 80 floats and the
+// lane -> (row = lane & 3, group = lane >> 2) mapping make them conflict-free); the weight table
+// w[wy][wx] = g[wy]*g[wx] (float product, as above) arrives in SGPRs.  Every accumulator is still
+// the (wy, wx)-raster fmaf chain of Harris.cu:36-43, so the bits do not change.
+template <int R>
+struct HarrisW {
+    float w[(2 * R + 1) * (2 * R + 1)];
+};
+typedef float hv4f __attribute__((ext_vector_type(4)));
+
+template <int R>
+__global__ __launch_bounds__(256) void harris_response_tiled_kernel(
+    const float *__restrict__ gx, const float *__restrict__ gy, int gstride, int rows, int cols,
+    HarrisW<R> hw, float alpha, float *__restrict__ resp, int rstride) {
+    constexpr int W = 2 * R + 1, TW = 64, TH = 16, RW = TW + 2 * R, RH = TH + 2 * R, PS = 80;
+    constexpr int NV = (4 + 2 * R + 3) / 4;
+    static_assert(60 + 4 * NV <= PS, "window reads stay inside a plane row");
+    __shared__ __attribute__((aligned(16))) float XX[RH * PS], XY[RH * PS], YY[RH * PS];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    {
+        constexpr int NB = (RH * RW + 255) / 256;
+        float vx[NB], vy[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * 256 < RH * RW ? threadIdx.x + k * 256 : RH * RW - 1;
+            const int ly = i / RW, lx = i - ly * RW;
+            const int yy = clampi(y0 - R + ly, 0, rows - 1), xx = clampi(x0 - R + lx, 0, cols - 1);
+            vx[k] = gx[(size_t)yy * gstride + xx];
+            vy[k] = gy[(size_t)yy * gstride + xx];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * 256;
+            if (i < RH * RW) {
+                const int ly = i / RW, lx = i - ly * RW;
+                XX[ly * PS + lx] = vx[k] * vx[k];
+                XY[ly * PS + lx] = vx[k] * vy[k];
+                YY[ly * PS + lx] = vy[k] * vy[k];
+            }
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ry = 4 * wave + (lane & 3), c0 = 4 * (lane >> 2);
+    float mxx[4] = {0.f, 0.f, 0.f, 0.f}, mxy[4] = {0.f, 0.f, 0.f, 0.f}, myy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int wy = 0; wy < W; wy++) {
+        float a[4 * NV], b[4 * NV], c[4 * NV];
+        const int o = (ry + wy) * PS + c0;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const hv4f va = *reinterpret_cast<const hv4f *>(XX + o + 4 * i);
+            const hv4f vb = *reinterpret_cast<const hv4f *>(XY + o + 4 * i);
+            const hv4f vc = *reinterpret_cast<const hv4f *>(YY + o + 4 * i);
+            a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
+            b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
+            c[4 * i] = vc.x; c[4 * i + 1] = vc.y; c[4 * i + 2] = vc.z; c[4 * i + 3] = vc.w;
+        }
+#pragma unroll
+        for (int wx = 0; wx < W; wx++) {
+            const float w = hw.w[wy * W + wx];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                mxx[j] = fmaf(w, a[j + wx], mxx[j]);
+                mxy[j] = fmaf(w, b[j + wx], mxy[j]);
+                myy[j] = fmaf(w, c[j + wx], myy[j]);
+            }
+        }
+        // pin the accumulators here: the row's FMAs must finish before the next row's reads are
+        // issued (the compiler otherwise hoists all 30 reads and holds 120 window registers)
+        asm volatile("" : "+v"(mxx[0]), "+v"(mxx[1]), "+v"(mxx[2]), "+v"(mxx[3]), "+v"(mxy[0]), "+v"(mxy[1]),
+                          "+v"(mxy[2]), "+v"(mxy[3]), "+v"(myy[0]), "+v"(myy[1]), "+v"(myy[2]), "+v"(myy[3])
+                     :: "memory");
+    }
+    const int y = y0 + ry;
+    if (y >= rows) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + c0 + j;
+        if (x < cols) {
+            const float trace = mxx[j] + myy[j];
+            const float det = mxx[j] * myy[j] - mxy[j] * mxy[j];
+            resp[(size_t)y * rstride + x] = det - alpha * trace * trace;
+        }
+    }
+}
+
+template <int R>
+static void launch_harris_tiled(hipStream_t s, const float *gx, const float *gy, int gstride, int rows,
+                                int cols, const Taps &g, float alpha, float *resp, int rstride) {
+    HarrisW<R> hw;
+    for (int wy = 0; wy <= 2 * R; wy++)
+        for (int wx = 0; wx <= 2 * R; wx++) hw.w[wy * (2 * R + 1) + wx] = g.k[wy] * g.k[wx];
+    harris_response_tiled_kernel<R><<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, 0, s>>>(
+        gx, gy, gstride, rows, cols, hw, alpha, resp, rstride);
+}
+
 // ---- a10: threshold + non-maximum suppression ----------------------------------------------
 // One thread per pixel; only pixels with R >= threshold scan their (2d+1)^2 clamped window
 // (strictly greater than every OTHER pixel, Harris.cpp:119-135).  flag marks kept maxima for
@@ -81,6 +180,82 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float *__restrict
     }
     corners[(size_t)y * cstride + x] = keep ? v : 0.f;
     flag[(size_t)y * cols + x] = keep ? 1 : 0;
+}
+
+// LDS-tiled form for minDistance <= 16: "strictly greater than every other pixel of the clamped
+// window" == "equals the window maximum and that maximum occurs once".  (max, multiplicity) is
+// separable: a row pass over the staged tile, then a column pass -- 2(2d+1) steps per pixel instead
+// of (2d+1)^2 divergent global reads.  Cells outside the image are staged as NaN, which neither
+// wins a `>` nor matches a `==`, exactly like the clamped window never adding a new pixel; a NaN
+// response inside the image is ignored by its neighbours for the same reason (`v <= NaN` is false
+// in the scan above too).
+// DT > 0: minDistance known at compile time (loops unroll, the LDS reads of a window are all in
+// flight); DT == 0: any d <= 16 with rolled loops.
+template <int DT>
+__global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__restrict__ resp,
+                                                                int rstride, int rows, int cols,
+                                                                double threshold, int d_rt,
+                                                                float *__restrict__ corners,
+                                                                int cstride,
+                                                                uint8_t *__restrict__ flag) {
+    constexpr int TW = 64, TH = 16, DMAX = DT > 0 ? DT : 16;
+    const int d = DT > 0 ? DT : d_rt;
+    __shared__ float T[(TH + 2 * DMAX) * (TW + 2 * DMAX + 1)];
+    __shared__ float RM[(TH + 2 * DMAX) * TW];
+    __shared__ int RN[(TH + 2 * DMAX) * TW];
+    const int RW = TW + 2 * d, RH = TH + 2 * d, TS = RW | 1;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    // Staging: 128 lanes per region row (RW <= 96), two rows per pass of the workgroup, four
+    // passes' loads in flight at once -- no division by the runtime pitch anywhere.
+    {
+        const int lx = threadIdx.x & 127, lr = threadIdx.x >> 7;
+        const int xx = x0 - d + lx;
+        const bool col_in = (unsigned)xx < (unsigned)cols;
+        const int xc = clampi(xx, 0, cols - 1);
+        for (int rb = 0; rb < RH; rb += 8) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                v[k] = resp[(size_t)clampi(y0 - d + rb + 2 * k + lr, 0, rows - 1) * rstride + xc];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int ly = rb + 2 * k + lr, yy = y0 - d + ly;
+                if (ly < RH && lx < RW)
+                    T[ly * TS + lx] = (col_in && (unsigned)yy < (unsigned)rows) ? v[k] : __builtin_nanf("");
+            }
+        }
+    }
+    __syncthreads();
+    // row pass: window maximum (fmaxf skips NaN), then how many cells equal it
+    for (int i = threadIdx.x; i < RH * TW; i += 256) {
+        const int r = i / TW, c = i - r * TW;
+        const float *tp = T + r * TS + c;
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k <= 2 * d; k++) m = fmaxf(m, tp[k]);
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * d; k++) n += tp[k] == m ? 1 : 0;
+        RM[i] = m;
+        RN[i] = n;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63, x = x0 + c;
+    if (x >= cols) return;
+    for (int ry = threadIdx.x >> 6; ry < TH; ry += 4) {
+        const int y = y0 + ry;
+        if (y >= rows) break;
+        float M = -INFINITY;
+#pragma unroll
+        for (int k = 0; k <= 2 * d; k++) M = fmaxf(M, RM[(ry + k) * TW + c]);
+        int N = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * d; k++) N += RM[(ry + k) * TW + c] == M ? RN[(ry + k) * TW + c] : 0;
+        const float v = T[(ry + d) * TS + c + d];
+        const bool keep = (double)v >= threshold && v == M && N == 1;
+        corners[(size_t)y * cstride + x] = keep ? v : 0.f;
+        flag[(size_t)y * cols + x] = keep ? 1 : 0;
+    }
 }
 
 struct FlagPred {
@@ -146,6 +321,16 @@ int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, in
     Taps g;
     gaussian_taps(win, sigma, &g);  // cv::getGaussianKernel(win, sigma, CV_32F), Harris.cpp:61
     const int r = win / 2;
+    static const bool force_generic = getenv("MICV_HARRIS_GENERIC") != nullptr;
+    if (!force_generic && r >= 1 && r <= 3) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int gs = (int)(gstride / 4), rs = (int)(rstride / 4);
+        if (r == 1) launch_harris_tiled<1>(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
+        if (r == 2) launch_harris_tiled<2>(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
+        if (r == 3) launch_harris_tiled<3>(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     const size_t lds = (size_t)(64 + 2 * r) * (16 + 2 * r) * 2 * sizeof(float);
     static thread_local int attr_dev = -1;
     if (attr_dev != ctx->device) {
@@ -179,9 +364,30 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
     Carver c(scratch);
     uint8_t *flag = c.take<uint8_t>(n);
     int32_t *idx = c.take<int32_t>(cap);
-    harris_nms_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(
-        resp, (int)(rstride / 4), rows, cols, threshold, min_distance, corners, (int)(cstride / 4),
-        flag);
+    static const bool force_scan = getenv("MICV_NMS_SCAN") != nullptr;
+    if (min_distance <= 16 && !force_scan) {
+        const dim3 grid(cdiv(cols, 64), cdiv(rows, 16));
+#define MICV_NMS(DT)                                                                             \
+    harris_nms_tiled_kernel<DT><<<grid, 256, 0, s>>>(resp, (int)(rstride / 4), rows, cols,         \
+                                                     threshold, min_distance, corners,             \
+                                                     (int)(cstride / 4), flag)
+        switch (min_distance) {
+            case 1: MICV_NMS(1); break;
+            case 2: MICV_NMS(2); break;
+            case 3: MICV_NMS(3); break;
+            case 4: MICV_NMS(4); break;
+            case 5: MICV_NMS(5); break;
+            case 6: MICV_NMS(6); break;
+            case 7: MICV_NMS(7); break;
+            case 8: MICV_NMS(8); break;
+            default: MICV_NMS(0); break;
+        }
+#undef MICV_NMS
+    }
+    else
+        harris_nms_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(
+            resp, (int)(rstride / 4), rows, cols, threshold, min_distance, corners,
+            (int)(cstride / 4), flag);
     MICV_LAUNCH_CHECK();
     MICV_TRY(ordered_compact(s, FlagPred{flag}, n, idx, cap, count, c.base + c.off));
     if (cap > 0) {

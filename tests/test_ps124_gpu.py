@@ -78,6 +78,50 @@ def test_harris_pipeline_c1(M):
     assert np.allclose(host(ang), orc.sift_angles(egx, egy), rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("rows,cols", [(64, 64), (33, 129), (97, 61), (1, 70), (70, 1), (2, 2)])
+@pytest.mark.parametrize("ksize", [3, 5, 7])
+def test_sobel_fused_tiles_and_tiny_images(M, rows, cols, ksize):
+    """The fused 64x32-tile Sobel on sizes around / below the tile and the reflect border."""
+    harris, stereo, hough, synth = M
+    img = synth.smooth_noise(5, rows, cols)
+    for scale in (1.0, 1.0 / 9.0):
+        ex, ey = orc.sobel(img, ksize, np.float32(scale))
+        gx, gy = harris.getGradients(dev(img), ksize, np.float32(scale))
+        assert np.array_equal(host(gx), ex) and np.array_equal(host(gy), ey)
+
+
+@pytest.mark.parametrize("rows,cols", [(16, 64), (17, 65), (5, 300), (130, 3)])
+@pytest.mark.parametrize("win,sigma", [(3, 0.8), (5, 1.5), (7, 2.0), (11, 2.5)])
+def test_harris_response_tiled_and_generic(M, rows, cols, win, sigma):
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(rows * 1000 + cols)
+    gx = (rng.standard_normal((rows, cols)) * 300).astype(np.float32)
+    gy = (rng.standard_normal((rows, cols)) * 300).astype(np.float32)
+    exp = orc.harris_response(gx, gy, win, sigma, 0.04)
+    assert np.array_equal(host(harris.getCornerResponse(dev(gx), dev(gy), win, sigma, 0.04)), exp)
+
+
+@pytest.mark.parametrize("dist", [0, 1, 3, 5, 16, 17])
+def test_harris_refine_ties_nan_inf(M, dist):
+    """Quantised responses (many exact ties), -0/+0, infinities and NaNs: the tiled (max,
+    multiplicity) NMS (dist <= 16) and the scanning kernel (17) against the oracle's loop."""
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(dist + 40)
+    R = rng.integers(0, 6, (83, 150)).astype(np.float32)
+    R[rng.random(R.shape) < 0.02] = np.nan
+    R[rng.random(R.shape) < 0.01] = np.inf
+    R[rng.random(R.shape) < 0.01] = -np.inf
+    R[5, 5] = 9.0          # an isolated strict maximum
+    R[40, 70] = -0.0
+    R[0, 149] = 11.0       # corners of the image: clamped windows
+    R[82, 0] = 12.0
+    for thr in (3.0, 0.0, -np.inf):
+        ec, el = orc.harris_refine(R, thr, dist)
+        c, l = harris.refineCorners(dev(R), thr, dist)
+        assert np.array_equal(host(l), el)
+        assert np.array_equal(host(c), ec)
+
+
 @pytest.mark.parametrize("thr,dist", [(0.5, 1), (0.0, 3), (-1.0, 2), (0.9, 0)])
 def test_harris_refine_random(M, thr, dist):
     harris, stereo, hough, synth = M
