@@ -141,6 +141,12 @@ int micv_gaussian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int col
                               int levels, float *const *dst_levels, micv_stream stream);
 int micv_gaussian_pyramid_host(micv_ctx *ctx, const float *src, int rows, int cols,
                                size_t sstride, int levels, float *const *dst_levels);
+/* The Laplacian pyramid of sol::runProblem2, ps5_cpp/src/Solution.cpp:187-200 (SURVEY.md §8f row
+ * N4): L_i = G_i - resize_if_smaller(pyrUp(G_{i+1})), L_{levels-1} = G_{levels-1}; level l is
+ * (rows>>l) x (cols>>l), written densely at dst_levels[l].  Device-resident throughout. */
+int micv_laplacian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int cols,
+                               size_t sstride, int levels, float *const *dst_levels,
+                               micv_stream stream);
 /* cv::cvtColor(COLOR_RGB2GRAY) + convertTo(CV_32F) for 8-bit 3-channel input
  * (Pyramids.cpp:10-15). */
 int micv_rgb8_to_gray_f32_dev(micv_ctx *ctx, const uint8_t *rgb, int rows, int cols,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "micv_pyr_up_host": (i32, [vp, vp, i32, i32, sz, vp, sz]),
     "micv_gaussian_pyramid_dev": (i32, [vp, vp, i32, i32, sz, i32, C.POINTER(vp), vp]),
     "micv_gaussian_pyramid_host": (i32, [vp, vp, i32, i32, sz, i32, C.POINTER(vp)]),
+    "micv_laplacian_pyramid_dev": (i32, [vp, vp, i32, i32, sz, i32, C.POINTER(vp), vp]),
     "micv_rgb8_to_gray_f32_dev": (i32, [vp, vp, i32, i32, sz, vp, sz, vp]),
     "micv_resize_linear_dev": (i32, [vp, vp, i32, i32, sz, vp, i32, i32, sz, vp]),
     # ps4

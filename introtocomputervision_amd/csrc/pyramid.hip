@@ -193,6 +193,17 @@ __global__ __launch_bounds__(256) void rgb8_to_gray_kernel(const uint8_t *__rest
     dst[(size_t)y * dstride + x] = (float)g;
 }
 
+// dst = a - b (dense a, b of pitch `cols`; dst strided).
+__global__ __launch_bounds__(256) void sub_kernel(const float *__restrict__ a,
+                                                   const float *__restrict__ b,
+                                                   float *__restrict__ dst, int dstride, int rows,
+                                                   int cols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    dst[(size_t)y * dstride + x] = a[(size_t)y * cols + x] - b[(size_t)y * cols + x];
+}
+
 int launch_pyr_down(hipStream_t s, const float *src, int rows, int cols, int sstride, float *dst,
                     int dstride) {
     const int dr = rows / 2, dc = cols / 2;
@@ -314,6 +325,49 @@ int micv_gaussian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int col
     MICV_HIP(hipSetDevice(ctx->device));
     return launch_pyr_build(static_cast<hipStream_t>(stream), src, 0, (int)(sstride / 4), rows,
                             cols, levels, dst_levels, 1);
+}
+
+int micv_laplacian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int cols,
+                               size_t sstride, int levels, float *const *dst_levels,
+                               micv_stream stream) {
+    MICV_REQUIRE(ctx && src && dst_levels, "micv_laplacian_pyramid: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0, "micv_laplacian_pyramid: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(levels >= 1 && levels <= 16 && (rows >> (levels - 1)) > 0 &&
+                     (cols >> (levels - 1)) > 0,
+                 "micv_laplacian_pyramid: %d levels do not fit a %dx%d image", levels, rows, cols);
+    MICV_REQUIRE(stride_ok(sstride, cols, 4), "micv_laplacian_pyramid: bad stride");
+    for (int l = 0; l < levels; l++)
+        MICV_REQUIRE(dst_levels[l] != nullptr, "micv_laplacian_pyramid: dst_levels[%d] is null", l);
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // scratch: the Gaussian levels, the expanded image, the resized image, pyrUp's row-pass buffer
+    size_t need = 0;
+    for (int l = 0; l < levels; l++) need += Carver::need((size_t)(rows >> l) * (cols >> l), 4);
+    const size_t big = Carver::need((size_t)rows * cols, 4);
+    need += 3 * big;
+    void *scratch;
+    MICV_TRY(ctx->reserve(need, &scratch));
+    Carver c(scratch);
+    float *G[16];
+    for (int l = 0; l < levels; l++) G[l] = c.take<float>((size_t)(rows >> l) * (cols >> l));
+    float *up = c.take<float>((size_t)rows * cols), *rs = c.take<float>((size_t)rows * cols);
+    float *tmp = c.take<float>((size_t)rows * cols);
+    MICV_TRY(launch_pyr_build(s, src, 0, (int)(sstride / 4), rows, cols, levels, G, 1));
+    for (int i = 0; i + 1 < levels; i++) {
+        const int r = rows >> i, cc = cols >> i, r1 = rows >> (i + 1), c1 = cols >> (i + 1);
+        MICV_TRY(launch_pyr_up(s, G[i + 1], r1, c1, c1, up, 2 * c1, 1.f, tmp));  // Solution.cpp:191
+        const float *next = up;
+        if (2 * r1 < r || 2 * c1 < cc) {  // :194-196
+            MICV_TRY(launch_resize_linear(s, up, 2 * r1, 2 * c1, 2 * c1, rs, r, cc, cc));
+            next = rs;
+        }
+        sub_kernel<<<dim3(cdiv(cc, 64), cdiv(r, 4)), 256, 0, s>>>(G[i], next, dst_levels[i], cc, r, cc);
+        MICV_LAUNCH_CHECK();
+    }
+    const int rl = rows >> (levels - 1), cl = cols >> (levels - 1);
+    MICV_HIP(hipMemcpyAsync(dst_levels[levels - 1], G[levels - 1], (size_t)rl * cl * 4,
+                            hipMemcpyDeviceToDevice, s));  // :199
+    return MICV_OK;
 }
 
 int micv_rgb8_to_gray_f32_dev(micv_ctx *ctx, const uint8_t *rgb, int rows, int cols,

@@ -56,6 +56,20 @@ def makeGaussianPyramid(src, levels, ctx=None):
     return outs
 
 
+def makeLaplacianPyramid(src, levels, ctx=None):
+    """The Laplacian pyramid built by sol::runProblem2 (ps5_cpp/src/Solution.cpp:187-200) from a grey
+    f32 CUDA tensor -> list of levels (device tensors only)."""
+    B.check2d(src, np.float32, name="src")
+    if not B.is_dev(src):
+        raise ValueError("makeLaplacianPyramid: device tensors only")
+    rows, cols = src.shape
+    outs = [B.empty_like_shape(src, (rows >> l, cols >> l)) for l in range(levels)]
+    arr = (vp * levels)(*[B.ptr(o) for o in outs])
+    check(lib.micv_laplacian_pyramid_dev(_ctx_for(src, ctx).handle, B.ptr(src), rows, cols,
+                                         B.stride_bytes(src), int(levels), arr, B.stream_of(src)))
+    return outs
+
+
 def resizeLinear(src, drows, dcols, ctx=None):
     """cv::resize(src, dst, Size(dcols, drows)) INTER_LINEAR as used at OpticalFlow.cpp:149-150
     (device tensors only)."""

@@ -279,3 +279,23 @@ def test_every_tile_is_written_once_border_first_order(rows, cols, levels):
     from introtocomputervision_amd import lk
     bu, bv = lk.calcOpticalFlowPyrBatch(torch.stack([dp, dp]), torch.stack([dn, dn]), 15, levels, ctx=ctx)
     assert torch.equal(bu[0], u) and torch.equal(bu[1], u) and torch.equal(bv[1], v)
+
+
+@pytest.mark.parametrize("rows,cols,levels", [(128, 96, 3), (135, 241, 4), (67, 120, 1), (270, 481, 5)])
+def test_laplacian_pyramid(rows, cols, levels):
+    """ps5 runProblem2's Laplacian pyramid (Solution.cpp:187-200), composed on the oracle side from
+    its pyrDown / pyrUp / resize restatements; odd sizes take the resize branch (:194-196)."""
+    from introtocomputervision_amd import pyr
+    a = rand_img(rows, cols, 31)
+    G = orc.gaussian_pyramid(a, levels)
+    exp = []
+    for i in range(levels - 1):
+        nxt = orc.pyr_up(G[i + 1])
+        if nxt.shape[0] < G[i].shape[0] or nxt.shape[1] < G[i].shape[1]:
+            nxt = orc.resize_linear(nxt, *G[i].shape)
+        exp.append(G[i] - nxt)
+    exp.append(G[levels - 1])
+    got = pyr.makeLaplacianPyramid(dev(a), levels)
+    assert len(got) == levels
+    for g, e in zip(got, exp):
+        assert np.array_equal(host(g), e)
