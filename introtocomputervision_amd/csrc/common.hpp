@@ -106,6 +106,8 @@ struct micv_ctx {
         bool busy;
     };
     std::vector<IoBlock> io_cache;
+    // Hough trig tables (hough.hip), uploaded once per context: [0] theta = -90.., [1] theta = 0..
+    void *trig_tables[2] = {nullptr, nullptr};
     void *io_acquire(size_t bytes);
     void io_release(void *p);
     // Up to 3 auxiliary streams for group-parallel pyramid chains (lk.hip); fork makes them wait

@@ -198,6 +198,8 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (auto &b : ctx->io_cache) (void)hipFree(b.p);
+    for (void *t : ctx->trig_tables)
+        if (t) (void)hipFree(t);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;

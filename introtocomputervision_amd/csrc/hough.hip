@@ -42,27 +42,29 @@ static TrigTable make_trig(int theta0) {
     return t;
 }
 
-// grid (theta bins, chunks); dynamic LDS = rho_bins ints.
-__global__ __launch_bounds__(256) void hough_lines_kernel(const int32_t *__restrict__ pts,
-                                                           const int64_t *__restrict__ npts_p,
-                                                           int cols, int row0,
-                                                           const float *__restrict__ ct,
-                                                           const float *__restrict__ st,
-                                                           float diag, unsigned rho_bin,
-                                                           unsigned theta_bin, int rho_bins,
-                                                           int theta_bins,
-                                                           int32_t *__restrict__ acc) {
+// One workgroup per theta: the whole rho column of that angle is a histogram in LDS (dynamic
+// LDS = rho_bins ints), every edge point votes into it with an LDS atomic, and the column is then
+// written once with plain stores -- zeros included, so neither global atomics nor a memset of the
+// accumulator are needed (a chunked grid does not aggregate: with ~1 vote per bin per chunk its
+// flush was as many global atomics as there are votes).
+__global__ __launch_bounds__(1024) void hough_lines_kernel(const int32_t *__restrict__ pts,
+                                                            const int64_t *__restrict__ npts_p,
+                                                            int cols, int row0,
+                                                            const float *__restrict__ ct,
+                                                            const float *__restrict__ st,
+                                                            float diag, unsigned rho_bin,
+                                                            unsigned theta_bin, int rho_bins,
+                                                            int theta_bins,
+                                                            int32_t *__restrict__ acc) {
     extern __shared__ int hist[];
     const int tb = blockIdx.x;
     const int theta = -90 + tb * (int)theta_bin;  // Hough.cu:51
-    for (int i = threadIdx.x; i < rho_bins; i += 256) hist[i] = 0;
+    for (int i = threadIdx.x; i < rho_bins; i += 1024) hist[i] = 0;
     __syncthreads();
     const float c = ct[theta + 90], s = st[theta + 90];
     const int thetaBin = (int)roundf(((float)theta - -90.f) / (float)theta_bin);  // :56
     const int64_t npts = *npts_p;
-    const int64_t per = (npts + gridDim.y - 1) / gridDim.y;
-    const int64_t lo = blockIdx.y * per, hi = lo + per < npts ? lo + per : npts;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    for (int64_t i = threadIdx.x; i < npts; i += 1024) {
         const int32_t p = pts[i];
         const int yl = p / cols, x = p - yl * cols, y = yl + row0;
         const float rho = roundf((float)x * c + (float)y * s) + diag;  // :54
@@ -71,10 +73,7 @@ __global__ __launch_bounds__(256) void hough_lines_kernel(const int32_t *__restr
     }
     __syncthreads();
     if ((unsigned)thetaBin >= (unsigned)theta_bins) return;
-    for (int i = threadIdx.x; i < rho_bins; i += 256) {
-        const int v = hist[i];
-        if (v) atomicAdd(&acc[(size_t)i * theta_bins + thetaBin], v);
-    }
+    for (int i = threadIdx.x; i < rho_bins; i += 1024) acc[(size_t)i * theta_bins + thetaBin] = hist[i];
 }
 
 // Fallback for accumulators whose rho axis does not fit LDS: global atomics per vote.
@@ -124,6 +123,79 @@ __global__ __launch_bounds__(256) void hough_circles_kernel(const int32_t *__res
         const unsigned b = f2u_sat((float)y - radius * st[t]);
         if (a < (unsigned)cols && b < (unsigned)rows && a > 0 && b > 0)
             atomicAdd(&acc[(size_t)b * cols + a], 1);
+    }
+}
+
+// Same votes, gathered per accumulator tile: a 64x32 tile of the accumulator lives in LDS, the
+// workgroup walks the edge points that can reach it (the point list is in row-major order, so the
+// rows [b0 - r - 1, b0 + 32 + r + 1] are one contiguous range found by binary search; columns are
+// filtered into an LDS list), every thread owns one or two angles, votes are LDS atomics, and the
+// tile is written once with plain stores -- no global atomics and no memset of the accumulator.
+// Integer counts: identical to the scatter form in any order.
+__global__ __launch_bounds__(1024) void hough_circles_tiled_kernel(
+    const int32_t *__restrict__ pts, const int64_t *__restrict__ npts_p, int rows, int cols, int row0,
+    const float *__restrict__ ct, const float *__restrict__ st, float radius, int reach,
+    int32_t *__restrict__ acc) {
+    constexpr int TA = 64, TB = 32, CH = 2048, NT = 1024;  // 16 waves per tile: the heaviest tile sets the tail
+    __shared__ int hist[TA * TB];
+    __shared__ int list[CH];
+    __shared__ int nlist;
+    __shared__ long long range[2];
+    const int tid = threadIdx.x;
+    const int a0 = blockIdx.x * TA, b0 = blockIdx.y * TB;
+    for (int i = tid; i < TA * TB; i += NT) hist[i] = 0;
+    if (tid < 2) {
+        // first point with local row >= yl (tid 0: lowest row that reaches the tile; tid 1: one past
+        // the highest)
+        const long long yl = tid == 0 ? (long long)b0 - reach - row0 : (long long)b0 + TB + reach - row0;
+        const long long key = yl <= 0 ? 0 : yl * cols;
+        long long lo = 0, hi = *npts_p;
+        while (lo < hi) {
+            const long long mid = (lo + hi) >> 1;
+            if ((long long)pts[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        range[tid] = lo;
+    }
+    __shared__ float tc[360], ts[360];
+    for (int i = tid; i < 360; i += NT) {
+        tc[i] = ct[i];
+        ts[i] = st[i];
+    }
+    // cells of this tile a vote may land in (Hough.cu:89: 0 < a < cols, 0 < b < rows)
+    const unsigned amin = a0 > 1 ? a0 : 1, bmin = b0 > 1 ? b0 : 1;
+    const unsigned amax = a0 + TA < cols ? a0 + TA : cols, bmax = b0 + TB < rows ? b0 + TB : rows;
+    const unsigned aw = amax > amin ? amax - amin : 0, bw = bmax > bmin ? bmax - bmin : 0;
+    __syncthreads();
+    const long long lo = range[0], hi = range[1];
+    for (long long base = lo; base < hi; base += CH) {
+        if (tid == 0) nlist = 0;
+        __syncthreads();
+        const long long end = base + CH < hi ? base + CH : hi;
+        for (long long i = base + tid; i < end; i += NT) {
+            const int p = pts[i];
+            const int yl = p / cols, x = p - yl * cols;
+            if (x >= a0 - reach && x < a0 + TA + reach) list[atomicAdd(&nlist, 1)] = ((yl + row0) << 16) | x;
+        }
+        __syncthreads();
+        // (point, angle) pairs dealt flat over the workgroup: every lane busy, one vote per trip
+        const int nv = nlist * 360;
+        for (int w = tid; w < nv; w += NT) {
+            const int k = w / 360, t = w - k * 360;
+            const int e = list[k];
+            const float fx = (float)(e & 0xFFFF), fy = (float)(e >> 16);
+            // v_cvt_u32_f32 saturates (negative and NaN -> 0, >= 2^32 -> 0xFFFFFFFF): it IS f2u_sat
+            unsigned a, b;
+            const float va = fx - radius * tc[t], vb = fy - radius * ts[t];
+            asm("v_cvt_u32_f32 %0, %1" : "=v"(a) : "v"(va));
+            asm("v_cvt_u32_f32 %0, %1" : "=v"(b) : "v"(vb));
+            const unsigned la = a - amin, lb = b - bmin;
+            if (la < aw && lb < bw) atomicAdd(&hist[(b - (unsigned)b0) * TA + (a - (unsigned)a0)], 1);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < TA * TB; i += NT) {
+        const int a = a0 + (i & (TA - 1)), b = b0 + i / TA;
+        if (a < cols && b < rows) acc[(size_t)b * cols + a] = hist[i];
     }
 }
 
@@ -181,6 +253,64 @@ __global__ __launch_bounds__(256) void peak_select_kernel(const int32_t *__restr
     }
 }
 
+// All selection rounds in ONE launch by a single 1024-thread workgroup (num_peaks <= 64): a round
+// per launch costs more in launch latency than the scan itself when the candidate list is the
+// usual few hundred entries.  Keys of up to 4096 candidates are kept in LDS between rounds.
+__global__ __launch_bounds__(1024) void peak_select_all_kernel(
+    const int32_t *__restrict__ acc, const int32_t *__restrict__ cand,
+    const int64_t *__restrict__ ncand_p, int64_t cap, unsigned num_peaks, int cols,
+    uint32_t *__restrict__ peaks_rc, int64_t *__restrict__ count) {
+    constexpr int KEEP = 4096;
+    __shared__ unsigned long long keys[KEEP];
+    __shared__ unsigned long long wmax[16];
+    const int64_t n = *ncand_p < cap ? *ncand_p : cap;
+    const bool cached = n <= KEEP;
+    if (cached) {
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t idx = (uint32_t)cand[i];
+            keys[i] = peak_key(acc[idx], idx);
+        }
+        __syncthreads();
+    }
+    unsigned long long bound = ~0ull;
+    int64_t found = 0;
+    for (unsigned k = 0; k < num_peaks; k++) {
+        unsigned long long m = 0;
+        if (cached) {
+            for (int i = threadIdx.x; i < n; i += 1024) {
+                const unsigned long long key = keys[i];
+                if (key < bound && key > m) m = key;
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < n; i += 1024) {
+                const uint32_t idx = (uint32_t)cand[i];
+                const unsigned long long key = peak_key(acc[idx], idx);
+                if (key < bound && key > m) m = key;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(m, d);
+            m = o > m ? o : m;
+        }
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = wmax[0];
+#pragma unroll
+        for (int w = 1; w < 16; w++) m = wmax[w] > m ? wmax[w] : m;
+        __syncthreads();  // wmax is rewritten next round
+        if (m == 0) break;
+        if (threadIdx.x == 0) {
+            const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull);
+            peaks_rc[2 * found] = idx / (uint32_t)cols;      // rho = row
+            peaks_rc[2 * found + 1] = idx % (uint32_t)cols;  // theta = col
+        }
+        bound = m;
+        found++;
+    }
+    if (threadIdx.x == 0) *count = found;
+}
+
 __global__ void peak_emit_kernel(const unsigned long long *__restrict__ sel, unsigned num_peaks,
                                  int cols, uint32_t *__restrict__ peaks_rc,
                                  int64_t *__restrict__ count) {
@@ -219,6 +349,24 @@ int micv_hough_lines_dims(int rows, int cols, unsigned rho_bin, unsigned theta_b
     return MICV_OK;
 }
 
+// Device copy of a trig table, uploaded on the context's first use (a pageable H2D copy per call
+// costs more than the vote kernel).
+static int trig_on_device(micv_ctx *ctx, int which, int theta0, const TrigTable **out) {
+    if (!ctx->trig_tables[which]) {
+        const TrigTable ht = make_trig(theta0);
+        void *p = nullptr;
+        MICV_HIP(hipMalloc(&p, sizeof(TrigTable)));
+        if (hipMemcpy(p, &ht, sizeof(ht), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(p);
+            set_error("hough: trig table upload failed");
+            return MICV_EHIP;
+        }
+        ctx->trig_tables[which] = p;
+    }
+    *out = static_cast<const TrigTable *>(ctx->trig_tables[which]);
+    return MICV_OK;
+}
+
 static int hough_points(micv_ctx *ctx, hipStream_t s, const uint8_t *mask, int rows, int cols,
                         size_t mstride, size_t extra_bytes, int32_t **pts, int64_t **npts,
                         char **extra) {
@@ -254,18 +402,17 @@ int micv_hough_lines_band_dev(micv_ctx *ctx, const uint8_t *mask, int band_rows,
     int32_t *pts;
     int64_t *npts;
     char *extra;
-    MICV_TRY(hough_points(ctx, s, mask, band_rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
-    TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
-    static const TrigTable ht = make_trig(-90);  // thread-safe one-time initialisation
-    MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
-    MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rb * tb * sizeof(int32_t), s));
+    MICV_TRY(hough_points(ctx, s, mask, band_rows, cols, mstride, 0, &pts, &npts, &extra));
+    const TrigTable *dt;
+    MICV_TRY(trig_on_device(ctx, 0, -90, &dt));  // theta = -90..89, Hough.cu:51
     const float diag = (float)hough_diag(rows, cols);
     // theta loop `for (theta = -90; theta < 90; theta += bin)` has ceil(180/bin) iterations = tb
     const int n_theta = (int)((180 + theta_bin - 1) / theta_bin);
-    if ((size_t)rb * 4 <= 64 * 1024) {
-        hough_lines_kernel<<<dim3(n_theta, 16), 256, (size_t)rb * 4, s>>>(
+    if ((size_t)rb * 4 <= 64 * 1024 && n_theta == tb) {
+        hough_lines_kernel<<<n_theta, 1024, (size_t)rb * 4, s>>>(
             pts, npts, cols, row0, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
     } else {
+        MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rb * tb * sizeof(int32_t), s));
         hough_lines_global_kernel<<<dim3(64, n_theta), 256, 0, s>>>(
             pts, npts, cols, row0, dt->c, dt->s, diag, rho_bin, theta_bin, rb, tb, acc);
     }
@@ -292,10 +439,19 @@ int micv_hough_circles_band_dev(micv_ctx *ctx, const uint8_t *mask, int band_row
     int32_t *pts;
     int64_t *npts;
     char *extra;
-    MICV_TRY(hough_points(ctx, s, mask, band_rows, cols, mstride, sizeof(TrigTable), &pts, &npts, &extra));
-    TrigTable *dt = reinterpret_cast<TrigTable *>(extra);
-    static const TrigTable ht = make_trig(0);  // theta = 0..359, Hough.cu:85
-    MICV_HIP(hipMemcpyAsync(dt, &ht, sizeof(ht), hipMemcpyHostToDevice, s));
+    MICV_TRY(hough_points(ctx, s, mask, band_rows, cols, mstride, 0, &pts, &npts, &extra));
+    const TrigTable *dt;
+    MICV_TRY(trig_on_device(ctx, 1, 0, &dt));  // theta = 0..359, Hough.cu:85
+    static const bool scatter = getenv("MICV_HOUGH_SCATTER") != nullptr;
+    if (!scatter) {
+        // every accumulator cell is written by its tile (zeros included; the reference forgets
+        // to clear, Hough.cu:318)
+        const int reach = (int)std::ceil((double)radius) + 1;
+        hough_circles_tiled_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 1024, 0, s>>>(
+            pts, npts, rows, cols, row0, dt->c, dt->s, (float)radius, reach, acc);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rows * cols * sizeof(int32_t), s));  // ref forgets, :318
     hough_circles_kernel<<<2048, 256, 0, s>>>(pts, npts, rows, cols, row0, dt->c, dt->s, (float)radius, acc);
     MICV_LAUNCH_CHECK();
@@ -324,6 +480,11 @@ int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
     unsigned long long *sel = c.take<unsigned long long>((size_t)num_peaks + 1);
     MICV_TRY(ordered_compact(s, PeakPred{acc, rows, cols, threshold}, n, cand, n, ncand,
                              c.base + c.off));
+    if (num_peaks <= 64) {
+        peak_select_all_kernel<<<1, 1024, 0, s>>>(acc, cand, ncand, n, num_peaks, cols, peaks_rc, count);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     MICV_HIP(hipMemsetAsync(sel, 0, ((size_t)num_peaks + 1) * 8, s));
     for (unsigned k = 0; k < num_peaks; k++) {
         peak_select_kernel<<<64, 256, 0, s>>>(acc, cand, ncand, n, sel, (int)k);

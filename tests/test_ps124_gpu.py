@@ -271,6 +271,19 @@ def test_hough_peaks(M, num_peaks, thr):
     assert np.array_equal(hough.findLocalMaxima(acc, num_peaks, thr), exp)
 
 
+@pytest.mark.parametrize("num_peaks", [20, 64, 65, 300])
+def test_hough_peaks_many_candidates(M, num_peaks):
+    """> 4096 candidates (keys not cached in LDS) through the single-launch selection
+    (num_peaks <= 64) and through the launch-per-round path (> 64); many equal votes."""
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(num_peaks)
+    acc = rng.integers(0, 50, (300, 400)).astype(np.int32)
+    exp = orc.hough_peaks(acc, num_peaks, 10)
+    assert len(exp) == num_peaks
+    got = hough.findLocalMaxima(dev(acc), num_peaks, 10)
+    assert np.array_equal(host(got).astype(np.uint32), exp)
+
+
 def test_hough_peaks_ties_are_stable(M):
     harris, stereo, hough, synth = M
     acc = np.zeros((40, 50), np.int32)
