@@ -28,63 +28,119 @@ struct Top2 {
     }
 };
 
-constexpr int kQT = 64, kTT = 64, kDC = 32;  // queries / train rows per tile, dimensions per chunk
+// Tile: 64 queries x 128 train rows per pass of a 256-thread workgroup, a thread owns 4 queries x 8
+// train rows (32 chains).  Both operands are staged TRANSPOSED ([k][row]) so that a thread's 4
+// query values and 8 train values of one dimension k are ds_read_b128 reads, and adjacent train
+// rows sit in adjacent registers: the chain step  d = a - t; acc = fma(d, d, acc)  runs as
+// v_pk_add_f32 / v_pk_fma_f32 on (t_j, t_j+1) pairs -- two chains per instruction, each still its
+// own IEEE fmaf chain in dimension order.  The train set is cut into slices over blockIdx.y so
+// that small query sets still fill the GPU; bf_merge_kernel folds the slices' top-2 in slice
+// (= index) order.
+typedef float mf2 __attribute__((ext_vector_type(2)));
+typedef float mf4 __attribute__((ext_vector_type(4)));
+constexpr int kQT = 64, kTT = 128, kDC = 32;
 
 __global__ __launch_bounds__(256) void bf_knn2_kernel(const float *__restrict__ query, int nq,
                                                        int qstride, const float *__restrict__ train,
-                                                       int nt, int tstride, int dim,
-                                                       int32_t *__restrict__ idx2,
-                                                       float *__restrict__ dist2) {
-    __shared__ float Q[kQT][kDC + 1];   // +1: lanes read a column, one row per lane
-    __shared__ float T[kTT][kDC];
-    __shared__ float md[4][kQT][2];
-    __shared__ int mi[4][kQT][2];
-    const int tid = threadIdx.x, q = tid & 63, grp = tid >> 6;
+                                                       int nt, int tstride, int dim, int slice_rows,
+                                                       int32_t *__restrict__ part_i,
+                                                       float *__restrict__ part_d) {
+    __shared__ __attribute__((aligned(16))) float Qt[kDC][kQT];
+    __shared__ __attribute__((aligned(16))) float Tt[kDC][kTT];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int q0 = blockIdx.x * kQT;
-    Top2 best;
-    best.init();
-    for (int t0 = 0; t0 < nt; t0 += kTT) {
-        float acc[16];
+    const int ts0 = blockIdx.y * slice_rows, ts1 = ts0 + slice_rows < nt ? ts0 + slice_rows : nt;
+    Top2 best[4];
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[j] = 0.f;
+    for (int i = 0; i < 4; i++) best[i].init();
+    for (int t0 = ts0; t0 < ts1; t0 += kTT) {
+        mf2 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (mf2)(0.f);
         for (int k0 = 0; k0 < dim; k0 += kDC) {  // chains continue across chunks in dimension order
             __syncthreads();
-            for (int i = tid; i < kQT * kDC; i += 256) {
-                const int r = i / kDC, c = i - r * kDC;
-                Q[r][c] = (q0 + r < nq && k0 + c < dim) ? query[(size_t)(q0 + r) * qstride + k0 + c] : 0.f;
-                T[r][c] = (t0 + r < nt && k0 + c < dim) ? train[(size_t)(t0 + r) * tstride + k0 + c] : 0.f;
+            {   // stage, transposing: lane = row, so the LDS stores of one k are contiguous
+                const int r = tid & 63, kq = (tid >> 6) * 8;
+                const bool rin = q0 + r < nq;
+                const float *src = query + (size_t)(rin ? q0 + r : 0) * qstride + k0 + kq;
+#pragma unroll
+                for (int i = 0; i < 8; i++) Qt[kq + i][r] = (rin && k0 + kq + i < dim) ? src[i] : 0.f;
+            }
+            {
+                const int r = tid & 127, kh = (tid >> 7) * 16;
+                const bool rin = t0 + r < ts1;
+                const float *src = train + (size_t)(rin ? t0 + r : 0) * tstride + k0 + kh;
+#pragma unroll
+                for (int i = 0; i < 16; i++) Tt[kh + i][r] = (rin && k0 + kh + i < dim) ? src[i] : 0.f;
             }
             __syncthreads();
             const int kn = dim - k0 < kDC ? dim - k0 : kDC;
+#pragma unroll 4
             for (int k = 0; k < kn; k++) {
-                const float a = Q[q][k];
+                const mf4 a = *reinterpret_cast<const mf4 *>(&Qt[k][4 * tx]);
+                const mf4 b0 = *reinterpret_cast<const mf4 *>(&Tt[k][8 * ty]);
+                const mf4 b1 = *reinterpret_cast<const mf4 *>(&Tt[k][8 * ty + 4]);
+                const mf2 t[4] = {b0.xy, b0.zw, b1.xy, b1.zw};
+                const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const float diff = a - T[grp * 16 + j][k];
-                    acc[j] = fmaf(diff, diff, acc[j]);
-                }
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const mf2 d = (mf2)(av[i]) - t[j];
+                        acc[i][j] = __builtin_elementwise_fma(d, d, acc[i][j]);
+                    }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int t = t0 + grp * 16 + j;
-            if (t < nt) best.push(acc[j], t);
-        }
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int t = t0 + 8 * ty + 2 * j;
+                if (t < ts1) best[i].push(acc[i][j].x, t);
+                if (t + 1 < ts1) best[i].push(acc[i][j].y, t + 1);
+            }
     }
-    md[grp][q][0] = best.d0; md[grp][q][1] = best.d1;
-    mi[grp][q][0] = best.i0; mi[grp][q][1] = best.i1;
+    // fold the 16 train-row groups of each query (ascending ty = ascending index)
+    __shared__ float md[16][kQT][2];
+    __shared__ int mi[16][kQT][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        md[ty][4 * tx + i][0] = best[i].d0; md[ty][4 * tx + i][1] = best[i].d1;
+        mi[ty][4 * tx + i][0] = best[i].i0; mi[ty][4 * tx + i][1] = best[i].i1;
+    }
     __syncthreads();
-    if (grp == 0 && q0 + q < nq) {
+    if (tid < kQT && q0 + tid < nq) {
         Top2 m;
         m.init();
-        for (int g = 0; g < 4; g++)
-            for (int s = 0; s < 2; s++)
-                if (mi[g][q][s] >= 0) m.push(md[g][q][s], mi[g][q][s]);
-        idx2[2 * (q0 + q)] = m.i0;
-        idx2[2 * (q0 + q) + 1] = m.i1;
-        dist2[2 * (q0 + q)] = sqrtf(m.d0);
-        dist2[2 * (q0 + q) + 1] = sqrtf(m.d1);
+        for (int g = 0; g < 16; g++)
+            for (int sidx = 0; sidx < 2; sidx++)
+                if (mi[g][tid][sidx] >= 0) m.push(md[g][tid][sidx], mi[g][tid][sidx]);
+        const size_t o = ((size_t)blockIdx.y * nq + q0 + tid) * 2;
+        part_i[o] = m.i0; part_i[o + 1] = m.i1;
+        part_d[o] = m.d0; part_d[o + 1] = m.d1;
     }
+}
+
+// Top-2 over the slices' partial top-2 lists (slice order = index order), then the square roots.
+__global__ __launch_bounds__(256) void bf_merge_kernel(const int32_t *__restrict__ part_i,
+                                                        const float *__restrict__ part_d, int nq,
+                                                        int slices, int32_t *__restrict__ idx2,
+                                                        float *__restrict__ dist2) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    Top2 m;
+    m.init();
+    for (int s = 0; s < slices; s++)
+        for (int k = 0; k < 2; k++) {
+            const size_t o = ((size_t)s * nq + q) * 2 + k;
+            if (part_i[o] >= 0) m.push(part_d[o], part_i[o]);
+        }
+    idx2[2 * q] = m.i0;
+    idx2[2 * q + 1] = m.i1;
+    dist2[2 * q] = sqrtf(m.d0);
+    dist2[2 * q + 1] = sqrtf(m.d1);
 }
 
 struct RatioPred {
@@ -122,8 +178,24 @@ int micv_bf_knn2_dev(micv_ctx *ctx, const float *query, int nq, size_t qstride, 
     MICV_REQUIRE(nq > 0 && nt >= 2 && dim > 0, "micv_bf_knn2: need nq > 0, nt >= 2, dim > 0");
     MICV_REQUIRE(stride_ok(qstride, dim, 4) && stride_ok(tstride, dim, 4), "micv_bf_knn2: bad stride");
     MICV_HIP(hipSetDevice(ctx->device));
-    bf_knn2_kernel<<<cdiv(nq, kQT), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        query, nq, (int)(qstride / 4), train, nt, (int)(tstride / 4), dim, idx2, dist2);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // slices of the train set: enough workgroups for ~2 per CU, whole 128-row passes per slice
+    const int qblocks = (int)cdiv(nq, kQT), passes = (int)cdiv(nt, kTT);
+    int slices = (512 + qblocks - 1) / qblocks;
+    if (slices > passes) slices = passes;
+    if (slices < 1) slices = 1;
+    const int slice_rows = (int)cdiv(passes, slices) * kTT;
+    slices = (int)cdiv(nt, slice_rows);
+    void *scratch;
+    MICV_TRY(ctx->reserve(2 * Carver::need((size_t)slices * nq * 2, 4), &scratch));
+    Carver c(scratch);
+    int32_t *part_i = c.take<int32_t>((size_t)slices * nq * 2);
+    float *part_d = c.take<float>((size_t)slices * nq * 2);
+    bf_knn2_kernel<<<dim3(qblocks, slices), 256, 0, s>>>(query, nq, (int)(qstride / 4), train, nt,
+                                                         (int)(tstride / 4), dim, slice_rows, part_i,
+                                                         part_d);
+    MICV_LAUNCH_CHECK();
+    bf_merge_kernel<<<cdiv(nq, 256), 256, 0, s>>>(part_i, part_d, nq, slices, idx2, dist2);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }

@@ -49,7 +49,8 @@ def test_oracle_knn_matches_numpy():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nq,nt,dim", [(300, 500, 128), (1, 2, 128), (65, 64, 128), (130, 257, 61), (2000, 3000, 128)])
+@pytest.mark.parametrize("nq,nt,dim", [(300, 500, 128), (1, 2, 128), (65, 64, 128), (130, 257, 61), (2000, 3000, 128),
+                                       (7, 129, 5), (64, 128, 32), (63, 1025, 33), (1000, 130, 127), (5000, 300, 128)])
 def test_knn_ratio_gpu(nq, nt, dim):
     import torch
     from introtocomputervision_amd import match

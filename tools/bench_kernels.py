@@ -104,3 +104,20 @@ line("HOST stereo SSD 1080p r=5 d=128", ms, 1080 * 1920, 9)
 img480 = synth.checkerboard(480, 640, 40, seed=1)
 ms = wall(lambda: harris.getGradients(img480, 3, ctx=ctx))
 line("HOST sobel3 pair 640x480", ms, 480 * 640, 12)
+
+# "next" rows: matcher, edge front-end, motion history at representative sizes
+from introtocomputervision_amd import match, mhi
+rng = np.random.default_rng(1)
+for nq, nt in ((2000, 2000), (8192, 8192)):
+    q = torch.from_numpy(rng.random((nq, 128), dtype=np.float32) * 255).cuda()
+    tr = torch.from_numpy(rng.random((nt, 128), dtype=np.float32) * 255).cuda()
+    ms = timeit(lambda: match.knnMatch2(q, tr, ctx=ctx), iters=10)
+    print(json.dumps({"kernel": f"BFMatcher knn2 {nq}x{nt}x128", "ms": round(ms, 4),
+                      "GFLOPs": round(3 * nq * nt * 128 / ms / 1e6, 1)}))
+img8 = torch.from_numpy((synth.smooth_noise(9, 1080, 1920)).astype(np.uint8)).cuda()
+ms = timeit(lambda: hough.generateEdge(img8, 5, 1.4, 30, 90, ctx=ctx), iters=10)
+line("generateEdge (blur 5 + Canny) 1080p u8", ms, 1080 * 1920, 2)
+f1 = img8
+f2 = torch.roll(img8, 3, 1).contiguous()
+ms = timeit(lambda: mhi.frameDifference(f1, f2, 20, 5, 1.5, ctx=ctx), iters=10)
+line("mhi::frameDifference (blur 5, open 7x7) 1080p u8", ms, 1080 * 1920, 3)
