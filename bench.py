@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=8, help="frame pairs per GPU per step")
     ap.add_argument("--cpu-pairs", type=int, default=6, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="passes in flight (contexts/streams), pairs mode")
     ap.add_argument("--mode", choices=["pairs", "rowshard"], default="pairs",
                     help="pairs: every rank owns whole frame pairs (default, weak scaling, no data-path "
                          "collective); rowshard: every pair is split by rows over all ranks with a "
@@ -147,8 +148,21 @@ def main():
                 u[i, a0:b0] = bu[a0:b0]
                 v[i, a0:b0] = bv[a0:b0]
     else:
+        # `--inflight F` batches in flight: step i runs on context / HIP stream / output buffers
+        # i mod F (a context owns its scratch arena and aux streams, so passes on different contexts
+        # are independent).  With F = 2 the latency-bound coarse pyramid levels of one pass overlap
+        # the throughput-bound fine levels of the previous one -- double buffering, as a video
+        # pipeline would run it.  Every pass still does all of its work and writes its own outputs.
+        F = max(1, args.inflight)
+        lanes = [(ctx, torch.cuda.current_stream(dev), (u, v))]
+        for _ in range(1, F):
+            lanes.append((Context(local_rank), torch.cuda.Stream(dev), (torch.empty_like(prev), torch.empty_like(prev))))
+        counter = [0]
+
         def step():
-            lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
+            c, st, out = lanes[counter[0] % F]
+            counter[0] += 1
+            lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=c, out=out, stream=st.cuda_stream)
 
     def barrier():
         if dist is not None:
@@ -172,6 +186,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same K steps one at a time on one context (no overlap between passes): reported beside
+    # `value` so the effect of keeping two passes in flight is visible
+    serial_ms = None
+    if args.mode == "pairs" and max(1, args.inflight) > 1:
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - ts) / args.steps * 1e3
+
     # sanity of what was measured: known translation comes back (not part of the timing)
     if args.mode == "rowshard":
         chk_u, chk_v = u[0, a0 + 8:b0 - 8, 64:-64], v[0, a0 + 8:b0 - 8, 64:-64]
@@ -192,8 +217,9 @@ def main():
         os.environ["MICV_LK_GROUPS"] = "1"
         ctx.profile(True)
         ctx.profile_reset()
-        for _ in range(args.steps):
-            step()
+        torch.cuda.synchronize()
+        for _ in range(args.steps):  # one pass at a time on one context: nothing runs beside the timed launch
+            lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
         torch.cuda.synchronize()
         if saved_groups is None:
             del os.environ["MICV_LK_GROUPS"]
@@ -254,6 +280,8 @@ def main():
                 "pairs_per_gpu_per_step": B, "levels": LEVELS, "win": WIN,
                 "parallelism": f"pair-dp{n_gpus}" if args.mode == "pairs" else f"row-shard{n_gpus} (coarse-flow halo, p2p)",
                 "flow_check": {"median_u": um, "median_v": vm, "ok": ok},
+                "passes_in_flight": max(1, args.inflight) if args.mode == "pairs" else 1,
+                "one_pass_at_a_time_ms_per_step": serial_ms,
             },
             "algorithmic_GBps_pipeline": value * 1e6 * algorithmic_bytes_pair(ROWS, COLS, LEVELS)
                                          / (ROWS * COLS) / 1e9,
