@@ -21,6 +21,7 @@ struct PyrLevels {
     int rows[16], cols[16];
     int tiles_before[17];  // prefix sum of 64x4-tiles per level (levels 1..n-1 and level 0 copy)
     int n;
+    int chain;  // levels >= 2 are emitted by the level-1 tiles
 };
 
 // One block = 64x4 output pixels of some level; blockIdx.x indexes tiles over all levels,
@@ -46,7 +47,21 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict_
     const int sh = (1 << l) - 1;
     const float *s = src + blockIdx.y * img_elems;
     float *d = L.dst[l] + blockIdx.y * (size_t)L.rows[l] * L.cols[l];
-    d[(size_t)y * L.cols[l] + x] = s[(size_t)((y << l) + sh) * sstride + (x << l) + sh];
+    const float v = s[(size_t)((y << l) + sh) * sstride + (x << l) + sh];
+    d[(size_t)y * L.cols[l] + x] = v;
+    // Every level is a decimation of the previous one at odd coordinates, so the level-1 tiles
+    // also emit the deeper levels (which then have no tiles of their own): the source is read
+    // once, on its odd rows only.
+    if (l == 1 && L.chain) {
+        int yy = y, xx = x, ll = 1;
+        while (ll + 1 < L.n && (yy & 1) && (xx & 1)) {
+            yy >>= 1;
+            xx >>= 1;
+            ll++;
+            if (L.dst[ll] && yy < L.rows[ll] && xx < L.cols[ll])
+                L.dst[ll][blockIdx.y * (size_t)L.rows[ll] * L.cols[ll] + (size_t)yy * L.cols[ll] + xx] = v;
+        }
+    }
 }
 
 // pyr::pyrUp step 1+2a (Pyramids.cu:86-91 replicate, :126 row filter): the replicated image's
@@ -251,8 +266,10 @@ int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, siz
             L[k].cols[l] = cols >> l;
             L[k].dst[l] = dst ? dst[l] : nullptr;
             L[k].tiles_before[l] = total;
-            // both sets use the same tiling (a skipped level must be skipped in both)
-            if (dst_a[l]) total += cdiv(L[k].cols[l], 64) * cdiv(L[k].rows[l], 4);
+            // both sets use the same tiling (a skipped level must be skipped in both); with level 1
+            // present its tiles emit every deeper level
+            L[k].chain = levels > 1 && dst_a[1] != nullptr;
+            if (dst_a[l] && !(L[k].chain && l >= 2)) total += cdiv(L[k].cols[l], 64) * cdiv(L[k].rows[l], 4);
         }
         L[k].tiles_before[levels] = total;
     }
