@@ -121,3 +121,24 @@ f1 = img8
 f2 = torch.roll(img8, 3, 1).contiguous()
 ms = timeit(lambda: mhi.frameDifference(f1, f2, 20, 5, 1.5, ctx=ctx), iters=10)
 line("mhi::frameDifference (blur 5, open 7x7) 1080p u8", ms, 1080 * 1920, 3)
+
+# C5: the whole 4K chain on one GPU (Harris -> corner list -> keypoint angles -> 5-level LK sampled at
+# the corners), device resident, wall clock including the one host read-back of the corner count
+tex = synth.smooth_noise(0x5EED0004, 2160, 3840)
+chk = synth.checkerboard(2160, 3840, square=40)
+p4 = np.round(tex * (chk / 192.0)).astype(np.float32)
+n4 = np.ascontiguousarray(np.roll(p4, shift=(-2, 3), axis=(0, 1)))
+P4, N4 = torch.from_numpy(p4).cuda(), torch.from_numpy(n4).cuda()
+
+
+def c5():
+    gx_, gy_ = harris.getGradients(P4, 3, ctx=ctx)
+    R_ = harris.getCornerResponse(gx_, gy_, 5, 1.5, 0.04, ctx=ctx)
+    _, locs_ = harris.refineCorners(R_, 5e8, 5, capacity=1 << 20, ctx=ctx)
+    kp_ = harris.getKeypoints(gx_, gy_, locs_, 10, ctx=ctx)
+    u_, v_ = lk.calcOpticalFlowPyr(P4, N4, 15, 5, ctx=ctx)
+    return u_[locs_[:, 0].long(), locs_[:, 1].long()], kp_
+
+
+ms = wall(lambda: (c5(), torch.cuda.synchronize()), iters=10)
+line("C5 chain 3840x2160: Harris + corner list + keypoints + LK(5 levels) at corners", ms, 2160 * 3840, 26.6 + 12 + 12 + 9)
