@@ -104,29 +104,7 @@ __device__ __forceinline__ unsigned f2u_sat(float v) {
     return (unsigned)v;
 }
 
-// One thread per (point, theta); Hough.cu:85-93.
-__global__ __launch_bounds__(256) void hough_circles_kernel(const int32_t *__restrict__ pts,
-                                                             const int64_t *__restrict__ npts_p,
-                                                             int rows, int cols, int row0,
-                                                             const float *__restrict__ ct,
-                                                             const float *__restrict__ st,
-                                                             float radius,
-                                                             int32_t *__restrict__ acc) {
-    const int64_t npts = *npts_p;
-    const int64_t total = npts * 360;
-    for (int64_t w = blockIdx.x * 256ll + threadIdx.x; w < total; w += (int64_t)gridDim.x * 256) {
-        const int64_t i = w / 360;
-        const int t = (int)(w - i * 360);
-        const int32_t p = pts[i];
-        const int yl = p / cols, x = p - yl * cols, y = yl + row0;
-        const unsigned a = f2u_sat((float)x - radius * ct[t]);
-        const unsigned b = f2u_sat((float)y - radius * st[t]);
-        if (a < (unsigned)cols && b < (unsigned)rows && a > 0 && b > 0)
-            atomicAdd(&acc[(size_t)b * cols + a], 1);
-    }
-}
-
-// Same votes, gathered per accumulator tile: a 64x32 tile of the accumulator lives in LDS, the
+// Votes of Hough.cu:85-93, gathered per accumulator tile: a 64x32 tile of the accumulator lives in LDS, the
 // workgroup walks the edge points that can reach it (the point list is in row-major order, so the
 // rows [b0 - r - 1, b0 + 32 + r + 1] are one contiguous range found by binary search; columns are
 // filtered into an LDS list), every thread owns one or two angles, votes are LDS atomics, and the
@@ -442,18 +420,11 @@ int micv_hough_circles_band_dev(micv_ctx *ctx, const uint8_t *mask, int band_row
     MICV_TRY(hough_points(ctx, s, mask, band_rows, cols, mstride, 0, &pts, &npts, &extra));
     const TrigTable *dt;
     MICV_TRY(trig_on_device(ctx, 1, 0, &dt));  // theta = 0..359, Hough.cu:85
-    static const bool scatter = getenv("MICV_HOUGH_SCATTER") != nullptr;
-    if (!scatter) {
-        // every accumulator cell is written by its tile (zeros included; the reference forgets
-        // to clear, Hough.cu:318)
-        const int reach = (int)std::ceil((double)radius) + 1;
-        hough_circles_tiled_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 1024, 0, s>>>(
-            pts, npts, rows, cols, row0, dt->c, dt->s, (float)radius, reach, acc);
-        MICV_LAUNCH_CHECK();
-        return MICV_OK;
-    }
-    MICV_HIP(hipMemsetAsync(acc, 0, (size_t)rows * cols * sizeof(int32_t), s));  // ref forgets, :318
-    hough_circles_kernel<<<2048, 256, 0, s>>>(pts, npts, rows, cols, row0, dt->c, dt->s, (float)radius, acc);
+    // every accumulator cell is written by its tile (zeros included; the reference forgets to
+    // clear, Hough.cu:318)
+    const int reach = (int)std::ceil((double)radius) + 1;
+    hough_circles_tiled_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 1024, 0, s>>>(
+        pts, npts, rows, cols, row0, dt->c, dt->s, (float)radius, reach, acc);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }

@@ -260,6 +260,25 @@ def test_hough_circles(M, radius):
     assert np.array_equal(hough.houghCirclesAccumulate(mask, radius), exp)
 
 
+def test_hough_lines_tall_image_takes_the_global_atomics_kernel(M):
+    """rho axis of 2*ceil(sqrt(H^2+W^2)) > 16384 bins does not fit one workgroup's LDS."""
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(3)
+    mask = ((rng.random((9000, 48)) < 0.01) * 255).astype(np.uint8)
+    exp = orc.hough_lines(mask, 1, 2)
+    assert exp.shape[0] * 4 > 64 * 1024
+    assert np.array_equal(host(hough.houghLinesAccumulate(dev(mask), 1, 2)), exp)
+
+
+@pytest.mark.parametrize("rows,cols,radius", [(300, 400, 200), (65, 33, 1), (40, 700, 64)])
+def test_hough_circles_reach_beyond_tiles(M, rows, cols, radius):
+    """Radii larger than the 64x32 accumulator tile, and images smaller than one tile."""
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(radius)
+    mask = ((rng.random((rows, cols)) < 0.01) * 255).astype(np.uint8)
+    assert np.array_equal(host(hough.houghCirclesAccumulate(dev(mask), radius)), orc.hough_circles(mask, radius))
+
+
 @pytest.mark.parametrize("num_peaks,thr", [(10, 50), (3, 0), (40, 20), (0, 10)])
 def test_hough_peaks(M, num_peaks, thr):
     harris, stereo, hough, synth = M
