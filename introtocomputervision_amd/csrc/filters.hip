@@ -47,9 +47,102 @@ __global__ __launch_bounds__(256) void filter_cols_kernel(const float *__restric
     dst[blockIdx.z * dfield + (size_t)y * dstride + x] = acc;
 }
 
+// LDS-tiled forms of the two passes (the generic LK path runs 5 fields x 43 taps through them): the
+// tile (+ n/2 halo, BORDER_REFLECT_101 resolved while loading, loads batched) is staged once and
+// every tap is an LDS read by consecutive lanes; a thread carries 4 (rows) / 8 (columns) independent
+// chains.  Same fmaf chain per output as the kernels above.
+__global__ __launch_bounds__(256) void filter_rows_lds_kernel(const float *__restrict__ src,
+                                                               int sstride, size_t sfield,
+                                                               float *__restrict__ dst, int dstride,
+                                                               size_t dfield, int rows, int cols,
+                                                               Taps t) {
+    constexpr int TW = 256, TR = 4;
+    extern __shared__ float fl_lds[];
+    const int a = t.n / 2, pw = TW + t.n - 1;  // staged row width
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    const float *sp = src + blockIdx.z * sfield;
+    for (int base = 0; base < TR * pw; base += 4 * 256) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + k * 256 + threadIdx.x < TR * pw ? base + k * 256 + threadIdx.x : TR * pw - 1;
+            const int r = i / pw, c = i - r * pw;
+            const int yy = y0 + r < rows ? y0 + r : rows - 1;
+            v[k] = sp[(size_t)yy * sstride + reflect101(x0 - a + c, cols)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = base + k * 256 + threadIdx.x;
+            if (i < TR * pw) fl_lds[i] = v[k];
+        }
+    }
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= cols) return;
+    float acc[TR] = {0.f, 0.f, 0.f, 0.f};
+    const float *lp = fl_lds + threadIdx.x;
+    for (int k = 0; k < t.n; k++) {
+        const float w = t.k[k];
+#pragma unroll
+        for (int r = 0; r < TR; r++) acc[r] = fmaf(lp[r * pw + k], w, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < TR; r++)
+        if (y0 + r < rows) dst[blockIdx.z * dfield + (size_t)(y0 + r) * dstride + x] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void filter_cols_lds_kernel(const float *__restrict__ src,
+                                                               int sstride, size_t sfield,
+                                                               float *__restrict__ dst, int dstride,
+                                                               size_t dfield, int rows, int cols,
+                                                               Taps t) {
+    constexpr int TW = 64, TH = 32, RP = TH / 4;
+    extern __shared__ float fl_lds[];
+    const int a = t.n / 2, ph = TH + t.n - 1;  // staged rows
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const float *sp = src + blockIdx.z * sfield;
+    const int c = threadIdx.x & 63, x = x0 + c < cols ? x0 + c : cols - 1;
+    for (int base = 0; base < ph; base += 4 * 4) {  // 4 rows per pass of the workgroup, 4 passes in flight
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = base + 4 * k + (threadIdx.x >> 6);
+            v[k] = sp[(size_t)reflect101(y0 - a + (r < ph ? r : ph - 1), rows) * sstride + x];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = base + 4 * k + (threadIdx.x >> 6);
+            if (r < ph) fl_lds[r * TW + c] = v[k];
+        }
+    }
+    __syncthreads();
+    if (x0 + c >= cols) return;
+    const int rb = (threadIdx.x >> 6) * RP;
+    float acc[RP];
+#pragma unroll
+    for (int j = 0; j < RP; j++) acc[j] = 0.f;
+    const float *lp = fl_lds + rb * TW + c;
+    for (int k = 0; k < t.n; k++) {
+        const float w = t.k[k];
+#pragma unroll
+        for (int j = 0; j < RP; j++) acc[j] = fmaf(lp[(j + k) * TW], w, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RP; j++)
+        if (y0 + rb + j < rows) dst[blockIdx.z * dfield + (size_t)(y0 + rb + j) * dstride + x0 + c] = acc[j];
+}
+
 int launch_filter_rows(hipStream_t s, const float *src, int sstride, size_t sfield, float *dst,
                        int dstride, size_t dfield, int rows, int cols, int nfields,
                        const Taps &t) {
+    static const bool direct = getenv("MICV_FILTER_DIRECT") != nullptr;
+    if (!direct && t.n >= 5) {
+        filter_rows_lds_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 4), nfields), 256,
+                                 (size_t)4 * (256 + t.n - 1) * sizeof(float), s>>>(
+            src, sstride, sfield, dst, dstride, dfield, rows, cols, t);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     dim3 grid(cdiv(cols, 64), cdiv(rows, 4), nfields);
     filter_rows_kernel<<<grid, 256, 0, s>>>(src, sstride, sfield, dst, dstride, dfield, rows, cols,
                                             t);
@@ -60,6 +153,14 @@ int launch_filter_rows(hipStream_t s, const float *src, int sstride, size_t sfie
 int launch_filter_cols(hipStream_t s, const float *src, int sstride, size_t sfield, float *dst,
                        int dstride, size_t dfield, int rows, int cols, int nfields,
                        const Taps &t) {
+    static const bool direct = getenv("MICV_FILTER_DIRECT") != nullptr;
+    if (!direct && t.n >= 5) {
+        filter_cols_lds_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32), nfields), 256,
+                                 (size_t)64 * (32 + t.n - 1) * sizeof(float), s>>>(
+            src, sstride, sfield, dst, dstride, dfield, rows, cols, t);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     dim3 grid(cdiv(cols, 64), cdiv(rows, 4), nfields);
     filter_cols_kernel<<<grid, 256, 0, s>>>(src, sstride, sfield, dst, dstride, dfield, rows, cols,
                                             t);
