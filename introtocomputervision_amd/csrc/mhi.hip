@@ -59,25 +59,49 @@ struct Ellipse7 {
     unsigned char m[7];  // bit j of m[i] = element (i, j)
 };
 
-__global__ __launch_bounds__(256) void mhi_morph7_kernel(const uint8_t *__restrict__ src, int rows,
-                                                          int cols, int dilate, Ellipse7 e,
-                                                          uint8_t *__restrict__ dst,
-                                                          size_t dstride) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    int v = dilate ? 0 : 255;
+// Erode / dilate with the 7x7 ellipse from an LDS tile: 64x16 outputs + 3-pixel halo (BORDER_REFLECT_101 resolved
+// while loading), 37 taps per pixel served from LDS instead of global bytes.
+__global__ __launch_bounds__(256) void mhi_morph7_tiled_kernel(const uint8_t *__restrict__ src, int rows,
+                                                                int cols, int dilate, Ellipse7 e,
+                                                                uint8_t *__restrict__ dst,
+                                                                size_t dstride) {
+    constexpr int TW = 64, TH = 16, RW = TW + 6, RH = TH + 6, PS = RW + 1;
+    __shared__ int T[RH * PS];  // one value per word: byte-wide LDS reads would serialise on banks
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    {
+        constexpr int NB = (RH * RW + 255) / 256;
+        int v[NB];
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        const uint8_t *r = src + (size_t)reflect101(y + i - 3, rows) * cols;
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * 256 < RH * RW ? threadIdx.x + k * 256 : RH * RW - 1;
+            const int ly = i / RW, lx = i - ly * RW;
+            v[k] = src[(size_t)reflect101(y0 - 3 + ly, rows) * cols + reflect101(x0 - 3 + lx, cols)];
+        }
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
-            if (!((e.m[i] >> j) & 1)) continue;
-            const int s = r[reflect101(x + j - 3, cols)];
-            v = dilate ? (s > v ? s : v) : (s < v ? s : v);
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * 256;
+            if (i < RH * RW) T[(i / RW) * PS + (i % RW)] = v[k];
         }
     }
-    dst[(size_t)y * dstride + x] = (uint8_t)v;
+    __syncthreads();
+    const int c = threadIdx.x & 63, x = x0 + c;
+    if (x >= cols) return;
+#pragma unroll
+    for (int q = 0; q < TH / 4; q++) {
+        const int ry = (threadIdx.x >> 6) * (TH / 4) + q, y = y0 + ry;
+        if (y >= rows) break;
+        int v = dilate ? 0 : 255;
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                if (!((e.m[i] >> j) & 1)) continue;
+                const int t = T[(ry + i) * PS + c + j];
+                v = dilate ? (t > v ? t : v) : (t < v ? t : v);
+            }
+        }
+        dst[(size_t)y * dstride + x] = (uint8_t)v;
+    }
 }
 
 __global__ __launch_bounds__(256) void mhi_threshold_kernel(const uint8_t *__restrict__ src,
@@ -151,9 +175,10 @@ int micv_mhi_frame_difference_dev(micv_ctx *ctx, const uint8_t *f1, const uint8_
     mhi_blur_cols_diff_kernel<<<grid, 256, 0, s>>>(buf, rows, cols, t, thresh, m0);
     MICV_LAUNCH_CHECK();
     const Ellipse7 e = ellipse7();
-    mhi_morph7_kernel<<<grid, 256, 0, s>>>(m0, rows, cols, 0, e, m1, (size_t)cols);  // erode
+    const dim3 mgrid(cdiv(cols, 64), cdiv(rows, 16));
+    mhi_morph7_tiled_kernel<<<mgrid, 256, 0, s>>>(m0, rows, cols, 0, e, m1, (size_t)cols);  // erode
     MICV_LAUNCH_CHECK();
-    mhi_morph7_kernel<<<grid, 256, 0, s>>>(m1, rows, cols, 1, e, diff, dstride);     // dilate
+    mhi_morph7_tiled_kernel<<<mgrid, 256, 0, s>>>(m1, rows, cols, 1, e, diff, dstride);     // dilate
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
