@@ -99,13 +99,34 @@ __global__ __launch_bounds__(256) void canny_hyst_kernel(uint8_t *__restrict__ m
     __shared__ uint8_t t[34][36];
     __shared__ int tile_changed, any;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-    for (int i = threadIdx.x; i < 34 * 34; i += 256) {
-        const int ly = i / 34, lx = i - ly * 34;
-        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        t[ly][lx] = ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols) ? map[(size_t)gy * cols + gx] : 0;
+    {   // all five loads per thread in flight at once (clamped addresses, zeroed outside the image)
+        uint8_t v[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = threadIdx.x + 256 * k < 34 * 34 ? threadIdx.x + 256 * k : 34 * 34 - 1;
+            const int ly = i / 34, lx = i - ly * 34;
+            const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+            const uint8_t m = map[(size_t)clampi(gy, 0, rows - 1) * cols + clampi(gx, 0, cols - 1)];
+            v[k] = ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols) ? m : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < 34 * 34) t[i / 34][i % 34] = v[k];
+        }
     }
     if (threadIdx.x == 0) any = 0;
     __syncthreads();
+    {   // nothing to promote in a tile without candidates, or without a strong pixel in reach
+        bool weak = false, strong = false;
+        for (int i = threadIdx.x; i < 34 * 34; i += 256) {
+            const int ly = i / 34, lx = i - ly * 34;
+            const uint8_t m = t[ly][lx];
+            weak |= m == 1 && ly >= 1 && ly <= 32 && lx >= 1 && lx <= 32;
+            strong |= m == 2;
+        }
+        if (!__syncthreads_or(weak) || !__syncthreads_or(strong)) return;
+    }
     for (;;) {
         if (threadIdx.x == 0) tile_changed = 0;
         __syncthreads();
@@ -192,10 +213,16 @@ extern "C" int micv_generate_edge_dev(micv_ctx *ctx, const uint8_t *src, int row
     MICV_LAUNCH_CHECK();
     int *h_changed = static_cast<int *>(ctx->pinned);
     const int max_rounds = (int)(cdiv(cols, 32) * cdiv(rows, 32)) + 2;  // a path crosses each tile at most once per round
-    for (int round = 0; round < max_rounds; round++) {  // data-dependent: reads one flag per round
-        MICV_HIP(hipMemsetAsync(changed, 0, 4, s));
-        canny_hyst_kernel<<<dim3(cdiv(cols, 32), cdiv(rows, 32)), 256, 0, s>>>(map, rows, cols, changed);
-        MICV_LAUNCH_CHECK();
+    // Data-dependent loop: rounds are enqueued four at a time and the host reads ONE flag per batch
+    // (did the batch's last round still promote anything?).  A round after convergence changes
+    // nothing, so overshooting is harmless; a host round trip per round was most of the time.
+    constexpr int kBatch = 4;
+    for (int round = 0; round < max_rounds; round += kBatch) {
+        for (int b = 0; b < kBatch; b++) {
+            MICV_HIP(hipMemsetAsync(changed, 0, 4, s));
+            canny_hyst_kernel<<<dim3(cdiv(cols, 32), cdiv(rows, 32)), 256, 0, s>>>(map, rows, cols, changed);
+            MICV_LAUNCH_CHECK();
+        }
         MICV_HIP(hipMemcpyAsync(h_changed, changed, 4, hipMemcpyDeviceToHost, s));
         MICV_HIP(hipStreamSynchronize(s));
         if (!*h_changed) break;
