@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
                                                                 float *__restrict__ corners,
                                                                 int cstride,
                                                                 uint8_t *__restrict__ flag) {
-    constexpr int TW = 64, TH = 16, DMAX = DT > 0 ? DT : 16;
+    constexpr int TW = 64, TH = DT > 0 ? 32 : 16, DMAX = DT > 0 ? DT : 16;  // taller tiles re-fetch less halo
     const int d = DT > 0 ? DT : d_rt;
     __shared__ float T[(TH + 2 * DMAX) * (TW + 2 * DMAX + 1)];
     __shared__ float RM[(TH + 2 * DMAX) * TW];
@@ -366,9 +366,9 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
     int32_t *idx = c.take<int32_t>(cap);
     static const bool force_scan = getenv("MICV_NMS_SCAN") != nullptr;
     if (min_distance <= 16 && !force_scan) {
-        const dim3 grid(cdiv(cols, 64), cdiv(rows, 16));
 #define MICV_NMS(DT)                                                                             \
-    harris_nms_tiled_kernel<DT><<<grid, 256, 0, s>>>(resp, (int)(rstride / 4), rows, cols,         \
+    harris_nms_tiled_kernel<DT><<<dim3(cdiv(cols, 64), cdiv(rows, (DT) > 0 ? 32 : 16)), 256, 0, s>>>(     \
+        resp, (int)(rstride / 4), rows, cols,                                                     \
                                                      threshold, min_distance, corners,             \
                                                      (int)(cstride / 4), flag)
         switch (min_distance) {
