@@ -142,3 +142,13 @@ def c5():
 
 ms = wall(lambda: (c5(), torch.cuda.synchronize()), iters=10)
 line("C5 chain 3840x2160: Harris + corner list + keypoints + LK(5 levels) at corners", ms, 2160 * 3840, 26.6 + 12 + 12 + 9)
+
+# the standalone pyramid / warp entry points (a4-a6) at 1080p
+ms = timeit(lambda: pyr.pyrDown(P, ctx=ctx))
+line("pyr::pyrDown 1080p", ms, 1080 * 1920, 4 * 0.25 + 4 * 0.25)
+small = pyr.pyrDown(P, ctx=ctx)
+ms = timeit(lambda: pyr.pyrUp(P, ctx=ctx))
+line("pyr::pyrUp 1080p -> 2160p", ms, 4 * 1080 * 1920, 4 * 0.25 + 4)
+du = torch.full_like(P, 2.3); dv = torch.full_like(P, -1.7)
+ms = timeit(lambda: lk.warp(P, du, dv, ctx=ctx))
+line("lk::warp 1080p", ms, 1080 * 1920, 16)
