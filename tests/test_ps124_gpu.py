@@ -356,3 +356,34 @@ def test_c5_4k_harris_keypoints_lk(M):
     fu, fv = eu[inner[:, 0], inner[:, 1]], ev[inner[:, 0], inner[:, 1]]
     # the checker edges bias LK at the corners themselves (the oracle gives (2.99, -2.55) here)
     assert abs(np.median(fu) - 3.0) < 0.3 and abs(np.median(fv) + 2.0) < 0.75
+
+
+def test_pitched_views_all_families(M):
+    """cv::Mat ROIs are non-continuous: every entry point takes a byte stride.  Inputs here are column
+    slices of wider buffers (row pitch != cols * elem)."""
+    harris, stereo, hough, synth = M
+    rows, cols = 70, 90
+    big = dev(np.zeros((rows, cols + 38), np.float32))
+    img = synth.checkerboard(rows, cols, 10, seed=4)
+    view = big[:, 19:19 + cols]
+    view.copy_(dev(img))
+    assert not view.is_contiguous()
+    egx, egy = orc.sobel(img, 3, 1.0)
+    gx, gy = harris.getGradients(view, 3)
+    assert np.array_equal(host(gx), egx) and np.array_equal(host(gy), egy)
+    bigx, bigy = torch.zeros_like(big), torch.zeros_like(big)
+    vx, vy = bigx[:, 5:5 + cols], bigy[:, 7:7 + cols]
+    vx.copy_(gx), vy.copy_(gy)
+    assert np.array_equal(host(harris.getCornerResponse(vx, vy, 5, 1.5, 0.04)),
+                          orc.harris_response(egx, egy, 5, 1.5, 0.04))
+    left, right, _ = synth.stereo_pair(9, rows, cols)
+    bl, br = torch.zeros_like(big), torch.zeros_like(big)
+    vl, vr = bl[:, 3:3 + cols], br[:, 30:30 + cols]
+    vl.copy_(dev(left)), vr.copy_(dev(right))
+    assert np.array_equal(host(stereo.disparitySSD(vl, vr, 3, -20, 0)), orc.disparity_ssd(left, right, 3, -20, 0))
+    mask, _, _ = synth.hough_mask(rows, cols, n_lines=3, radii=(10,))
+    bm = dev(np.zeros((rows, cols + 21), np.uint8))
+    vm = bm[:, 11:11 + cols]
+    vm.copy_(dev(mask))
+    assert np.array_equal(host(hough.houghLinesAccumulate(vm, 1, 1)), orc.hough_lines(mask, 1, 1))
+    assert np.array_equal(host(hough.houghCirclesAccumulate(vm, 10)), orc.hough_circles(mask, 10))
