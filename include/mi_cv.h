@@ -270,6 +270,9 @@ int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
 int micv_generate_edge_dev(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t stride,
                            int gauss_size, double gauss_sigma, double low_thresh, double high_thresh,
                            uint8_t *edges, size_t estride, micv_stream stream);
+int micv_generate_edge_host(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t stride,
+                            int gauss_size, double gauss_sigma, double low_thresh,
+                            double high_thresh, uint8_t *edges, size_t estride);
 
 /* --------------------------- ps4: descriptor matching ----------- */
 
@@ -280,11 +283,16 @@ int micv_generate_edge_dev(micv_ctx *ctx, const uint8_t *src, int rows, int cols
 int micv_bf_knn2_dev(micv_ctx *ctx, const float *query, int nq, size_t qstride, const float *train,
                      int nt, size_t tstride, int dim, int32_t *idx2, float *dist2,
                      micv_stream stream);
+int micv_bf_knn2_host(micv_ctx *ctx, const float *query, int nq, size_t qstride, const float *train,
+                      int nt, size_t tstride, int dim, int32_t *idx2, float *dist2);
 /* The ratio test of Solution.cpp:180-184: keep query q when dist0 < ratio * dist1.  matches_qt
  * [cap][2] = (queryIdx, trainIdx) in query order, distances [cap]; *count (device) = number kept. */
 int micv_bf_ratio_filter_dev(micv_ctx *ctx, const int32_t *idx2, const float *dist2, int nq,
                              double ratio, int32_t *matches_qt, float *distances, int64_t cap,
                              int64_t *count, micv_stream stream);
+int micv_bf_ratio_filter_host(micv_ctx *ctx, const int32_t *idx2, const float *dist2, int nq,
+                              double ratio, int32_t *matches_qt, float *distances, int64_t cap,
+                              int64_t *count);
 
 /* ----------------------------------- ps7: motion history ----- */
 
@@ -295,13 +303,20 @@ int micv_mhi_frame_difference_dev(micv_ctx *ctx, const uint8_t *f1, const uint8_
                                   int cols, size_t stride, double thresh, int blur_size,
                                   double blur_sigma, uint8_t *diff, size_t dstride,
                                   micv_stream stream);
+int micv_mhi_frame_difference_host(micv_ctx *ctx, const uint8_t *f1, const uint8_t *f2, int rows,
+                                   int cols, size_t stride, double thresh, int blur_size,
+                                   double blur_sigma, uint8_t *diff, size_t dstride);
 /* thresholdDifference / AbsThreshold<uint8_t>, ps7_cpp/lib/MotionHistory.cu:17-48. */
 int micv_mhi_threshold_dev(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t sstride,
                            double thresh, uint8_t *dst, size_t dstride, micv_stream stream);
+int micv_mhi_threshold_host(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t sstride,
+                            double thresh, uint8_t *dst, size_t dstride);
 /* mhi::calcMotionHistory -> motionHistoryKernel, MotionHistory.cu:52-83: in place,
  * history = mask == 1 ? tau : max(history - 1, 0). */
 int micv_mhi_update_dev(micv_ctx *ctx, uint8_t *history, size_t hstride, const uint8_t *mask,
                         size_t mstride, int rows, int cols, int tau, micv_stream stream);
+int micv_mhi_update_host(micv_ctx *ctx, uint8_t *history, size_t hstride, const uint8_t *mask,
+                         size_t mstride, int rows, int cols, int tau);
 
 #ifdef __cplusplus
 }

@@ -110,6 +110,13 @@ SIGNATURES = {
     "micv_mhi_frame_difference_dev": (i32, [vp, vp, vp, i32, i32, sz, f64, i32, f64, vp, sz, vp]),
     "micv_mhi_threshold_dev": (i32, [vp, vp, i32, i32, sz, f64, vp, sz, vp]),
     "micv_mhi_update_dev": (i32, [vp, vp, sz, vp, sz, i32, i32, i32, vp]),
+    # host-pointer flavours of the "next" rows
+    "micv_generate_edge_host": (i32, [vp, vp, i32, i32, sz, i32, f64, f64, f64, vp, sz]),
+    "micv_bf_knn2_host": (i32, [vp, vp, i32, sz, vp, i32, sz, i32, vp, vp]),
+    "micv_bf_ratio_filter_host": (i32, [vp, vp, vp, i32, f64, vp, vp, i64, vp]),
+    "micv_mhi_frame_difference_host": (i32, [vp, vp, vp, i32, i32, sz, f64, i32, f64, vp, sz]),
+    "micv_mhi_threshold_host": (i32, [vp, vp, i32, i32, sz, f64, vp, sz]),
+    "micv_mhi_update_host": (i32, [vp, vp, sz, vp, sz, i32, i32, i32]),
 }
 
 MISSING = []

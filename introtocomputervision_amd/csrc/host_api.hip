@@ -367,4 +367,112 @@ int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
     return MICV_OK;
 }
 
+// ---- host-pointer flavours of the "next" rows --------------------------
+
+int micv_generate_edge_host(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t stride,
+                            int gauss_size, double gauss_sigma, double low_thresh,
+                            double high_thresh, uint8_t *edges, size_t estride) {
+    HOST_PROLOGUE("micv_generate_edge_host");
+    MICV_REQUIRE(src && edges && rows > 0 && cols > 0 && stride >= (size_t)cols && estride >= (size_t)cols,
+                 "micv_generate_edge_host: bad argument");
+    DevBuf ds((size_t)rows * cols), de((size_t)rows * cols);
+    MICV_ALLOC_OK(ds); MICV_ALLOC_OK(de);
+    MICV_TRY(up2d(ds.p, src, stride, (size_t)cols, rows, s));
+    MICV_TRY(micv_generate_edge_dev(ctx, ds.as<uint8_t>(), rows, cols, cols, gauss_size, gauss_sigma,
+                                    low_thresh, high_thresh, de.as<uint8_t>(), cols, s));
+    MICV_TRY(down2d(edges, estride, de.p, (size_t)cols, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_bf_knn2_host(micv_ctx *ctx, const float *query, int nq, size_t qstride, const float *train,
+                      int nt, size_t tstride, int dim, int32_t *idx2, float *dist2) {
+    HOST_PROLOGUE("micv_bf_knn2_host");
+    MICV_REQUIRE(query && train && idx2 && dist2 && nq > 0 && nt >= 2 && dim > 0 &&
+                     stride_ok(qstride, dim, 4) && stride_ok(tstride, dim, 4),
+                 "micv_bf_knn2_host: bad argument");
+    const size_t rb = (size_t)dim * 4;
+    DevBuf dq(rb * nq), dt(rb * nt), di((size_t)nq * 8), dd((size_t)nq * 8);
+    MICV_ALLOC_OK(dq); MICV_ALLOC_OK(dt); MICV_ALLOC_OK(di); MICV_ALLOC_OK(dd);
+    MICV_TRY(up2d(dq.p, query, qstride, rb, nq, s));
+    MICV_TRY(up2d(dt.p, train, tstride, rb, nt, s));
+    MICV_TRY(micv_bf_knn2_dev(ctx, dq.as<float>(), nq, rb, dt.as<float>(), nt, rb, dim, di.as<int32_t>(),
+                              dd.as<float>(), s));
+    MICV_HIP(hipMemcpyAsync(idx2, di.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipMemcpyAsync(dist2, dd.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_bf_ratio_filter_host(micv_ctx *ctx, const int32_t *idx2, const float *dist2, int nq,
+                              double ratio, int32_t *matches_qt, float *distances, int64_t cap,
+                              int64_t *count) {
+    HOST_PROLOGUE("micv_bf_ratio_filter_host");
+    MICV_REQUIRE(idx2 && dist2 && count && nq > 0 && cap >= 0 && (cap == 0 || (matches_qt && distances)),
+                 "micv_bf_ratio_filter_host: bad argument");
+    DevBuf di((size_t)nq * 8), dd((size_t)nq * 8), dm((size_t)cap * 8 + 8), dl((size_t)cap * 4 + 8), dn(8);
+    MICV_ALLOC_OK(di); MICV_ALLOC_OK(dd); MICV_ALLOC_OK(dm); MICV_ALLOC_OK(dl); MICV_ALLOC_OK(dn);
+    MICV_HIP(hipMemcpyAsync(di.p, idx2, (size_t)nq * 8, hipMemcpyHostToDevice, s));
+    MICV_HIP(hipMemcpyAsync(dd.p, dist2, (size_t)nq * 8, hipMemcpyHostToDevice, s));
+    MICV_TRY(micv_bf_ratio_filter_dev(ctx, di.as<int32_t>(), dd.as<float>(), nq, ratio, dm.as<int32_t>(),
+                                      dl.as<float>(), cap, dn.as<int64_t>(), s));
+    MICV_HIP(hipMemcpyAsync(count, dn.p, 8, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    const int64_t n = *count < cap ? *count : cap;
+    if (n > 0) {
+        MICV_HIP(hipMemcpy(matches_qt, dm.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+        MICV_HIP(hipMemcpy(distances, dl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    return MICV_OK;
+}
+
+int micv_mhi_frame_difference_host(micv_ctx *ctx, const uint8_t *f1, const uint8_t *f2, int rows,
+                                   int cols, size_t stride, double thresh, int blur_size,
+                                   double blur_sigma, uint8_t *diff, size_t dstride) {
+    HOST_PROLOGUE("micv_mhi_frame_difference_host");
+    MICV_REQUIRE(f1 && f2 && diff && rows > 0 && cols > 0 && stride >= (size_t)cols && dstride >= (size_t)cols,
+                 "micv_mhi_frame_difference_host: bad argument");
+    const size_t n = (size_t)rows * cols;
+    DevBuf d1(n), d2(n), dd(n);
+    MICV_ALLOC_OK(d1); MICV_ALLOC_OK(d2); MICV_ALLOC_OK(dd);
+    MICV_TRY(up2d(d1.p, f1, stride, (size_t)cols, rows, s));
+    MICV_TRY(up2d(d2.p, f2, stride, (size_t)cols, rows, s));
+    MICV_TRY(micv_mhi_frame_difference_dev(ctx, d1.as<uint8_t>(), d2.as<uint8_t>(), rows, cols, cols, thresh,
+                                           blur_size, blur_sigma, dd.as<uint8_t>(), cols, s));
+    MICV_TRY(down2d(diff, dstride, dd.p, (size_t)cols, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_mhi_threshold_host(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t sstride,
+                            double thresh, uint8_t *dst, size_t dstride) {
+    HOST_PROLOGUE("micv_mhi_threshold_host");
+    MICV_REQUIRE(src && dst && rows > 0 && cols > 0 && sstride >= (size_t)cols && dstride >= (size_t)cols,
+                 "micv_mhi_threshold_host: bad argument");
+    const size_t n = (size_t)rows * cols;
+    DevBuf ds(n), dd(n);
+    MICV_ALLOC_OK(ds); MICV_ALLOC_OK(dd);
+    MICV_TRY(up2d(ds.p, src, sstride, (size_t)cols, rows, s));
+    MICV_TRY(micv_mhi_threshold_dev(ctx, ds.as<uint8_t>(), rows, cols, cols, thresh, dd.as<uint8_t>(), cols, s));
+    MICV_TRY(down2d(dst, dstride, dd.p, (size_t)cols, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_mhi_update_host(micv_ctx *ctx, uint8_t *history, size_t hstride, const uint8_t *mask,
+                         size_t mstride, int rows, int cols, int tau) {
+    HOST_PROLOGUE("micv_mhi_update_host");
+    MICV_REQUIRE(history && mask && rows > 0 && cols > 0 && hstride >= (size_t)cols && mstride >= (size_t)cols,
+                 "micv_mhi_update_host: bad argument");
+    const size_t n = (size_t)rows * cols;
+    DevBuf dh(n), dm(n);
+    MICV_ALLOC_OK(dh); MICV_ALLOC_OK(dm);
+    MICV_TRY(up2d(dh.p, history, hstride, (size_t)cols, rows, s));
+    MICV_TRY(up2d(dm.p, mask, mstride, (size_t)cols, rows, s));
+    MICV_TRY(micv_mhi_update_dev(ctx, dh.as<uint8_t>(), cols, dm.as<uint8_t>(), cols, rows, cols, tau, s));
+    MICV_TRY(down2d(history, hstride, dh.p, (size_t)cols, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
 }  // extern "C"

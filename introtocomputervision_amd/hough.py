@@ -77,6 +77,17 @@ def findLocalMaxima(accumulator, numPeaks, threshold, ctx=None):
 def generateEdge(image, gaussianSize, gaussianSigma, lowerThreshold, upperThreshold, ctx=None):
     """sol::generateEdge (ps1_cpp/src/Solution.cpp:21-47) on a 2-D uint8 CUDA tensor -> 255/0 edge
     mask (Gaussian blur + Canny, aperture 3)."""
+    if isinstance(image, np.ndarray):  # host-pointer entry point
+        img = np.ascontiguousarray(image, np.uint8)
+        if img.ndim != 2:
+            raise ValueError("image: need a 2-D uint8 array")
+        out = np.empty_like(img)
+        from .match import _host_ctx
+        check(lib.micv_generate_edge_host((ctx or _host_ctx()).handle, img.ctypes.data, img.shape[0], img.shape[1],
+                                          img.strides[0], int(gaussianSize), float(gaussianSigma),
+                                          float(lowerThreshold), float(upperThreshold), out.ctypes.data,
+                                          out.strides[0]))
+        return out
     import torch
     if not (B.is_dev(image) and image.is_cuda and image.dim() == 2 and image.dtype == torch.uint8
             and image.stride(1) == 1):

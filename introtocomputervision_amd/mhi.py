@@ -2,6 +2,7 @@
 frame differencing and motion-history images, device tensors (uint8 CUDA, single channel)."""
 from ._capi import check, lib
 from .lk import _ctx_for
+from .match import _host_ctx
 
 
 def _chk(t, name):
@@ -19,6 +20,18 @@ def _stream(t):
 def frameDifference(f1, f2, thresh, blurSize=3, blurSigma=1.0, ctx=None):
     """mhi::frameDifference (MotionHistory.cpp:26-77) -> {0,1} uint8 mask (blurSize = the side of the
     reference's square cv::Size)."""
+    import numpy as np
+    if isinstance(f1, np.ndarray):  # host-pointer entry point
+        a1 = np.ascontiguousarray(f1, np.uint8)
+        a2 = np.ascontiguousarray(f2, np.uint8)
+        if a1.ndim != 2 or a1.shape != a2.shape:
+            raise ValueError("f1 / f2: need 2-D uint8 arrays of equal shape")
+        out = np.empty_like(a1)
+        check(lib.micv_mhi_frame_difference_host((ctx or _host_ctx()).handle, a1.ctypes.data, a2.ctypes.data,
+                                                 a1.shape[0], a1.shape[1], a1.strides[0], float(thresh),
+                                                 int(blurSize), float(blurSigma), out.ctypes.data,
+                                                 out.strides[0]))
+        return out
     import torch
     _chk(f1, "f1")
     _chk(f2, "f2")
@@ -34,6 +47,13 @@ def frameDifference(f1, f2, thresh, blurSize=3, blurSigma=1.0, ctx=None):
 
 def thresholdDifference(src, thresh, ctx=None):
     """thresholdDifference (MotionHistory.cu:27-48) -> {0,1} uint8."""
+    import numpy as np
+    if isinstance(src, np.ndarray):
+        a1 = np.ascontiguousarray(src, np.uint8)
+        out = np.empty_like(a1)
+        check(lib.micv_mhi_threshold_host((ctx or _host_ctx()).handle, a1.ctypes.data, a1.shape[0], a1.shape[1],
+                                          a1.strides[0], float(thresh), out.ctypes.data, out.strides[0]))
+        return out
     import torch
     _chk(src, "src")
     rows, cols = src.shape
@@ -45,6 +65,16 @@ def thresholdDifference(src, thresh, ctx=None):
 
 def calcMotionHistory(history, binaryMask, tau, ctx=None):
     """mhi::calcMotionHistory (MotionHistory.cpp:79-96): updates `history` in place."""
+    import numpy as np
+    if isinstance(history, np.ndarray):
+        if history.dtype != np.uint8 or history.ndim != 2 or not history.flags.c_contiguous:
+            raise ValueError("history: need a contiguous 2-D uint8 array (updated in place)")
+        m = np.ascontiguousarray(binaryMask, np.uint8)
+        if m.shape != history.shape:
+            raise ValueError("history and binaryMask differ in size")
+        check(lib.micv_mhi_update_host((ctx or _host_ctx()).handle, history.ctypes.data, history.strides[0],
+                                       m.ctypes.data, m.strides[0], history.shape[0], history.shape[1], int(tau)))
+        return history
     _chk(history, "history")
     _chk(binaryMask, "binaryMask")
     if tuple(history.shape) != tuple(binaryMask.shape):

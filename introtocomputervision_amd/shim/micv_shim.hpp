@@ -329,3 +329,66 @@ inline void disparityNCorr(const Mat &left, const Mat &right, const size_t windo
     micv_shim::disparity(true, left, right, windowRad, minDisparity, maxDisparity, 0, disparity);
 }
 }  // namespace serial
+
+// ---- "next" rows -----------------------------------------------------------------
+
+namespace mhi {  // ProblemSets/ps7_cpp/include/MotionHistory.h:7-28 (single-channel CV_8U frames)
+using micv_shim::Mat;
+// `blurSize` is the side of the reference's square cv::Size (MotionHistory.h:14).
+inline void frameDifference(const Mat &f1, const Mat &f2, const double thresh, Mat &diff,
+                            const int blurSize = 3, const double blurSigma = 1.0) {
+    micv_shim::require(f1.type() == micv_shim::U8 && f2.type() == micv_shim::U8 && f1.rows == f2.rows &&
+                           f1.cols == f2.cols && f1.step == f2.step,
+                       "mhi::frameDifference: two CV_8UC1 frames of one size expected");
+    Mat out(f1.rows, f1.cols, micv_shim::U8);
+    micv_shim::check(micv_mhi_frame_difference_host(micv_shim::context(), f1.ptr<uint8_t>(), f2.ptr<uint8_t>(),
+                                                    f1.rows, f1.cols, f1.step, thresh, blurSize, blurSigma,
+                                                    out.ptr<uint8_t>(), out.step));
+    diff = out;
+}
+inline void calcMotionHistory(Mat &history, const Mat &binaryMask, const int tau) {
+    micv_shim::require(history.type() == micv_shim::U8 && binaryMask.type() == micv_shim::U8 &&
+                           history.rows == binaryMask.rows && history.cols == binaryMask.cols,
+                       "mhi::calcMotionHistory: CV_8UC1 history and mask of one size expected");
+    micv_shim::check(micv_mhi_update_host(micv_shim::context(), history.ptr<uint8_t>(), history.step,
+                                          binaryMask.ptr<uint8_t>(), binaryMask.step, history.rows,
+                                          history.cols, tau));
+}
+}  // namespace mhi
+
+namespace sol {
+using micv_shim::Mat;
+// sol::generateEdge, ps1_cpp/src/Solution.cpp:21-47, with Config::EdgeDetect spelled out
+// (gaussianSize, gaussianSigma, lowerThreshold, upperThreshold; Sobel aperture 3).
+inline void generateEdge(const Mat &input, const int gaussianSize, const double gaussianSigma,
+                         const double lowerThreshold, const double upperThreshold, Mat &output) {
+    micv_shim::require(input.type() == micv_shim::U8, "sol::generateEdge: CV_8UC1 expected");
+    Mat out(input.rows, input.cols, micv_shim::U8);
+    micv_shim::check(micv_generate_edge_host(micv_shim::context(), input.ptr<uint8_t>(), input.rows, input.cols,
+                                             input.step, gaussianSize, gaussianSigma, lowerThreshold,
+                                             upperThreshold, out.ptr<uint8_t>(), out.step));
+    output = out;
+}
+// The matching step of Solution::siftHelper, ps4_cpp/src/Solution.cpp:172-184:
+// BFMatcher::knnMatch(d1, d2, raw, 2) + `m[0].distance < ratio * m[1].distance`.
+// goodMatches receives (queryIdx, trainIdx) pairs, distances the matching m[0].distance.
+inline void matchDescriptors(const Mat &d1, const Mat &d2, const double ratio,
+                             std::vector<std::pair<int, int>> &goodMatches, std::vector<float> &distances) {
+    micv_shim::require(d1.type() == micv_shim::F32 && d2.type() == micv_shim::F32 && d1.cols == d2.cols &&
+                           d2.rows >= 2,
+                       "sol::matchDescriptors: CV_32FC1 descriptor matrices of one width expected");
+    std::vector<int32_t> idx2(static_cast<size_t>(d1.rows) * 2), m(static_cast<size_t>(d1.rows) * 2);
+    std::vector<float> dist2(static_cast<size_t>(d1.rows) * 2), dd(static_cast<size_t>(d1.rows));
+    micv_shim::check(micv_bf_knn2_host(micv_shim::context(), d1.ptr<float>(), d1.rows, d1.step, d2.ptr<float>(),
+                                       d2.rows, d2.step, d1.cols, idx2.data(), dist2.data()));
+    int64_t n = 0;
+    micv_shim::check(micv_bf_ratio_filter_host(micv_shim::context(), idx2.data(), dist2.data(), d1.rows, ratio,
+                                               m.data(), dd.data(), d1.rows, &n));
+    goodMatches.clear();
+    distances.clear();
+    for (int64_t i = 0; i < n; i++) {
+        goodMatches.emplace_back(m[2 * i], m[2 * i + 1]);
+        distances.push_back(dd[i]);
+    }
+}
+}  // namespace sol

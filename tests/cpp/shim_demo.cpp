@@ -92,6 +92,28 @@ int main(int argc, char **argv) {
         for (auto &p : peaks) { pf.push_back(p.first); pf.push_back(p.second); }
         save(dir + "/peaks.u32", pf.data(), pf.size() * 4);
         save(dir + "/acc.i32", acc);
+
+        // ---- next rows: ps1 edge front-end, ps7 motion history, ps4 matching ----------------------
+        Mat img8 = load(dir + "/img8.u8", rows, cols, micv_shim::U8);
+        Mat edges;
+        sol::generateEdge(img8, 5, 1.4, 30, 90, edges);
+        save(dir + "/edges.u8", edges);
+        Mat f2 = load(dir + "/img8b.u8", rows, cols, micv_shim::U8);
+        Mat diff;
+        mhi::frameDifference(img8, f2, 20, diff, 5, 1.5);
+        save(dir + "/mhi_diff.u8", diff);
+        Mat hist = load(dir + "/hist.u8", rows, cols, micv_shim::U8);
+        mhi::calcMotionHistory(hist, diff, 25);
+        save(dir + "/mhi_hist.u8", hist);
+        Mat d1 = load(dir + "/desc1.f32", 60, 128, micv_shim::F32);
+        Mat d2 = load(dir + "/desc2.f32", 75, 128, micv_shim::F32);
+        std::vector<std::pair<int, int>> good;
+        std::vector<float> gdist;
+        sol::matchDescriptors(d1, d2, 0.75, good, gdist);
+        std::vector<int> gf;
+        for (auto &g : good) { gf.push_back(g.first); gf.push_back(g.second); }
+        save(dir + "/good.i32", gf.data(), gf.size() * 4);
+        save(dir + "/good_dist.f32", gdist.data(), gdist.size() * 4);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "shim_demo failed: %s\n", e.what());
         return 1;

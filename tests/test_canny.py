@@ -54,3 +54,4 @@ def test_generate_edge_gpu(rows, cols, gs, sigma, lo, hi):
     # the edge mask feeds the Hough accumulator unchanged
     acc = hough.houghLinesAccumulate(got, 1, 1)
     assert int(acc.sum().item()) == int((exp > 0).sum()) * 180
+    assert np.array_equal(hough.generateEdge(img, gs, sigma, lo, hi), exp)  # host-pointer flavour

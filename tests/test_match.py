@@ -65,3 +65,8 @@ def test_knn_ratio_gpu(nq, nt, dim):
     em, ed = oracle_ratio(eidx, edist, 0.75)
     m, d = match.ratioTest(idx, dist, 0.75)
     assert np.array_equal(m.cpu().numpy(), em) and np.array_equal(d.cpu().numpy(), ed)
+    if nq <= 2000:  # host-pointer flavours
+        hi, hd = match.knnMatch2(q, t)
+        assert np.array_equal(hi, eidx) and np.array_equal(hd, edist)
+        hm, hdd = match.ratioTest(hi, hd, 0.75)
+        assert np.array_equal(hm, em) and np.array_equal(hdd, ed)

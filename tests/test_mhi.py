@@ -48,3 +48,9 @@ def test_mhi_gpu_matches_oracle(rows, cols, ksize, sigma, thr):
     assert np.array_equal(hist.cpu().numpy(), eh)
     assert np.array_equal(mhi.thresholdDifference(d1, thr).cpu().numpy(), orc.mhi_threshold(f1, thr))
     assert np.array_equal(mhi.energyFromHistory(hist).cpu().numpy(), (eh > 0).astype(np.uint8))
+    # host-pointer flavours (numpy in, numpy out)
+    assert np.array_equal(mhi.frameDifference(f1, f2, thr, ksize, sigma), exp)
+    assert np.array_equal(mhi.thresholdDifference(f1, thr), orc.mhi_threshold(f1, thr))
+    hh = np.random.default_rng(1).integers(0, 256, (rows, cols)).astype(np.uint8)
+    mhi.calcMotionHistory(hh, exp, 25)
+    assert np.array_equal(hh, eh)

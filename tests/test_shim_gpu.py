@@ -34,8 +34,17 @@ def test_shim_matches_oracle(tmp_path):
     chk = synth.checkerboard(rows, cols, square=20, seed=0x5EED0001)
     left, right, _ = synth.stereo_pair(0x5EED0002, rows, cols)
     mask, lines, _ = synth.hough_mask(rows, cols, n_lines=4, radii=())
+    import test_canny as tc
+    import test_match as tm
+    img8 = tc.scene(rows, cols, seed=3)
+    img8b = np.ascontiguousarray(np.roll(img8, 5, axis=1))
+    hist = np.random.default_rng(2).integers(0, 256, (rows, cols)).astype(np.uint8)
+    desc1, desc2 = tm.descriptors(60, 75, 128, 9)
+    desc2[5] = desc2[3]
+    desc1[0] = desc2[3]
     for name, a in (("prev.f32", prev), ("next.f32", nxt), ("chk.f32", chk), ("left.f32", left),
-                    ("right.f32", right), ("mask.u8", mask)):
+                    ("right.f32", right), ("mask.u8", mask), ("img8.u8", img8), ("img8b.u8", img8b),
+                    ("hist.u8", hist), ("desc1.f32", desc1), ("desc2.f32", desc2)):
         a.tofile(os.path.join(d, name))
     r = subprocess.run([exe, d, str(rows), str(cols)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -65,3 +74,12 @@ def test_shim_matches_oracle(tmp_path):
     acc = orc.hough_lines(mask, 1, 1)
     assert np.array_equal(rd("acc.i32", np.int32, acc.shape), acc)
     assert np.array_equal(rd("peaks.u32", np.uint32).reshape(-1, 2), orc.hough_peaks(acc, 10, 40))
+    # next rows through the shim's host-pointer path
+    assert np.array_equal(rd("edges.u8", np.uint8, (rows, cols)), tc.oracle_edges(img8, 5, 1.4, 30, 90))
+    ediff = orc.mhi_frame_difference(img8, img8b, 20, 5, 1.5)
+    assert np.array_equal(rd("mhi_diff.u8", np.uint8, (rows, cols)), ediff)
+    assert np.array_equal(rd("mhi_hist.u8", np.uint8, (rows, cols)), orc.mhi_update(hist, ediff, 25))
+    eidx, edist = tm.oracle_knn2(desc1, desc2)
+    em, ed = tm.oracle_ratio(eidx, edist, 0.75)
+    assert len(em) > 0 and np.array_equal(rd("good.i32", np.int32).reshape(-1, 2), em)
+    assert np.array_equal(rd("good_dist.f32", np.float32), ed)
