@@ -51,10 +51,45 @@ struct StereoArgs {
     float init_best;  // +inf, or 5e6 with MICV_STEREO_MIN_SSD_5E6 (SSD); 0 for NCC
     int8_t *disp;
     int dstride;
+    // NCC: window energy of `right`, E[y][s - s_lo] = sum over the window whose LAST column is
+    // (unclamped) column s, every column clamped on its own -- written by stereo_energy_kernel
+    const float *energy;
+    int e_width, s_lo;
 };
 
 // LDS budget of the staged right-image strip: DCH disparities per chunk -> SPAN columns per row.
 constexpr int ST_DCH_DEFAULT = 64;
+
+// NCC: the energy of the right-image window depends on (row, last window column) only, not on the
+// pair (x, d) that selects it, so it is summed once per position here -- same terms, same order as
+// the search loop would (column sums top -> bottom from +0, then the systolic left -> right chain) --
+// instead of once per (pixel, disparity).  One wave = 64 consecutive positions x RPW rows; the first
+// 2R lanes only feed the chain.
+template <int R, int RPW>
+__global__ __launch_bounds__(256) void stereo_energy_kernel(StereoArgs a, float *__restrict__ E) {
+    constexpr int W = 2 * R + 1, STEPS = RPW + 2 * R, OUTW = 64 - 2 * R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ys = blockIdx.y * (4 * RPW) + wave * RPW;
+    if (ys >= a.rows) return;
+    const bool full = a.wcols == W;
+    const int sp = a.s_lo - 2 * R + blockIdx.x * OUTW + lane;  // position of this lane's column
+    const int xr = clampi(sp, 0, a.cols - 1);
+    float ringB[W];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        const int yy = clampi(ys - R + s, 0, a.rows - 1);
+        const float rv = a.right[(size_t)yy * a.stride + xr];
+        ringB[s % W] = rv * rv;
+        if (s >= 2 * R) {
+            float csb = 0.f;
+#pragma unroll
+            for (int k = 0; k < W; k++) csb += ringB[(s - 2 * R + k) % W];
+            const float accb = systolic_sum<W>(csb, full);
+            const int y = ys + s - 2 * R, e = sp - a.s_lo;
+            if (lane >= 2 * R && y < a.rows && e < a.e_width) E[(size_t)y * a.e_width + e] = accb;
+        }
+    }
+}
 
 template <int R, int MODE, int RPW, int ST_DCH = ST_DCH_DEFAULT>
 __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
@@ -65,7 +100,9 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
     const bool full = a.wcols == W;
     const int ys = blockIdx.y * (4 * RPW) + wave * RPW;
     if (ys >= a.rows) return;  // whole wave; waves never synchronise with each other
-    float *Rs = st_lds + wave * (STEPS * ST_SPAN);
+    constexpr int ESTEPS = MODE == ST_NCC ? RPW : 0;  // staged rows of the window-energy field
+    float *Rs = st_lds + wave * ((STEPS + ESTEPS) * ST_SPAN);
+    float *Es = Rs + STEPS * ST_SPAN;
     const int x_base = blockIdx.x * OUTW - R;
     const int xc = x_base + lane;  // window column of this lane (unclamped)
     const int xl = clampi(xc, 0, a.cols - 1);
@@ -124,6 +161,18 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
                     Rs[s * ST_SPAN + i] = rr[clampi(x_base + d0 + i, 0, a.cols - 1)];
             }
         }
+        if (MODE == ST_NCC) {
+#pragma unroll
+            for (int j = 0; j < RPW; j++) {
+                const float *er = a.energy + (size_t)(ys + j < a.rows ? ys + j : a.rows - 1) * a.e_width;
+#pragma unroll
+                for (int h = 0; h < (ST_SPAN + 63) / 64; h++) {
+                    const int i = lane + 64 * h;
+                    if (ST_SPAN % 64 == 0 || i < ST_SPAN)
+                        Es[j * ST_SPAN + i] = er[clampi(x_base + d0 + i - a.s_lo, 0, a.e_width - 1)];
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int d1 = d0 + ST_DCH - 1 < a.max_d ? d0 + ST_DCH - 1 : a.max_d;
@@ -131,13 +180,11 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
             const float *rcol = Rs + lane + (d - d0);
             const bool d_ok = MODE != ST_SSD_SERIAL || (d >= d_lo && d <= d_hi);
             acc_t ring[W];
-            float ringB[W];
 #pragma unroll
             for (int s = 0; s < STEPS; s++) {
                 const float rv = rcol[s * ST_SPAN];
                 if (MODE == ST_NCC) {
                     ring[s % W] = (acc_t)(Lv[s] * rv);
-                    ringB[s % W] = rv * rv;
                 } else {
                     const float diff = Lv[s] - rv;
                     const float sq = diff * diff;
@@ -151,10 +198,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
                     for (int k = MODE == ST_NCC ? 0 : 1; k < W; k++) cs += ring[(s - 2 * R + k) % W];
                     const acc_t acc = systolic_sum<W>(cs, full);
                     if (MODE == ST_NCC) {
-                        float csb = 0.f;
-#pragma unroll
-                        for (int k = 0; k < W; k++) csb += ringB[(s - 2 * R + k) % W];
-                        const float accb = systolic_sum<W>(csb, full);
+                        const float accb = Es[j * ST_SPAN + lane + (d - d0)];  // window energy of `right`
                         const float nc = (float)acc / sqrtf(AT[j] * accb);  // DisparityNCorr.cu:106
                         if (nc > (float)best[j]) {                          // :108
                             best[j] = (acc_t)nc;
@@ -231,9 +275,19 @@ static int launch_stereo(hipStream_t s, const StereoArgs &a, int r) {
     const long waves8 = (long)cdiv(a.cols, 64 - 2 * (r < 1 ? 1 : r)) * cdiv(a.rows, 8);
     const long waves10 = (long)cdiv(a.cols, 64 - 2 * (r < 1 ? 1 : r)) * cdiv(a.rows, 10);
     const bool ten = force_rpw ? force_rpw == 10 : (waves8 > 4096 && (waves10 + 4095) / 4096 < (waves8 + 4095) / 4096);
+    // NCC also stages RPW rows of the energy field: 32-disparity chunks keep 3-4 blocks per CU
 #define MICV_ST_LAUNCH(RR, RPW)                                                                    \
-    stereo_kernel<RR, MODE, RPW><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256,    \
-                                   4 * (RPW + 2 * RR) * (64 + ST_DCH_DEFAULT) * sizeof(float), s>>>(a)
+    do {                                                                                           \
+        if (MODE == ST_NCC) {                                                                      \
+            stereo_energy_kernel<RR, RPW><<<dim3(cdiv(a.e_width, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256, 0, s>>>( \
+                a, const_cast<float *>(a.energy));                                                 \
+            stereo_kernel<RR, MODE, RPW, 32><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256, \
+                                              4 * (2 * RPW + 2 * RR) * (64 + 32) * sizeof(float), s>>>(a); \
+        } else {                                                                                   \
+            stereo_kernel<RR, MODE, RPW><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256, \
+                                           4 * (RPW + 2 * RR) * (64 + ST_DCH_DEFAULT) * sizeof(float), s>>>(a); \
+        }                                                                                          \
+    } while (0)
 #define MICV_ST_CASE(RR)                                                                      \
     case RR:                                                                                  \
         if (ten) MICV_ST_LAUNCH(RR, 10); else MICV_ST_LAUNCH(RR, 8);                          \
@@ -269,6 +323,17 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
     a.wcols = (flags & MICV_STEREO_COLS_2R) ? 2 * rad : 2 * rad + 1;
     a.init_best = ncc ? 0.f : ((flags & MICV_STEREO_MIN_SSD_5E6) ? 5000000.f : INFINITY);
     a.disp = disp; a.dstride = (int)dstride;
+    a.energy = nullptr; a.e_width = 0; a.s_lo = 0;
+    if (ncc && rad >= 1 && rad <= 10) {
+        // positions a window's last column can take: lanes reach from -R to past cols + R (whole
+        // 64-lane strips), shifted by every disparity
+        const int outw = 64 - 2 * rad;
+        a.s_lo = -rad + min_d;
+        a.e_width = (int)cdiv(cols, outw) * outw + 64 + (max_d - min_d);
+        void *scratch;
+        MICV_TRY(ctx->reserve(Carver::need((size_t)rows * a.e_width, 4), &scratch));
+        a.energy = static_cast<const float *>(scratch);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (ncc) return launch_stereo<ST_NCC>(s, a, rad);
     if (flags & MICV_STEREO_SERIAL) return launch_stereo<ST_SSD_SERIAL>(s, a, rad);
