@@ -232,10 +232,12 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         const float *tp = T + r * TS + c;
         float m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k <= 2 * d; k++) m = fmaxf(m, tp[k]);
+        for (int k = 0; k <= 2 * DMAX; k++)
+            if (DT > 0 || k <= 2 * d) m = fmaxf(m, tp[k]);
         int n = 0;
 #pragma unroll
-        for (int k = 0; k <= 2 * d; k++) n += tp[k] == m ? 1 : 0;
+        for (int k = 0; k <= 2 * DMAX; k++)
+            if (DT > 0 || k <= 2 * d) n += tp[k] == m ? 1 : 0;
         RM[i] = m;
         RN[i] = n;
     }
@@ -247,10 +249,12 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         if (y >= rows) break;
         float M = -INFINITY;
 #pragma unroll
-        for (int k = 0; k <= 2 * d; k++) M = fmaxf(M, RM[(ry + k) * TW + c]);
+        for (int k = 0; k <= 2 * DMAX; k++)
+            if (DT > 0 || k <= 2 * d) M = fmaxf(M, RM[(ry + k) * TW + c]);
         int N = 0;
 #pragma unroll
-        for (int k = 0; k <= 2 * d; k++) N += RM[(ry + k) * TW + c] == M ? RN[(ry + k) * TW + c] : 0;
+        for (int k = 0; k <= 2 * DMAX; k++)
+            if (DT > 0 || k <= 2 * d) N += RM[(ry + k) * TW + c] == M ? RN[(ry + k) * TW + c] : 0;
         const float v = T[(ry + d) * TS + c + d];
         const bool keep = (double)v >= threshold && v == M && N == 1;
         corners[(size_t)y * cstride + x] = keep ? v : 0.f;

@@ -547,11 +547,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     const int c = tid & (TW - 1), r0 = RPT * (tid / TW);
     float Sxx[RPT], Sxy[RPT], Syy[RPT], Sxt[RPT], Syt[RPT];
     constexpr int RPI = 4 * (NT / 64);  // gradient rows one row-pass iteration covers
+    constexpr int SWEEP_UNROLL = NT >= 512 ? 1 : 4;  // 512 threads: rolled sweeps keep the 128-VGPR budget
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int grp = lane >> 2, c0 = 4 * grp;
         // sweep A: Ix^2, Ix*Iy, Iy^2  (windows of Ix, Iy read once)
-#pragma unroll(NT >= 512 ? 1 : 4)
+#pragma unroll SWEEP_UNROLL
         for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
             const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
@@ -572,7 +573,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         __syncthreads();
         if (a.stop_after == 42) return;
         // sweep B: Ix*It, Iy*It
-#pragma unroll(NT >= 512 ? 1 : 4)
+#pragma unroll SWEEP_UNROLL
         for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
             const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
