@@ -464,15 +464,25 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // image (inside this region) of prev and of the warped image with the reflected
             // values, so the marching code below serves border tiles too.  Gradient cells outside
             // the image come out as garbage here and are overwritten by the reflected fill.
-            for (int i = tid; i < RH * RW; i += NT) {
-                const int ly = i / RW, lx = i - ly * RW;
+            // The ring is at most two region rows (gy = -1, gy = rows) and two region columns
+            // (gx = -1, gx = cols): walk those 2 RW + 2 RH cells, not the whole region.
+            for (int n = tid; n < 2 * RW + 2 * RH; n += NT) {
+                int ly, lx;
+                if (n < 2 * RW) {
+                    ly = (n < RW ? -1 : rows) - ry0;
+                    lx = n < RW ? n : n - RW;
+                } else {
+                    const int m = n - 2 * RW;
+                    lx = (m < RH ? -1 : cols) - rx0;
+                    ly = m < RH ? m : m - RH;
+                }
+                if ((unsigned)ly >= (unsigned)RH || (unsigned)lx >= (unsigned)RW) continue;
                 const int gy = ry0 + ly, gx = rx0 + lx;
-                const bool oy = gy == -1 || gy == rows, ox = gx == -1 || gx == cols;
-                if ((oy || ox) && gy >= -1 && gy <= rows && gx >= -1 && gx <= cols) {
+                if (gy >= -1 && gy <= rows && gx >= -1 && gx <= cols) {
                     const int sy = reflect101(gy, rows) - ry0, sx = reflect101(gx, cols) - rx0;
                     if ((unsigned)sy < (unsigned)RH && (unsigned)sx < (unsigned)RW) {
-                        P[i] = P[sy * PS + sx];
-                        Wp[i] = Wp[sy * PS + sx];
+                        P[ly * PS + lx] = P[sy * PS + sx];
+                        Wp[ly * PS + lx] = Wp[sy * PS + sx];
                     }
                 }
             }
@@ -528,15 +538,28 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // window sums below run the same straight-line code as interior tiles.  Cells whose
             // source lies outside this tile feed only outputs that are outside the image.
             __syncthreads();
-            for (int i = tid; i < GH * GW; i += NT) {
-                const int qy = i / GW, qx = i - qy * GW;
+            // Walk only the cells outside the image: whole gradient rows above / below it, then the
+            // left / right columns of the rows in between.
+            auto fill = [&](int qy, int qx) {
                 const int gy = y0 - R + qy, gx = x0 - R + qx;
-                if ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols) continue;
                 const int sy = reflect101(gy, rows) - (y0 - R), sx = reflect101(gx, cols) - (x0 - R);
                 const bool ok = (unsigned)sy < (unsigned)GH && (unsigned)sx < (unsigned)GW;
                 Gx[qy * GS + qx] = ok ? Gx[sy * GS + sx] : 0.f;
                 Gy[qy * GS + qx] = ok ? Gy[sy * GS + sx] : 0.f;
                 Gt[qy * GS + qx] = ok ? Gt[sy * GS + sx] : 0.f;
+            };
+            const int rt = clampi(-(y0 - R), 0, GH), rb = clampi(rows - (y0 - R), rt, GH);
+            const int cl = clampi(-(x0 - R), 0, GW), cr = clampi(cols - (x0 - R), cl, GW);
+            const int n_full = (rt + GH - rb) * GW, side = cl + GW - cr;
+            for (int i = tid; i < n_full; i += NT) {
+                const int r = i / GW, qx = i - r * GW;
+                fill(r < rt ? r : rb + (r - rt), qx);
+            }
+            if (side > 0) {
+                for (int i = tid; i < (rb - rt) * 16; i += NT) {
+                    const int qy = rt + (i >> 4);
+                    for (int cc = i & 15; cc < side; cc += 16) fill(qy, cc < cl ? cc : cr + (cc - cl));
+                }
             }
         }
     }
