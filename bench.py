@@ -2,16 +2,25 @@
 """bench.py -- Mpix/s through 5-level pyramidal Lucas-Kanade on 1080p frame pairs.
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no WORLD_SIZE in the environment this process is only a LAUNCHER: before torch
+or the GPU is touched it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a child, relays rank 0's JSON line and exits with the child's return code (the driver's own
+torchrun launch sets WORLD_SIZE and runs the ranks directly).
 
 One "step" = one pass of the hot path (lk::calcOpticalFlowPyr, 5 levels, win 15) over one
 batch of --pairs synthetic 1080p frame pairs that already sit in HBM.  Frame pairs are
 independent, so N GPUs = N ranks each with its own batch (weak scaling, no data-path
-collective).  Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the byte model.
+collective; RCCL carries only the timing barrier / MAX).  `--mode rowshard` splits every pair
+by rows over the ranks instead (coarse-flow halo exchange per level, strong scaling).
+Rank 0 prints ONE JSON line.  See DESIGN.md "Measurement" for the byte model.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,7 +28,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ROWS, COLS, WIN, LEVELS = 1080, 1920, 15, 5
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_COPY_GBS = 6290.0      # same guide: 6.29 TB/s measured float4 copy
+VALU_PEAK_TFLOPS = 157.3   # same guide: peak FP32 vector (packed); 78.65 unpacked
+SIMDS, CLOCK_GHZ, CYC_PER_VALU = 1024, 2.4, 4   # 256 CUs x 4 SIMDs; one wave64 VALU instruction = 4 cycles
+# Irreducible arithmetic of one level pixel: five 15-tap separable window sums
+# (150 FMA), two Sobel pairs + averages + It (~22), five products, pyrUp of two fields (20),
+# bilinear warp (~12), 2x2 solve (~20) = ~230 FMA-equivalents = 460 flop.
+USEFUL_FLOP_PER_LEVEL_PX = 460.0
 
 
 def level_dims(rows, cols, levels):
@@ -41,16 +57,18 @@ def level0_kernel_bytes_pair(rows, cols, levels):
     return 16 * px[0] + (8 * px[1] if levels > 1 else 0)
 
 
-def cpu_baseline(sample_pairs):
+def cpu_baseline(sample_pairs, hip_uv=None):
     """The CPU oracle (a plain-C port of the reference algorithm, single thread -- the
-    reference's own loops are single-threaded, OpticalFlow.cpp:85-103) timed on this host."""
+    reference's own loops are single-threaded, OpticalFlow.cpp:85-103) timed on this host.
+    `hip_uv(i)` returns the HIP path's (u, v) of bench pair i as numpy arrays: the oracle's result
+    on the same pair is compared bit for bit (the checker's only other use here)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
     import _oracle as orc
     from introtocomputervision_amd import synth
     pairs = [synth.lk_pair(0x5EED0005 + i, ROWS, COLS, 3, -2) for i in range(sample_pairs)]
     t0 = time.perf_counter()
-    for p, n in pairs:
-        orc.lk_flow_pyr(p, n, WIN, LEVELS)
+    res = [orc.lk_flow_pyr(p, n, WIN, LEVELS) for p, n in pairs]
     dt = time.perf_counter() - t0
     out = {
         "value": sample_pairs * ROWS * COLS / dt / 1e6,
@@ -59,6 +77,19 @@ def cpu_baseline(sample_pairs):
         "kind": "port",
         "sample": f"{sample_pairs} of the same 1080p pairs, 5 levels, win 15, oracle/liboracle.so, {dt:.1f} s",
     }
+    parity = None
+    if hip_uv is not None:
+        parity = {"pairs_compared": 0, "bit_exact": True, "mismatching_values": 0}
+        for i, (eu, ev) in enumerate(res):
+            got = hip_uv(i)
+            if got is None:
+                break
+            bad = int(np.count_nonzero(got[0] != eu) + np.count_nonzero(got[1] != ev))
+            parity["pairs_compared"] += 1
+            parity["mismatching_values"] += bad
+            parity["bit_exact"] = parity["bit_exact"] and bad == 0
+        if parity["pairs_compared"] == 0:
+            parity = None
     # The same oracle over all host cores: one frame pair per thread -- the ctypes
     # call releases the GIL and pairs are independent, so this is the data-parallel CPU ceiling.
     ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(), 32)
@@ -71,10 +102,10 @@ def cpu_baseline(sample_pairs):
         dt = time.perf_counter() - t0
         out["all_cores"] = {"value": ncores * ROWS * COLS / dt / 1e6, "unit": "Mpix/s", "cores": ncores,
                             "sample": f"{ncores} pairs, one per thread, {dt:.1f} s"}
-    return out
+    return out, parity
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -83,16 +114,90 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=6, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--inflight", type=int, default=2, help="passes in flight (contexts/streams), pairs mode")
+    ap.add_argument("--lk-groups", type=int, default=0,
+                    help="stream groups the library splits a batch into (0 = its default, 2); the PMC "
+                         "passes of tools/profile.sh use 1 so a level-0 dispatch covers the whole batch")
+    ap.add_argument("--sustained-s", type=float, default=2.0,
+                    help="seconds of back-to-back steps for the `sustained` field (0 = skip)")
     ap.add_argument("--mode", choices=["pairs", "rowshard"], default="pairs",
                     help="pairs: every rank owns whole frame pairs (default, weak scaling, no data-path "
                          "collective); rowshard: every pair is split by rows over all ranks with a "
                          "coarse-flow halo exchange per level (strong scaling, RCCL point-to-point)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no kernels and no GPU: exercises launcher, rendezvous, barrier, MAX over ranks "
+                         "and the JSON line (value is null); what the CPU tests run")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a CHILD process (this
+    process has not imported torch, so nothing here has touched a GPU), relay rank 0's JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    relayed = False
+    for line in proc.stdout.splitlines():
+        if line.startswith("{") and '"metric"' in line:
+            print(line)
+            relayed = True
+        else:
+            print(line, file=sys.stderr)
+    if proc.returncode == 0 and not relayed:
+        print("[bench] the ranks exited 0 without a JSON line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def valu_roofline(lvl0_ms, pairs_per_launch):
+    """VALU axis of the dominant kernel: wave-VALU instructions per launch from the committed
+    rocprofv3 PMC pass (profiles/traffic.json, SQ_INSTS_VALU), the issue time they need on
+    1024 SIMDs at 4 cycles each, and the useful arithmetic rate against the FP32 vector peak."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    insts = tj.get("valu_insts_per_launch")
+    if not insts or tj.get("pairs_per_launch") != pairs_per_launch:
+        return None
+    px = ROWS * COLS * pairs_per_launch
+    issue_us = insts * CYC_PER_VALU / (SIMDS * CLOCK_GHZ * 1e3)
+    useful_tflops = USEFUL_FLOP_PER_LEVEL_PX * px / (lvl0_ms * 1e-3) / 1e12
+    return {
+        "wave_valu_insts_per_launch": insts,
+        "valu_insts_per_output_px": insts * 64 / px,
+        "issue_bound_us": issue_us,
+        "frac_of_issue_bound": issue_us / (lvl0_ms * 1e3),
+        "useful_flop_per_px": USEFUL_FLOP_PER_LEVEL_PX,
+        "useful_tflops": useful_tflops,
+        "peak_tflops": VALU_PEAK_TFLOPS,
+        "frac": useful_tflops / VALU_PEAK_TFLOPS,
+        "source": f"profiles/traffic.json ({tj.get('profile', 'rocprofv3 --pmc SQ_INSTS_VALU')}, not this run)",
+    }
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    if args.backend == "gloo" and not args.dry_run:
+        sys.exit("[bench] --backend gloo is for --dry-run only: the hot path needs a GPU (no CPU fallback)")
 
     import numpy as np
     import torch
-    from introtocomputervision_amd import lk, synth
-    from introtocomputervision_amd._capi import Context
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,16 +209,57 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_run:
+            dist.init_process_group(args.backend if args.backend == "gloo" or torch.cuda.is_available() else "gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; running {n_gpus}", file=sys.stderr)
+    B = args.pairs
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def max_and_all(dt, device):
+        """MAX over ranks of a wall time + every rank's own value."""
+        if dist is None:
+            return dt, [dt]
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), [float(x.item()) for x in every]
+
+    if args.dry_run:
+        # launcher / rendezvous / reduction path only: no kernels, nothing measured
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pass
+        barrier()
+        dt, every = max_and_all(time.perf_counter() - t0, torch.device("cpu"))
+        if rank == 0:
+            print(json.dumps({
+                "metric": "Mpix/s (LK 5-level pyramid, 1080p pairs)", "value": None, "unit": "Mpix/s",
+                "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                "higher_is_better": True, "scaling": "weak" if args.mode == "pairs" else "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "none (dry run: no kernels launched)",
+                "config": {"workload": "dry run", "ranks": dist.get_world_size() if dist is not None else 1,
+                           "backend": args.backend, "per_rank_s": every},
+            }))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    from introtocomputervision_amd import lk, synth
+    from introtocomputervision_amd._capi import Context
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
     # Synthetic C2/C4 frame pairs (SURVEY 8d), distinct per rank, resident in HBM.
-    B = args.pairs
     prev_h = np.empty((B, ROWS, COLS), np.float32)
     next_h = np.empty((B, ROWS, COLS), np.float32)
     for i in range(B):
@@ -123,30 +269,21 @@ def main():
     u = torch.empty_like(prev)
     v = torch.empty_like(prev)
     ctx = Context(local_rank)
+    ctx.set_lk_groups(args.lk_groups)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     if args.mode == "rowshard":
         # All ranks hold the same pairs (replicated inputs); each computes its row band of every pair.
-        from introtocomputervision_amd import pyr, shard
+        from introtocomputervision_amd import shard
         if dist is not None:
             for t in (prev, nxt):
                 dist.broadcast(t, src=0)
-        plan = shard.RowShardPlan(ROWS, COLS, LEVELS, n_gpus)
-        level_fn = shard.gpu_level_fn(ctx, WIN)
-
-        class _NoComm:
-            def exchange(self, *a):
-                pass
-        comm = shard.DistComm(rank, n_gpus) if dist is not None else _NoComm()
-        a0, b0 = plan.band(0, rank)
+        runner = shard.RowShardBatch(ctx, ROWS, COLS, LEVELS, WIN, B, rank, n_gpus,
+                                     comm=shard.DistComm(rank, n_gpus) if dist is not None else None)
+        a0, b0 = runner.band0
 
         def step():
-            for i in range(B):
-                pp = pyr.makeGaussianPyramid(prev[i], LEVELS, ctx=ctx)
-                npyr = pyr.makeGaussianPyramid(nxt[i], LEVELS, ctx=ctx)
-                bu, bv = shard.lk_pyr_band(pp, npyr, plan, rank, WIN, level_fn, comm)
-                u[i, a0:b0] = bu[a0:b0]
-                v[i, a0:b0] = bv[a0:b0]
+            runner.run(prev, nxt, u, v, stream)
     else:
         # `--inflight F` batches in flight: step i runs on context / HIP stream / output buffers
         # i mod F (a context owns its scratch arena and aux streams, so passes on different contexts
@@ -157,6 +294,7 @@ def main():
         lanes = [(ctx, torch.cuda.current_stream(dev), (u, v))]
         for _ in range(1, F):
             lanes.append((Context(local_rank), torch.cuda.Stream(dev), (torch.empty_like(prev), torch.empty_like(prev))))
+            lanes[-1][0].set_lk_groups(args.lk_groups)
         counter = [0]
 
         def step():
@@ -164,38 +302,56 @@ def main():
             counter[0] += 1
             lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=c, out=out, stream=st.cuda_stream)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    def timed(steps):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return max_and_all(time.perf_counter() - t0, dev)
 
     ctx.warmup(stream)
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_rank = timed(args.steps)
+
+    # the same code path for >= --sustained-s seconds back to back: clocks under sustained load
+    sustained = None
+    if args.sustained_s > 0:
+        n_s = max(args.steps, int(math.ceil(args.sustained_s / (dt / args.steps))))
+        dts, _ = timed(n_s)
+        sustained = {"seconds": dts, "steps": n_s, "ms_per_step": dts / n_s * 1e3,
+                     "ratio_to_short_run": (dts / n_s) / (dt / args.steps)}
 
     # the same K steps one at a time on one context (no overlap between passes): reported beside
     # `value` so the effect of keeping two passes in flight is visible
     serial_ms = None
-    if args.mode == "pairs" and max(1, args.inflight) > 1:
+    single_pair_ms = None
+    if args.mode == "pairs":
+        if max(1, args.inflight) > 1:
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
+            torch.cuda.synchronize()
+            serial_ms = (time.perf_counter() - ts) / args.steps * 1e3
+        # BASELINE configs[1] read literally: ONE 1080p pair per call, calls back to back
+        p1, n1, o1 = prev[:1], nxt[:1], (torch.empty_like(prev[:1]), torch.empty_like(prev[:1]))
+        for _ in range(5):
+            lk.calcOpticalFlowPyrBatch(p1, n1, WIN, LEVELS, ctx=ctx, out=o1, stream=stream)
         torch.cuda.synchronize()
         ts = time.perf_counter()
-        for _ in range(args.steps):
-            lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
+        n1p = max(50, args.steps * 4)
+        for _ in range(n1p):
+            lk.calcOpticalFlowPyrBatch(p1, n1, WIN, LEVELS, ctx=ctx, out=o1, stream=stream)
         torch.cuda.synchronize()
-        serial_ms = (time.perf_counter() - ts) / args.steps * 1e3
+        single_pair_ms = (time.perf_counter() - ts) / n1p * 1e3
+        lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
+        torch.cuda.synchronize()
 
     # sanity of what was measured: known translation comes back (not part of the timing)
     if args.mode == "rowshard":
@@ -213,18 +369,14 @@ def main():
         # The throughput pass above runs the library default (the batch split into two stream
         # groups whose launches overlap).  The kernel roofline is taken with ONE group, so the
         # level-0 launch covers the whole batch and has the GPU to itself while it is timed.
-        saved_groups = os.environ.get("MICV_LK_GROUPS")
-        os.environ["MICV_LK_GROUPS"] = "1"
+        ctx.set_lk_groups(1)
         ctx.profile(True)
         ctx.profile_reset()
         torch.cuda.synchronize()
         for _ in range(args.steps):  # one pass at a time on one context: nothing runs beside the timed launch
             lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
         torch.cuda.synchronize()
-        if saved_groups is None:
-            del os.environ["MICV_LK_GROUPS"]
-        else:
-            os.environ["MICV_LK_GROUPS"] = saved_groups
+        ctx.set_lk_groups(args.lk_groups)
         lvl_ms = []
         for l in range(LEVELS):
             ms, n = ctx.profile_lk_level(l)
@@ -234,29 +386,40 @@ def main():
         pairs_per_launch = ctx.profile_lk_pairs() or B  # the library splits the batch into stream groups
         k_bytes = level0_kernel_bytes_pair(ROWS, COLS, LEVELS) * pairs_per_launch
         achieved = k_bytes / (lvl_ms[0] * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from rocprofv3 --pmc runs
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("pairs_per_launch") == pairs_per_launch:
                     traffic = tj.get("level0_hbm_bytes_per_launch")
+                    traffic_source = (f"profiles/traffic.json ({tj.get('profile', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}"
+                                      ", separate passes, gfx950 x2 FETCH correction; not measured in this run)")
             except Exception:
                 traffic = None
         roofline = {
-            "bound": "hbm", "kernel": "lk_level_kernel<7,COARSE> (pyramid level 0)",
+            "bound": "hbm", "kernel": ctx.lk_level_kernel_name() + " (pyramid level 0)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_measured_copy_bw": achieved / HBM_COPY_GBS, "measured_copy_bw": HBM_COPY_GBS,
+            "traffic": traffic, "traffic_source": traffic_source,
             "bytes_per_launch": k_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": lvl_ms[0],
             "level_ms": lvl_ms,
-            "note": "kernel is f32-VALU/LDS-bound (5 x 15-tap separable window sums), not HBM-bound; "
-                    "timed in a second pass of the same steps with the batch in one stream group "
-                    "(whole batch per launch, no concurrent launches)",
+            "valu": valu_roofline(lvl_ms[0], pairs_per_launch),
+            "binding_axis": "valu",
+            "note": "HBM figures as the contract asks; the kernel itself is f32-VALU-issue bound "
+                    "(5 x 15-tap separable window sums) -- see `valu`.  Timed in a second pass of the "
+                    "same steps with the batch in one stream group (whole batch per launch, no "
+                    "concurrent launches)",
         }
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and n_gpus == 1 and args.cpu_pairs > 0:
-        cpu = cpu_baseline(args.cpu_pairs)
+        def hip_uv(i):
+            if args.mode != "pairs" or i >= B:
+                return None
+            return u[i].cpu().numpy(), v[i].cpu().numpy()
+        cpu, parity = cpu_baseline(args.cpu_pairs, hip_uv)
 
     if rank == 0:
         total_px = (n_gpus if args.mode == "pairs" else 1) * B * args.steps * ROWS * COLS
@@ -279,10 +442,18 @@ def main():
                             f"(C4 per-GPU share), {LEVELS}-level pyramid, win {WIN}, device-resident",
                 "pairs_per_gpu_per_step": B, "levels": LEVELS, "win": WIN,
                 "parallelism": f"pair-dp{n_gpus}" if args.mode == "pairs" else f"row-shard{n_gpus} (coarse-flow halo, p2p)",
+                "mode": args.mode,
+                "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
                 "flow_check": {"median_u": um, "median_v": vm, "ok": ok},
+                "parity_1080p": None if parity is None else parity["bit_exact"],
+                "parity_1080p_detail": parity,
                 "passes_in_flight": max(1, args.inflight) if args.mode == "pairs" else 1,
                 "one_pass_at_a_time_ms_per_step": serial_ms,
+                "single_pair_ms": single_pair_ms,
+                "single_pair_Mpix_s": None if not single_pair_ms else ROWS * COLS / single_pair_ms / 1e3,
             },
+            "sustained": sustained,
             "algorithmic_GBps_pipeline": value * 1e6 * algorithmic_bytes_pair(ROWS, COLS, LEVELS)
                                          / (ROWS * COLS) / 1e9,
             "roofline": roofline,

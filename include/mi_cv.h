@@ -48,6 +48,20 @@ int micv_ctx_create(int device, micv_ctx **out);
 void micv_ctx_destroy(micv_ctx *ctx);
 /* Bytes of device scratch currently held by the context. */
 size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
+/* Execution options of a context.  None of them changes a result: they select between kernels
+ * that produce identical bits (tests compare the alternatives) or how a batch is scheduled.
+ * The library reads NO environment variables. */
+#define MICV_OPT_LK_STREAM_GROUPS  1 /* stream groups a batch is split into: 0 = default (2), 1..4 */
+#define MICV_OPT_LK_FORCE_GENERIC  2 /* LK through the generic multi-launch kernels */
+#define MICV_OPT_LK_NARROW_TILES   3 /* win-15 level kernel: 256-thread tiles instead of 512 */
+#define MICV_OPT_SOBEL_GENERIC     4 /* Sobel through the generic row / column passes */
+#define MICV_OPT_HARRIS_GENERIC    5 /* Harris response: one-thread-per-pixel kernel */
+#define MICV_OPT_NMS_SCAN          6 /* Harris NMS: scanning kernel instead of the separable one */
+#define MICV_OPT_STEREO_ROWS       7 /* rows per stereo strip: 0 = automatic, 8 or 10 */
+#define MICV_OPT_LK_GRAPH          8 /* batch-1 pyramid as a captured hipGraph: 0 = default (on), -1 = off */
+#define MICV_OPT_COUNT             9
+int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
+int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value);
 
 /* ---------------------------------------------------------------- common/ (a17) ---- */
 /* common::warmup, common/src/CudaWarmup.cu:5-19 (10 blocks x 64 threads). */
@@ -71,11 +85,12 @@ int micv_profile_enable(micv_ctx *ctx, int on);
 int micv_profile_reset(micv_ctx *ctx);
 int micv_profile_lk_level(micv_ctx *ctx, int level, double *total_ms, int64_t *launches);
 /* Frame pairs covered by each profiled level launch: micv_lk_flow_pyr_batch_dev splits a batch
- * into groups that run on separate streams (env MICV_LK_GROUPS, default 2); the events bracket
+ * into groups that run on separate streams (MICV_OPT_LK_STREAM_GROUPS, default 2); the events bracket
  * the launches of the first group. */
 int micv_profile_lk_pairs(micv_ctx *ctx, int *pairs_per_launch);
-/* In-kernel phase stamps of the fused LK level kernel (diagnostic builds of a timing study, never
- * on in a timed run): while enabled, wave 0 of every workgroup adds the s_memtime ticks it spent
+/* In-kernel phase stamps of the fused LK level kernel.  Compiled in only with -DMICV_DIAG (a
+ * diagnostic build for timing studies; the default build returns MICV_EUNSUPPORTED when asked to
+ * enable them): while enabled, wave 0 of every workgroup adds the s_memtime ticks it spent
  * in each phase to 16 device counters ([0..5] interior tiles, [8..13] border tiles: stage, pyrUp
  * rows, warp, gradients, window sums, solve).  Reads the counters into ticks16 (may be NULL),
  * then enables/disables and zeroes them.  Synchronises the device. */

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmicv.so")
+# MICV_LIB (python side only) points the binding at another build of the same ABI, e.g. the
+# -DMICV_DIAG flavour tools/phase_pmc.sh makes; the library itself reads no environment variables.
+LIB_PATH = os.environ.get("MICV_LIB") or os.path.join(_HERE, "libmicv.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -29,6 +31,9 @@ f64 = C.c_double
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
 STEREO_COLS_2R, STEREO_MIN_SSD_5E6 = 1, 2
+# micv_ctx_set_option (include/mi_cv.h): none of these changes a result
+(OPT_LK_STREAM_GROUPS, OPT_LK_FORCE_GENERIC, OPT_LK_NARROW_TILES, OPT_SOBEL_GENERIC, OPT_HARRIS_GENERIC,
+ OPT_NMS_SCAN, OPT_STEREO_ROWS, OPT_LK_GRAPH) = range(1, 9)
 
 
 class MicvError(RuntimeError):
@@ -45,6 +50,8 @@ SIGNATURES = {
     "micv_ctx_create": (i32, [i32, C.POINTER(vp)]),
     "micv_ctx_destroy": (None, [vp]),
     "micv_ctx_scratch_bytes": (sz, [vp]),
+    "micv_ctx_set_option": (i32, [vp, i32, i32]),
+    "micv_ctx_get_option": (i32, [vp, i32, C.POINTER(i32)]),
     "micv_profile_enable": (i32, [vp, i32]),
     "micv_profile_reset": (i32, [vp]),
     "micv_profile_lk_level": (i32, [vp, i32, C.POINTER(f64), C.POINTER(i64)]),
@@ -154,6 +161,22 @@ class Context:
 
     def scratch_bytes(self):
         return int(lib.micv_ctx_scratch_bytes(self._h))
+
+    def set_option(self, option, value):
+        check(lib.micv_ctx_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = i32()
+        check(lib.micv_ctx_get_option(self._h, int(option), C.byref(v)))
+        return v.value
+
+    def set_lk_groups(self, n):
+        """Stream groups a batch of pairs is split into (0 = library default)."""
+        self.set_option(OPT_LK_STREAM_GROUPS, n)
+
+    def lk_level_kernel_name(self, win=15):
+        narrow = self.get_option(OPT_LK_NARROW_TILES)
+        return f"lk_level_kernel<{win // 2},COARSE,{256 if narrow or win != 15 else 512}>"
 
     def profile(self, on=True):
         check(lib.micv_profile_enable(self._h, 1 if on else 0))

@@ -5,8 +5,12 @@
 #   objects are compiled in parallel, then linked; only amdhip64 is linked (no torch).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="$here/../libmicv.so"
+# MICV_OUT=libmicv_diag.so EXTRA_HIPCC_FLAGS=-DMICV_DIAG builds the diagnostic flavour (in-kernel
+# phase stamps, MICV_LK_STOP) beside the product library, with its own object directory.
+name="${MICV_OUT:-libmicv.so}"
+out="$here/../$name"
 obj="$here/.obj"
+[[ "$name" != "libmicv.so" ]] && obj="$here/.obj_${name%.so}"
 mkdir -p "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 #   -fno-gpu-flush-denormals-to-zero  keep f32 subnormals, as the host oracle does.

@@ -90,12 +90,15 @@ int sobel_taps(int ksize, int order, Taps *out);
 // The context: device ordinal + one growable scratch arena.
 struct micv_ctx {
     int device = 0;
+    int opt[MICV_OPT_COUNT] = {0};  // micv_ctx_set_option
     void *arena = nullptr;
     size_t arena_bytes = 0;
     void *pinned = nullptr;  // small pinned staging block for counts
     // Per-launch timing of the pyramid-level kernels (micv_profile_*): event pairs per level.
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof[16];
+    bool prof_open[16] = {false};
+    static constexpr size_t kMaxProfPairs = 4096;  // per level; recording stops there until a reset
     unsigned long long *stamps = nullptr;  // 16 device counters (micv_profile_lk_phases)
     int prof_pairs = 0;                    // frame pairs per profiled level launch
     // Device blocks of the host-pointer entry points (host_api.hip), kept between calls so that a

@@ -92,10 +92,19 @@ int micv_ctx::reserve(size_t bytes, void **out) {
 
 int micv_ctx::prof_begin(int level, hipStream_t s) {
     if (!profile) return MICV_OK;
+    if (prof[level].size() >= kMaxProfPairs) {  // bounded: stop recording, keep what there is
+        prof_open[level] = false;
+        return MICV_OK;
+    }
     hipEvent_t a, b;
     MICV_HIP(hipEventCreate(&a));
-    MICV_HIP(hipEventCreate(&b));
+    hipError_t e = hipEventCreate(&b);
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(a);
+        MICV_HIP(e);
+    }
     prof[level].emplace_back(a, b);
+    prof_open[level] = true;
     MICV_HIP(hipEventRecord(a, s));
     return MICV_OK;
 }
@@ -119,7 +128,8 @@ int micv_ctx::join(hipStream_t s, int n) {
     return MICV_OK;
 }
 int micv_ctx::prof_end(int level, hipStream_t s) {
-    if (!profile) return MICV_OK;
+    if (!profile || !prof_open[level]) return MICV_OK;
+    prof_open[level] = false;
     MICV_HIP(hipEventRecord(prof[level].back().second, s));
     return MICV_OK;
 }
@@ -207,6 +217,23 @@ void micv_ctx_destroy(micv_ctx *ctx) {
 
 size_t micv_ctx_scratch_bytes(const micv_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
 
+int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
+    MICV_REQUIRE(ctx != nullptr, "micv_ctx_set_option: ctx is null");
+    MICV_REQUIRE(option >= 1 && option < MICV_OPT_COUNT, "micv_ctx_set_option: unknown option %d", option);
+    if (option == MICV_OPT_LK_STREAM_GROUPS)
+        MICV_REQUIRE(value >= 0 && value <= 4, "micv_ctx_set_option: stream groups must be 0..4");
+    if (option == MICV_OPT_STEREO_ROWS)
+        MICV_REQUIRE(value == 0 || value == 8 || value == 10, "micv_ctx_set_option: stereo rows must be 0, 8 or 10");
+    ctx->opt[option] = value;
+    return MICV_OK;
+}
+int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value) {
+    MICV_REQUIRE(ctx && value, "micv_ctx_get_option: null argument");
+    MICV_REQUIRE(option >= 1 && option < MICV_OPT_COUNT, "micv_ctx_get_option: unknown option %d", option);
+    *value = ctx->opt[option];
+    return MICV_OK;
+}
+
 int micv_profile_enable(micv_ctx *ctx, int on) {
     MICV_REQUIRE(ctx != nullptr, "micv_profile_enable: ctx is null");
     ctx->profile = on != 0;
@@ -215,6 +242,12 @@ int micv_profile_enable(micv_ctx *ctx, int on) {
 
 int micv_profile_lk_phases(micv_ctx *ctx, int enable, uint64_t *ticks16) {
     MICV_REQUIRE(ctx != nullptr, "micv_profile_lk_phases: ctx is null");
+#ifndef MICV_DIAG
+    if (enable) {
+        micv::set_error("micv_profile_lk_phases: phase stamps need a -DMICV_DIAG build of libmicv.so");
+        return MICV_EUNSUPPORTED;
+    }
+#endif
     MICV_HIP(hipSetDevice(ctx->device));
     if (ticks16) {
         for (int i = 0; i < 16; i++) ticks16[i] = 0;
@@ -287,8 +320,16 @@ int micv_timer_create(micv_timer **out) {
         micv::set_error("micv_timer_create: host allocation failed");
         return MICV_ENOMEM;
     }
-    MICV_HIP(hipEventCreate(&t->start));
-    MICV_HIP(hipEventCreate(&t->stop));
+    hipError_t e = hipEventCreate(&t->start);
+    if (e == hipSuccess) {
+        e = hipEventCreate(&t->stop);
+        if (e != hipSuccess) (void)hipEventDestroy(t->start);
+    }
+    if (e != hipSuccess) {
+        micv::set_error("micv_timer_create: hipEventCreate failed: %s", hipGetErrorString(e));
+        delete t;
+        return MICV_EHIP;
+    }
     *out = t;
     return MICV_OK;
 }

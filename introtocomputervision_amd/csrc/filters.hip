@@ -135,8 +135,7 @@ __global__ __launch_bounds__(256) void filter_cols_lds_kernel(const float *__res
 int launch_filter_rows(hipStream_t s, const float *src, int sstride, size_t sfield, float *dst,
                        int dstride, size_t dfield, int rows, int cols, int nfields,
                        const Taps &t) {
-    static const bool direct = getenv("MICV_FILTER_DIRECT") != nullptr;
-    if (!direct && t.n >= 5) {
+    if (t.n >= 5) {
         filter_rows_lds_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 4), nfields), 256,
                                  (size_t)4 * (256 + t.n - 1) * sizeof(float), s>>>(
             src, sstride, sfield, dst, dstride, dfield, rows, cols, t);
@@ -153,8 +152,7 @@ int launch_filter_rows(hipStream_t s, const float *src, int sstride, size_t sfie
 int launch_filter_cols(hipStream_t s, const float *src, int sstride, size_t sfield, float *dst,
                        int dstride, size_t dfield, int rows, int cols, int nfields,
                        const Taps &t) {
-    static const bool direct = getenv("MICV_FILTER_DIRECT") != nullptr;
-    if (!direct && t.n >= 5) {
+    if (t.n >= 5) {
         filter_cols_lds_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32), nfields), 256,
                                  (size_t)64 * (32 + t.n - 1) * sizeof(float), s>>>(
             src, sstride, sfield, dst, dstride, dfield, rows, cols, t);
@@ -272,7 +270,7 @@ static int launch_sobel_fused(hipStream_t s, const float *src, int rows, int col
 // cv::cuda::createSobelFilter: `if (dx == 0) kx *= scale; else ky *= scale;` then a
 // separable filter, row kernel kx, column kernel ky.
 int sobel_dev(hipStream_t s, const float *src, int rows, int cols, int sstride, int ksize,
-              float scale, float *gx, float *gy, int gstride, float *tmp) {
+              float scale, float *gx, float *gy, int gstride, float *tmp, bool force_generic) {
     Taps kx, ky;
     const size_t n = (size_t)rows * cols;
     // d/dx
@@ -280,7 +278,6 @@ int sobel_dev(hipStream_t s, const float *src, int rows, int cols, int sstride, 
         set_error("sobel: kernel size %d not supported (1,3,5,7..31 odd)", ksize);
         return MICV_EINVAL;
     }
-    static const bool force_generic = getenv("MICV_SOBEL_GENERIC") != nullptr;
     if (!force_generic) {
         if (ksize == 3) return launch_sobel_fused<3>(s, src, rows, cols, sstride, scale, gx, gy, gstride);
         if (ksize == 5) return launch_sobel_fused<5>(s, src, rows, cols, sstride, scale, gx, gy, gstride);
@@ -315,5 +312,6 @@ extern "C" int micv_sobel_dev(micv_ctx *ctx, const float *src, int rows, int col
     void *scratch;
     MICV_TRY(ctx->reserve(Carver::need((size_t)rows * cols * 2, 4), &scratch));
     return sobel_dev(static_cast<hipStream_t>(stream), src, rows, cols, (int)(sstride / 4), ksize,
-                     scale, gx, gy, (int)(gstride / 4), static_cast<float *>(scratch));
+                     scale, gx, gy, (int)(gstride / 4), static_cast<float *>(scratch),
+                     ctx->opt[MICV_OPT_SOBEL_GENERIC] != 0);
 }

@@ -325,7 +325,7 @@ int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, in
     Taps g;
     gaussian_taps(win, sigma, &g);  // cv::getGaussianKernel(win, sigma, CV_32F), Harris.cpp:61
     const int r = win / 2;
-    static const bool force_generic = getenv("MICV_HARRIS_GENERIC") != nullptr;
+    const bool force_generic = ctx->opt[MICV_OPT_HARRIS_GENERIC] != 0;
     if (!force_generic && r >= 1 && r <= 3) {
         hipStream_t st = static_cast<hipStream_t>(stream);
         const int gs = (int)(gstride / 4), rs = (int)(rstride / 4);
@@ -368,7 +368,7 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
     Carver c(scratch);
     uint8_t *flag = c.take<uint8_t>(n);
     int32_t *idx = c.take<int32_t>(cap);
-    static const bool force_scan = getenv("MICV_NMS_SCAN") != nullptr;
+    const bool force_scan = ctx->opt[MICV_OPT_NMS_SCAN] != 0;
     if (min_distance <= 16 && !force_scan) {
 #define MICV_NMS(DT)                                                                             \
     harris_nms_tiled_kernel<DT><<<dim3(cdiv(cols, 64), cdiv(rows, (DT) > 0 ? 32 : 16)), 256, 0, s>>>(     \

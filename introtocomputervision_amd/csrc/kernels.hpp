@@ -14,7 +14,7 @@ int launch_filter_cols(hipStream_t s, const float *src, int sstride, size_t sfie
 
 // Sobel pair through the two generic passes. tmp: 2*rows*cols floats.
 int sobel_dev(hipStream_t s, const float *src, int rows, int cols, int sstride, int ksize,
-              float scale, float *gx, float *gy, int gstride, float *tmp);
+              float scale, float *gx, float *gy, int gstride, float *tmp, bool force_generic = false);
 
 // dst(y,x) = src(2y+1, 2x+1), dst dims (rows/2, cols/2).
 int launch_pyr_down(hipStream_t s, const float *src, int rows, int cols, int sstride, float *dst,

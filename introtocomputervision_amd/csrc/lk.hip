@@ -170,6 +170,7 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.add_base = 1;
         a.row_begin = 0; a.row_end = R;
         a.stamps = (last && c.profile) ? ctx->stamps : nullptr;  // phase stamps: level 0 only
+        a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
         bool out_in_cur = false;
         if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
         if (level == 0) {
@@ -323,9 +324,8 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // 8-pair step on MI355X).  Groups share nothing but the read-only pyramids.
     int groups = 1;
     if (batch >= 2) {
-        const char *e = getenv("MICV_LK_GROUPS");
-        groups = e ? atoi(e) : 2;
-        groups = groups < 1 ? 1 : (groups > 4 ? 4 : groups);
+        groups = ctx->opt[MICV_OPT_LK_STREAM_GROUPS] > 0 ? ctx->opt[MICV_OPT_LK_STREAM_GROUPS] : 2;
+        groups = groups > 4 ? 4 : groups;
         if (groups > batch) groups = batch;
     }
     if (groups > 1) MICV_TRY(ctx->fork(s, groups - 1));
@@ -378,7 +378,7 @@ int micv_lk_flow_pyr_batch_dev(micv_ctx *ctx, const float *prev, const float *ne
     MICV_HIP(hipSetDevice(ctx->device));
     return lk_pyr_batch(ctx, static_cast<hipStream_t>(stream), prev, next, batch, pair_stride / 4,
                         rows, cols, (int)(stride / 4), win, levels, u, v, opair_stride / 4,
-                        (int)(ostride / 4), !getenv("MICV_FORCE_GENERIC"));
+                        (int)(ostride / 4), !ctx->opt[MICV_OPT_LK_FORCE_GENERIC]);
 }
 
 int micv_lk_flow_pyr_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
@@ -394,7 +394,7 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
     MICV_TRY(check_lk_args("micv_lk_flow", ctx, prev, next, u, v, rows, cols, stride, ostride, win));
     MICV_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (lk_fused_supports(win) && !getenv("MICV_FORCE_GENERIC")) {
+    if (lk_fused_supports(win) && !ctx->opt[MICV_OPT_LK_FORCE_GENERIC]) {
         LkLevelArgs a;
         a.rows = rows; a.cols = cols; a.batch = 1; a.win = win;
         a.prev = prev; a.next = next; a.img_stride = (int)(stride / 4); a.img_pair = 0;
@@ -403,6 +403,7 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
         a.out_u = u; a.out_v = v; a.out_stride = (int)(ostride / 4); a.out_pair = 0;
         a.add_base = 0;
         a.row_begin = 0; a.row_end = rows;
+        a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
         return launch_lk_level_fused(s, a);
     }
     void *scratch;
@@ -425,7 +426,7 @@ int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int r
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)rows * cols;
     const bool doubles = flow_u && 2 * flow_rows == rows && 2 * flow_cols == cols;
-    const bool fused = lk_fused_supports(win) && !getenv("MICV_FORCE_GENERIC");
+    const bool fused = lk_fused_supports(win) && !ctx->opt[MICV_OPT_LK_FORCE_GENERIC];
     void *scratch;
     MICV_TRY(ctx->reserve(Carver::need(n, 4) * 4 + Carver::need(lk_generic_scratch(rows, cols), 4) +
                               (flow_u ? Carver::need((size_t)flow_rows * flow_cols * 2, 4) : 0),
@@ -441,6 +442,7 @@ int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int r
         a.out_u = u; a.out_v = v; a.out_stride = (int)(ostride / 4); a.out_pair = 0;
         a.add_base = 1;
         a.row_begin = row_begin; a.row_end = row_end;
+        a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
         a.flow_pair = 0;
         if (!flow_u) {
             a.mode = LK_FLOW_NONE;

@@ -163,6 +163,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     const float *__restrict__ next = a.next + pair * a.img_pair;
     const int istride = a.img_stride;
     const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};  // Pyramids.cu:19
+#ifdef MICV_DIAG
     // wave-uniform on purpose: the running stamp then lives in SGPRs, not in a (spilled) VGPR pair
     const bool stamp_wave = a.stamps != nullptr && __builtin_amdgcn_readfirstlane(tid) < 64;
     unsigned long long t_prev = 0;
@@ -174,6 +175,11 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         t_prev = t_now;                                                      \
     }                                                                        \
     if (a.stop_after == (k)) return;
+#define MICV_STOP(k) if (a.stop_after == (k)) return;
+#else
+#define MICV_STAMP(k)
+#define MICV_STOP(k)
+#endif
 
     // ---- phase 0: stage prev (+ next / its window) and the coarse flow block -----------------
     // Interior tiles issue ALL their global loads into registers first and write LDS afterwards,
@@ -589,12 +595,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             }
         }
         __syncthreads();
-        if (a.stop_after == 41) return;
+        MICV_STOP(41)
         col_pass<C>(rb0, Sxx, g, c, r0);
         col_pass<C>(rb1, Sxy, g, c, r0);
         col_pass<C>(rb2, Syy, g, c, r0);
         __syncthreads();
-        if (a.stop_after == 42) return;
+        MICV_STOP(42)
         // sweep B: Ix*It, Iy*It
 #pragma unroll SWEEP_UNROLL
         for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
@@ -612,7 +618,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             }
         }
         __syncthreads();
-        if (a.stop_after == 43) return;
+        MICV_STOP(43)
         col_pass<C>(rb0, Sxt, g, c, r0);
         col_pass<C>(rb1, Syt, g, c, r0);
     }
@@ -640,6 +646,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     }
     MICV_STAMP(5)
 #undef MICV_STAMP
+#undef MICV_STOP
 }
 
 // Workgroup -> tile order.  (1) XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so workgroup b
@@ -779,16 +786,19 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
 }
 
 int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
-    static const int stop = [] { const char *e = getenv("MICV_LK_STOP"); return e ? atoi(e) : -1; }();
     LkLevelArgs a = a_in;
+#ifdef MICV_DIAG
+    static const int stop = [] { const char *e = getenv("MICV_LK_STOP"); return e ? atoi(e) : -1; }();
     a.stop_after = stop;
+#else
+    a.stamps = nullptr;
+#endif
     switch (a.win) {
         case 15: {
             // 512 threads per tile (4 waves per SIMD at 2 workgroups per CU) vs 256 (2 waves per SIMD)
             // Measured on MI355X (8 pairs of 1080p): 512 threads 0.377 ms per level-0 launch vs 0.406 ms,
-            // and the latency-bound coarse levels gain more.  MICV_LK_NT=256 selects the narrow form.
-            static const bool wide = [] { const char *e = getenv("MICV_LK_NT"); return !(e && atoi(e) == 256); }();
-            return wide ? launch_r<7, 512>(s, a) : launch_r<7, 256>(s, a);
+            // and the latency-bound coarse levels gain more.  MICV_OPT_LK_NARROW_TILES selects the narrow form.
+            return a.narrow ? launch_r<7, 256>(s, a) : launch_r<7, 512>(s, a);
         }
         case 7: return launch_r<3, 256>(s, a);
         case 21: return launch_r<10, 256>(s, a);  // the reference's default winSize (OpticalFlow.h:9,18)

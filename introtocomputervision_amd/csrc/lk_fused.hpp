@@ -25,11 +25,13 @@ struct LkLevelArgs {
     int add_base;  // 1: out = base + flow (OpticalFlow.cpp:161-162); 0: out = flow (:100-101)
     // Output rows [row_begin, row_end) only (row-sharded execution); 0 / rows = everything.
     int row_begin = 0, row_end = 0;
-    // Diagnostic only (micv_profile_lk_phases): when non-null, wave 0 of every workgroup adds the
-    // s_memtime ticks it spent in each phase to stamps[phase].  Null in normal runs.
+    int narrow = 0;  // MICV_OPT_LK_NARROW_TILES: 256-thread form of the win-15 kernel
+    // -DMICV_DIAG builds only (the default build compiles neither in):
+    //  * stamps (micv_profile_lk_phases): when non-null, wave 0 of every workgroup adds the
+    //    s_memtime ticks it spent in each phase to stamps[phase];
+    //  * stop_after (env MICV_LK_STOP=k, read by the diagnostic build only): leave the kernel after
+    //    phase k, so PMC counters can be attributed to phases by differencing runs -- garbage output.
     unsigned long long *stamps = nullptr;
-    // Diagnostics (env MICV_LK_STOP=k): leave the kernel after phase k, so PMC counters can be
-    // attributed to phases by differencing runs.  Results are garbage; -1 in normal runs.
     int stop_after = -1;
 };
 

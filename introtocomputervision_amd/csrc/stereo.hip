@@ -268,10 +268,9 @@ __global__ __launch_bounds__(256) void stereo_generic_kernel(StereoArgs a, int r
 }
 
 template <int MODE>
-static int launch_stereo(hipStream_t s, const StereoArgs &a, int r) {
+static int launch_stereo(hipStream_t s, const StereoArgs &a, int r, int force_rpw) {
     // Rows per wave: 8, or 10 when that lets the whole grid be resident at once (4 waves/SIMD on
     // 256 CUs = 4096 wave slots; 1080p r=5: 3888 waves instead of 4860 = one round, no tail).
-    static const int force_rpw = [] { const char *e = getenv("MICV_STEREO_RPW"); return e ? atoi(e) : 0; }();
     const long waves8 = (long)cdiv(a.cols, 64 - 2 * (r < 1 ? 1 : r)) * cdiv(a.rows, 8);
     const long waves10 = (long)cdiv(a.cols, 64 - 2 * (r < 1 ? 1 : r)) * cdiv(a.rows, 10);
     const bool ten = force_rpw ? force_rpw == 10 : (waves8 > 4096 && (waves10 + 4095) / 4096 < (waves8 + 4095) / 4096);
@@ -335,9 +334,10 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
         a.energy = static_cast<const float *>(scratch);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ncc) return launch_stereo<ST_NCC>(s, a, rad);
-    if (flags & MICV_STEREO_SERIAL) return launch_stereo<ST_SSD_SERIAL>(s, a, rad);
-    return launch_stereo<ST_SSD>(s, a, rad);
+    const int rpw = ctx->opt[MICV_OPT_STEREO_ROWS];
+    if (ncc) return launch_stereo<ST_NCC>(s, a, rad, rpw);
+    if (flags & MICV_STEREO_SERIAL) return launch_stereo<ST_SSD_SERIAL>(s, a, rad, rpw);
+    return launch_stereo<ST_SSD>(s, a, rad, rpw);
 }
 
 }  // namespace micv

@@ -9,9 +9,10 @@ dynamic:
     there is NO per-level image exchange (here each rank simply holds the full 8 MB frames);
   * the flow is produced level by level, so the only dynamic exchange is the coarse flow: to
     compute rows [a, b) of level l a rank needs 2*pyrUp(flow_{l+1}) on rows [a-8, b+8) (Sobel 1 +
-    window 7), i.e. coarse rows [(a-8-2)/2, (b+8+2)/2]: up to 6 rows beyond its own coarse band (7
-    with the cv::resize of odd-sized levels).  HALO = 8 coarse rows x cols x 2 fields x 4 B per
-    neighbour per level (level 1 -> 0 at 1080p: 61 KB): latency-bound point-to-point, no collective.
+    window 7), i.e. coarse rows [(a-8-2)/2, (b+8+2)/2]: up to 5 rows beyond its own coarse band, 6-7
+    with the cv::resize of odd-sized levels.  The halo follows the window: halo_rows(win) =
+    (win//2 + 2)//2 + 3 coarse rows (7 for win 15, 11 for win 31) x cols x 2 fields x 4 B per
+    neighbour per level (level 1 -> 0 at 1080p: 54 KB): latency-bound point-to-point, no collective.
 
 Cuts: the coarsest level is split evenly; finer levels double the cut (a_l = 2 a_{l+1}), the last
 rank absorbs the odd remainder, so a rank's band at level l is exactly the pyrUp image of its band at
@@ -21,12 +22,19 @@ one neighbour.  Results are bit-identical to the unsharded path (tests/test_shar
 """
 import numpy as np
 
-HALO = 8  # coarse-flow rows needed beyond a rank's own band (see header)
+def halo_rows(win):
+    """Coarse-flow rows a band needs beyond its own coarse band to compute the next finer level with
+    window `win`: the fine rows [a - r - 1, b + r + 1) (Sobel 1 + window radius r) read 2*pyrUp on
+    +-2 fine rows, i.e. coarse rows a/2 - ceil((r+3)/2) .. b/2 + (r+2)//2: (r+2)//2 + 1 rows, + 2 for
+    the cv::resize of odd-sized levels (source row within 1 of the target row, uneven last band)."""
+    r = int(win) // 2
+    return (r + 2) // 2 + 3
 
 
 class RowShardPlan:
-    def __init__(self, rows, cols, levels, world):
-        self.levels, self.world = levels, world
+    def __init__(self, rows, cols, levels, world, win=15):
+        self.levels, self.world, self.win = levels, world, int(win)
+        self.halo = halo_rows(win)
         self.dims = [(rows >> l, cols >> l) for l in range(levels)]
         if self.dims[-1][0] < world:
             raise ValueError(f"{world} ranks cannot split the {self.dims[-1][0]}-row coarsest level")
@@ -43,7 +51,7 @@ class RowShardPlan:
     def needed(self, level, rank):
         """Rows of level `level` (a coarse level) rank needs to compute its band one level finer."""
         a, b = self.band(level, rank)
-        return max(0, a - HALO), min(self.dims[level][0], b + HALO)
+        return max(0, a - self.halo), min(self.dims[level][0], b + self.halo)
 
     def transfers(self, level):
         """[(src, dst, row0, row1)]: rows of level `level` that dst needs and src owns."""
@@ -101,6 +109,9 @@ def lk_pyr_band(prev_pyr, next_pyr, plan, rank, win, level_fn, comm, poison=None
     returns (u, v) full-size arrays/tensors whose rows [a, b) are valid (fu/fv None at the coarsest
     level).  comm.exchange(plan, level, fu, fv) fills the halo rows of level `level` in place.
     Returns (u, v) of level 0 with rows plan.band(0, rank) valid."""
+    if halo_rows(win) > plan.halo:
+        raise ValueError(f"plan was built for window {plan.win} (halo {plan.halo} rows); window {win} "
+                         f"needs {halo_rows(win)}: pass win to RowShardPlan")
     fu = fv = None
     for l in range(plan.levels - 1, -1, -1):
         a, b = plan.band(l, rank)
@@ -121,6 +132,8 @@ def lk_pyr_virtual(prev_pyr, next_pyr, plan, win, level_fn, poison=12345.0):
     arithmetic and the same transfer list, with the exchange done by row copies.  Rows a rank does
     not own are overwritten with `poison` after every level, so a missing halo row shows up as a
     wrong result.  Returns the assembled level-0 (u, v)."""
+    if halo_rows(win) > plan.halo:
+        raise ValueError(f"plan was built for window {plan.win}; window {win} needs a wider halo")
     state = [None] * plan.world  # per rank: (fu, fv) of the previous (coarser) level
     for l in range(plan.levels - 1, -1, -1):
         if state[0] is not None:
@@ -178,9 +191,37 @@ def lk_pyr_row_sharded_gpu(prev, nxt, win, levels, ctx, rank, world):
     prev/nxt: full [rows, cols] float32 CUDA tensors on every rank.  Returns this rank's band
     (u_band, v_band, (a, b))."""
     from . import pyr
-    plan = RowShardPlan(prev.shape[0], prev.shape[1], levels, world)
+    plan = RowShardPlan(prev.shape[0], prev.shape[1], levels, world, win)
     pp = pyr.makeGaussianPyramid(prev, levels, ctx=ctx)
     npyr = pyr.makeGaussianPyramid(nxt, levels, ctx=ctx)
     u, v = lk_pyr_band(pp, npyr, plan, rank, win, gpu_level_fn(ctx, win), DistComm(rank, world))
     a, b = plan.band(0, rank)
     return u[a:b], v[a:b], (a, b)
+
+
+class _NoComm:
+    def exchange(self, *a):
+        pass
+
+
+class RowShardBatch:
+    """A batch of frame pairs, every pair split by rows over `world` ranks: what `bench.py --mode
+    rowshard` runs.  Inputs are replicated ([B, rows, cols] on every rank); run() writes this rank's
+    band of every pair into u / v."""
+
+    def __init__(self, ctx, rows, cols, levels, win, batch, rank, world, comm=None):
+        self.ctx, self.levels, self.win, self.batch, self.rank = ctx, levels, win, batch, rank
+        self.plan = RowShardPlan(rows, cols, levels, world, win)
+        self.comm = comm if comm is not None else _NoComm()
+        self.band0 = self.plan.band(0, rank)
+        self.level_fn = gpu_level_fn(ctx, win)
+
+    def run(self, prev, nxt, u, v, stream=None):
+        from . import pyr
+        a0, b0 = self.band0
+        for i in range(self.batch):
+            pp = pyr.makeGaussianPyramid(prev[i], self.levels, ctx=self.ctx)
+            npyr = pyr.makeGaussianPyramid(nxt[i], self.levels, ctx=self.ctx)
+            bu, bv = lk_pyr_band(pp, npyr, self.plan, self.rank, self.win, self.level_fn, self.comm)
+            u[i, a0:b0] = bu[a0:b0]
+            v[i, a0:b0] = bv[a0:b0]

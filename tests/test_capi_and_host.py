@@ -83,3 +83,39 @@ def test_byte_model_matches_baseline_md():
     assert b.algorithmic_bytes_pair(1080, 1920, 4) == 54950400
     assert b.algorithmic_bytes_pair(2160, 3840, 5) == 220838400
     assert b.level0_kernel_bytes_pair(1080, 1920, 5) == 16 * 2073600 + 8 * 518400
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus 2` run directly (no torchrun environment) must start 2 ranks itself:
+    the launcher spawns torch.distributed.run as a child and relays rank 0's JSON line.  --dry-run
+    over gloo: no kernels (there is no CPU fallback), only launcher / rendezvous / MAX / JSON."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--dry-run", "--steps", "3", "--warmup", "1"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and len(d["config"]["per_rank_s"]) == 2
+    assert d["steps"] == 3 and d["value"] is None and "dry run" in d["data"]
+    # a failing child is reported, not swallowed (gloo without --dry-run is refused by every rank)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--steps", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_no_environment_knobs_in_the_default_build():
+    """The shipped library reads no environment variables (options live in the context); the only
+    getenv left is behind -DMICV_DIAG."""
+    import subprocess
+    so = os.path.join(ROOT, "introtocomputervision_amd", "libmicv.so")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+    blob = open(so, "rb").read()
+    for knob in (b"MICV_LK_STOP", b"MICV_LK_GROUPS", b"MICV_FORCE_GENERIC", b"MICV_LK_NT"):
+        assert knob not in blob, knob

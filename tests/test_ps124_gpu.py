@@ -236,6 +236,31 @@ def test_ssd_1080p_known_ramp(M):
     assert (inner == want).mean() > 0.999
 
 
+def test_ssd_1080p_c3_bit_exact(M):
+    """BASELINE C3 at full size against the oracle: 1080x1920, 11x11 window, all 128 candidate
+    disparities (d in [-127, 0]), every pixel, byte for byte."""
+    harris, stereo, hough, synth = M
+    left, right, negd = synth.stereo_pair(0x5EED0002, 1080, 1920)
+    exp = orc.disparity_ssd(left, right, 5, -127, 0)
+    got = host(stereo.disparitySSD(dev(left), dev(right), 5, -127, 0))
+    assert got.dtype == np.int8 and np.array_equal(got, exp)
+    # the reference's own geometry: right-reference pass d in [0, 127]
+    exp_r = orc.disparity_ssd(right, left, 5, 0, 127)
+    assert np.array_equal(host(stereo.disparitySSD(dev(right), dev(left), 5, 0, 127)), exp_r)
+
+
+@pytest.mark.parametrize("rows,cols,rad,dmin", [(540, 960, 5, -63), (1080, 1920, 5, -127), (300, 700, 7, -95)])
+def test_ncorr_at_size(M, rows, cols, rad, dmin):
+    """disparityNCorr against the oracle at BASELINE-scale sizes (the small cases are in test_ncorr)."""
+    harris, stereo, hough, synth = M
+    left, right, negd = synth.stereo_pair(0x5EED0002, rows, cols)
+    left = left + 1.0  # keep window energies > 0
+    right = right + 1.0
+    exp = orc.disparity_ncorr(left, right, rad, dmin, 0)
+    got = host(stereo.disparityNCorr(dev(left), dev(right), rad, dmin, 0))
+    assert np.array_equal(got, exp)
+
+
 # ------------------------------------------------------------------------------ ps1 ------
 
 @pytest.mark.parametrize("rho_bin,theta_bin", [(1, 1), (2, 3), (5, 7)])

@@ -44,9 +44,11 @@ def test_plan_geometry():
         assert all(p.cuts[l][g] < p.cuts[l][g + 1] for g in range(8))
     for l in range(4):  # a band is the pyrUp image of the coarser band
         assert all(p.cuts[l][g] == 2 * p.cuts[l + 1][g] for g in range(8))
-    # level 1 -> 0 halo: <= 8 rows x 960 cols x 2 fields x 4 B from each neighbour
-    assert p.halo_bytes(1, 3) == 2 * 8 * 960 * 8
-    assert p.halo_bytes(1, 0) == 8 * 960 * 8
+    # level 1 -> 0 halo at win 15: 7 rows x 960 cols x 2 fields x 4 B from each neighbour
+    assert p.halo == shard.halo_rows(15) == 7
+    assert p.halo_bytes(1, 3) == 2 * 7 * 960 * 8
+    assert p.halo_bytes(1, 0) == 7 * 960 * 8
+    assert shard.halo_rows(31) == 11 and shard.halo_rows(7) == 5
     with pytest.raises(ValueError):
         shard.RowShardPlan(64, 64, 5, 8)
 
@@ -59,6 +61,21 @@ def test_virtual_shards_match_unsharded_oracle(rows, cols, levels, world):
     u, v = shard.lk_pyr_virtual(orc.gaussian_pyramid(prev, levels), orc.gaussian_pyramid(nxt, levels),
                                 plan, 7, oracle_level_fn(7))
     assert np.array_equal(u, eu) and np.array_equal(v, ev)
+
+
+@pytest.mark.parametrize("win,rows,cols,levels,world", [(21, 135, 96, 3, 3), (31, 135, 64, 3, 2), (31, 101, 77, 3, 4), (43, 160, 48, 2, 3)])
+def test_halo_follows_the_window(win, rows, cols, levels, world):
+    """Wide windows need more coarse rows than the 7 of win 15: the plan derives the halo from win
+    (rows a rank does not own are poisoned after every level, so a short halo shows)."""
+    prev, nxt = synth.lk_pair(7 + win, rows, cols, 2, -1)
+    eu, ev = orc.lk_flow_pyr(prev, nxt, win, levels)
+    plan = shard.RowShardPlan(rows, cols, levels, world, win)
+    u, v = shard.lk_pyr_virtual(orc.gaussian_pyramid(prev, levels), orc.gaussian_pyramid(nxt, levels),
+                                plan, win, oracle_level_fn(win))
+    assert np.array_equal(u, eu) and np.array_equal(v, ev)
+    with pytest.raises(ValueError):  # a plan built for a narrower window refuses the wide one
+        shard.lk_pyr_virtual(orc.gaussian_pyramid(prev, levels), orc.gaussian_pyramid(nxt, levels),
+                             shard.RowShardPlan(rows, cols, levels, world, 7), win, oracle_level_fn(win))
 
 
 def test_halo_is_actually_needed():
@@ -113,7 +130,8 @@ def test_two_ranks_over_gloo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,cols,levels,world,win", [(270, 480, 5, 8, 15), (540, 960, 5, 4, 15), (135, 240, 4, 3, 9)])
+@pytest.mark.parametrize("rows,cols,levels,world,win", [(270, 480, 5, 8, 15), (540, 960, 5, 4, 15), (135, 240, 4, 3, 9),
+                                                       (1080, 1920, 5, 8, 15)])  # the last one is BASELINE C4's geometry
 def test_virtual_shards_on_gpu(rows, cols, levels, world, win):
     import torch
     from introtocomputervision_amd import lk, pyr
@@ -122,7 +140,7 @@ def test_virtual_shards_on_gpu(rows, cols, levels, world, win):
     prev, nxt = synth.lk_pair(1234, rows, cols, 3, -2)
     dp, dn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
     gu, gv = lk.calcOpticalFlowPyr(dp, dn, win, levels, ctx=ctx)
-    plan = shard.RowShardPlan(rows, cols, levels, world)
+    plan = shard.RowShardPlan(rows, cols, levels, world, win)
     u, v = shard.lk_pyr_virtual(pyr.makeGaussianPyramid(dp, levels, ctx=ctx),
                                 pyr.makeGaussianPyramid(dn, levels, ctx=ctx), plan, win,
                                 shard.gpu_level_fn(ctx, win))

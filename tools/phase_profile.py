@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """In-kernel phase shares of the fused level-0 LK kernel (diagnostic; see micv_profile_lk_phases).
-Usage on the GPU box: python tools/phase_profile.py [pairs]"""
+Needs the diagnostic flavour of the library:
+  MICV_OUT=libmicv_diag.so EXTRA_HIPCC_FLAGS=-DMICV_DIAG bash introtocomputervision_amd/csrc/build.sh
+  MICV_LIB=$PWD/introtocomputervision_amd/libmicv_diag.so python tools/phase_profile.py [pairs]"""
 import os
 import sys
 

@@ -11,19 +11,18 @@ cd /tmp && export TMPDIR=/tmp
 BENCH=(python3 "$repo/bench.py" --cpu-pairs 0)
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- \
-    "${BENCH[@]}" --steps 20 --warmup 5 > "$out/bench_trace.log" 2>&1
+    "${BENCH[@]}" --steps 20 --warmup 5 --sustained-s 0 > "$out/bench_trace.log" 2>&1
 echo "trace rc=$?"
 
-# PMC passes: one stream group, so each level-0 dispatch covers the whole batch (the launch the
-# roofline line of bench.py is about); counters serialise dispatches anyway.
-export MICV_LK_GROUPS=1
+# PMC passes: one stream group (--lk-groups 1), so each level-0 dispatch covers the whole batch (the
+# launch the roofline line of bench.py is about); counters serialise dispatches anyway.
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
            "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d "$out/pmc$i" -- \
-      "${BENCH[@]}" --steps 3 --warmup 1 --no-profile-pass > "$out/bench_pmc$i.log" 2>&1
+      "${BENCH[@]}" --steps 3 --warmup 1 --no-profile-pass --lk-groups 1 --inflight 1 --sustained-s 0 > "$out/bench_pmc$i.log" 2>&1
   echo "pmc$i ($grp) rc=$?"
 done
 python3 "$repo/tools/summarize_profile.py" "$out" > "$out/summary.txt" 2>&1
