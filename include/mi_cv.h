@@ -63,6 +63,16 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
 int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value);
 
+/* Device memory for callers that keep images resident between calls (the role cv::cuda::GpuMat's
+ * allocator plays for the reference's GpuMat overloads, ps1_cpp/src/Hough.h:22-25,48-51,73-75).
+ * Copies are blocking, like GpuMat::upload / download without a Stream; pitches in bytes. */
+int micv_device_malloc(micv_ctx *ctx, size_t bytes, void **out);
+void micv_device_free(micv_ctx *ctx, void *p);
+int micv_memcpy2d_h2d(micv_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch,
+                      size_t width_bytes, int rows);
+int micv_memcpy2d_d2h(micv_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch,
+                      size_t width_bytes, int rows);
+
 /* ---------------------------------------------------------------- common/ (a17) ---- */
 /* common::warmup, common/src/CudaWarmup.cu:5-19 (10 blocks x 64 threads). */
 int micv_warmup(micv_ctx *ctx, micv_stream stream);
@@ -166,6 +176,24 @@ int micv_laplacian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int co
  * (Pyramids.cpp:10-15). */
 int micv_rgb8_to_gray_f32_dev(micv_ctx *ctx, const uint8_t *rgb, int rows, int cols,
                               size_t sstride, float *dst, size_t dstride, micv_stream stream);
+/* The general form of the same step, as pyr::makeGaussianPyramid (Pyramids.cpp:9-15) and
+ * denseLKWrapper (ps5_cpp/src/Solution.cpp:48-56) apply it to whatever cv::imread returned:
+ * `channels` 1 (convertTo only), 3 or 4 interleaved samples per pixel (cv::cvtColor(COLOR_RGB2GRAY)
+ * accepts both; alpha is ignored), `depth` MICV_DEPTH_8U (fixed-point weights 4899/9617/1868 >> 14,
+ * rounded) or MICV_DEPTH_32F ((c0*0.299f + c1*0.587f) + c2*0.114f, unfused).  sstride in bytes. */
+#define MICV_DEPTH_8U  0 /* CV_8U  */
+#define MICV_DEPTH_32F 5 /* CV_32F */
+int micv_to_gray_f32_dev(micv_ctx *ctx, const void *src, int rows, int cols, size_t sstride,
+                         int channels, int depth, float *dst, size_t dstride, micv_stream stream);
+int micv_to_gray_f32_host(micv_ctx *ctx, const void *src, int rows, int cols, size_t sstride,
+                          int channels, int depth, float *dst, size_t dstride);
+/* lk::calcOpticalFlowPyr on the frames as the unchanged ps5 caller passes them: denseLKWrapper hands
+ * the COLOUR frames to lk::calcOpticalFlowPyr (ps5_cpp/src/Solution.cpp:63) and
+ * makeGaussianPyramid converts them (Pyramids.cpp:9-15).  One upload of the interleaved frames,
+ * grey conversion on the device, then micv_lk_flow_pyr_dev. */
+int micv_lk_flow_pyr_frames_host(micv_ctx *ctx, const void *prev, const void *next, int rows, int cols,
+                                 size_t stride, int channels, int depth, int win, int levels, float *u,
+                                 float *v, size_t ostride);
 /* cv::resize(..., INTER_LINEAR) on f32 as used at OpticalFlow.cpp:149-150. */
 int micv_resize_linear_dev(micv_ctx *ctx, const float *src, int srows, int scols, size_t sstride,
                            float *dst, int drows, int dcols, size_t dstride, micv_stream stream);
@@ -312,15 +340,22 @@ int micv_bf_ratio_filter_host(micv_ctx *ctx, const int32_t *idx2, const float *d
 /* ----------------------------------- ps7: motion history ----- */
 
 /* mhi::frameDifference, ps7_cpp/lib/MotionHistory.cpp:26-77, for single-channel CV_8U frames:
- * Gaussian blur (blur_size odd <= 31, blur_sigma > 0), saturating f2 - f1, AbsThreshold -> {0,1},
- * 7x7 elliptical morphological open.  diff is rows x cols u8. */
+ * Gaussian blur with the reference's `const cv::Size& blurSize` (MotionHistory.h:14: blur_w taps
+ * along x, blur_h along y, each odd <= 31; blur_sigma > 0 for both directions as
+ * cv::cuda::createGaussianFilter(type, -1, ksize, sigma1) does), saturating f2 - f1,
+ * AbsThreshold -> {0,1}, 7x7 elliptical morphological open.  diff is rows x cols u8. */
 int micv_mhi_frame_difference_dev(micv_ctx *ctx, const uint8_t *f1, const uint8_t *f2, int rows,
-                                  int cols, size_t stride, double thresh, int blur_size,
+                                  int cols, size_t stride, double thresh, int blur_w, int blur_h,
                                   double blur_sigma, uint8_t *diff, size_t dstride,
                                   micv_stream stream);
 int micv_mhi_frame_difference_host(micv_ctx *ctx, const uint8_t *f1, const uint8_t *f2, int rows,
-                                   int cols, size_t stride, double thresh, int blur_size,
+                                   int cols, size_t stride, double thresh, int blur_w, int blur_h,
                                    double blur_sigma, uint8_t *diff, size_t dstride);
+/* mhi::energyFromHistory, MotionHistory.cpp:98-105: mei = mhi > 0 ? 1 : 0. */
+int micv_mhi_energy_dev(micv_ctx *ctx, const uint8_t *mhi, int rows, int cols, size_t sstride,
+                        uint8_t *mei, size_t dstride, micv_stream stream);
+int micv_mhi_energy_host(micv_ctx *ctx, const uint8_t *mhi, int rows, int cols, size_t sstride,
+                         uint8_t *mei, size_t dstride);
 /* thresholdDifference / AbsThreshold<uint8_t>, ps7_cpp/lib/MotionHistory.cu:17-48. */
 int micv_mhi_threshold_dev(micv_ctx *ctx, const uint8_t *src, int rows, int cols, size_t sstride,
                            double thresh, uint8_t *dst, size_t dstride, micv_stream stream);

@@ -50,6 +50,10 @@ SIGNATURES = {
     "micv_ctx_create": (i32, [i32, C.POINTER(vp)]),
     "micv_ctx_destroy": (None, [vp]),
     "micv_ctx_scratch_bytes": (sz, [vp]),
+    "micv_device_malloc": (i32, [vp, sz, C.POINTER(vp)]),
+    "micv_device_free": (None, [vp, vp]),
+    "micv_memcpy2d_h2d": (i32, [vp, vp, sz, vp, sz, sz, i32]),
+    "micv_memcpy2d_d2h": (i32, [vp, vp, sz, vp, sz, sz, i32]),
     "micv_ctx_set_option": (i32, [vp, i32, i32]),
     "micv_ctx_get_option": (i32, [vp, i32, C.POINTER(i32)]),
     "micv_profile_enable": (i32, [vp, i32]),
@@ -81,6 +85,9 @@ SIGNATURES = {
     "micv_gaussian_pyramid_host": (i32, [vp, vp, i32, i32, sz, i32, C.POINTER(vp)]),
     "micv_laplacian_pyramid_dev": (i32, [vp, vp, i32, i32, sz, i32, C.POINTER(vp), vp]),
     "micv_rgb8_to_gray_f32_dev": (i32, [vp, vp, i32, i32, sz, vp, sz, vp]),
+    "micv_to_gray_f32_dev": (i32, [vp, vp, i32, i32, sz, i32, i32, vp, sz, vp]),
+    "micv_to_gray_f32_host": (i32, [vp, vp, i32, i32, sz, i32, i32, vp, sz]),
+    "micv_lk_flow_pyr_frames_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, vp, sz]),
     "micv_resize_linear_dev": (i32, [vp, vp, i32, i32, sz, vp, i32, i32, sz, vp]),
     # ps4
     "micv_sobel_dev": (i32, [vp, vp, i32, i32, sz, i32, f32, vp, vp, sz, vp]),
@@ -114,14 +121,16 @@ SIGNATURES = {
     "micv_bf_knn2_dev": (i32, [vp, vp, i32, sz, vp, i32, sz, i32, vp, vp, vp]),
     "micv_bf_ratio_filter_dev": (i32, [vp, vp, vp, i32, f64, vp, vp, i64, vp, vp]),
     # ps7
-    "micv_mhi_frame_difference_dev": (i32, [vp, vp, vp, i32, i32, sz, f64, i32, f64, vp, sz, vp]),
+    "micv_mhi_frame_difference_dev": (i32, [vp, vp, vp, i32, i32, sz, f64, i32, i32, f64, vp, sz, vp]),
+    "micv_mhi_energy_dev": (i32, [vp, vp, i32, i32, sz, vp, sz, vp]),
+    "micv_mhi_energy_host": (i32, [vp, vp, i32, i32, sz, vp, sz]),
     "micv_mhi_threshold_dev": (i32, [vp, vp, i32, i32, sz, f64, vp, sz, vp]),
     "micv_mhi_update_dev": (i32, [vp, vp, sz, vp, sz, i32, i32, i32, vp]),
     # host-pointer flavours of the "next" rows
     "micv_generate_edge_host": (i32, [vp, vp, i32, i32, sz, i32, f64, f64, f64, vp, sz]),
     "micv_bf_knn2_host": (i32, [vp, vp, i32, sz, vp, i32, sz, i32, vp, vp]),
     "micv_bf_ratio_filter_host": (i32, [vp, vp, vp, i32, f64, vp, vp, i64, vp]),
-    "micv_mhi_frame_difference_host": (i32, [vp, vp, vp, i32, i32, sz, f64, i32, f64, vp, sz]),
+    "micv_mhi_frame_difference_host": (i32, [vp, vp, vp, i32, i32, sz, f64, i32, i32, f64, vp, sz]),
     "micv_mhi_threshold_host": (i32, [vp, vp, i32, i32, sz, f64, vp, sz]),
     "micv_mhi_update_host": (i32, [vp, vp, sz, vp, sz, i32, i32, i32]),
 }

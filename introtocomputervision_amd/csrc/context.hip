@@ -217,6 +217,34 @@ void micv_ctx_destroy(micv_ctx *ctx) {
 
 size_t micv_ctx_scratch_bytes(const micv_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
 
+int micv_device_malloc(micv_ctx *ctx, size_t bytes, void **out) {
+    MICV_REQUIRE(ctx && out, "micv_device_malloc: null argument");
+    MICV_HIP(hipSetDevice(ctx->device));
+    MICV_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return MICV_OK;
+}
+void micv_device_free(micv_ctx *ctx, void *p) {
+    if (!p) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipFree(p);
+}
+int micv_memcpy2d_h2d(micv_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch,
+                      size_t width_bytes, int rows) {
+    MICV_REQUIRE(ctx && dst && src && rows > 0 && width_bytes > 0 && dpitch >= width_bytes && spitch >= width_bytes,
+                 "micv_memcpy2d_h2d: bad argument");
+    MICV_HIP(hipSetDevice(ctx->device));
+    MICV_HIP(hipMemcpy2D(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyHostToDevice));
+    return MICV_OK;
+}
+int micv_memcpy2d_d2h(micv_ctx *ctx, void *dst, size_t dpitch, const void *src, size_t spitch,
+                      size_t width_bytes, int rows) {
+    MICV_REQUIRE(ctx && dst && src && rows > 0 && width_bytes > 0 && dpitch >= width_bytes && spitch >= width_bytes,
+                 "micv_memcpy2d_d2h: bad argument");
+    MICV_HIP(hipSetDevice(ctx->device));
+    MICV_HIP(hipMemcpy2D(dst, dpitch, src, spitch, width_bytes, rows, hipMemcpyDeviceToHost));
+    return MICV_OK;
+}
+
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
     MICV_REQUIRE(ctx != nullptr, "micv_ctx_set_option: ctx is null");
     MICV_REQUIRE(option >= 1 && option < MICV_OPT_COUNT, "micv_ctx_set_option: unknown option %d", option);

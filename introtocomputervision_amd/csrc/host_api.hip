@@ -50,11 +50,20 @@ static int down2d(void *dst, size_t dstride, const void *src, size_t row_bytes, 
 
 using namespace micv;
 
+// Every `_host` function enqueues asynchronous copies; whichever way it returns (an error in a
+// later step included) the stream is drained first, so no D2H copy into the caller's buffer is
+// still in flight and no cached device block is handed out again while something uses it.
+struct HostSync {
+    hipStream_t s;
+    ~HostSync() { (void)hipStreamSynchronize(s); }
+};
+
 #define HOST_PROLOGUE(fn)                                    \
     MICV_REQUIRE(ctx != nullptr, fn ": ctx is null");        \
     MICV_HIP(hipSetDevice(ctx->device));                     \
     ::micv::io_ctx = ctx;                                    \
-    hipStream_t s = nullptr
+    hipStream_t s = nullptr;                                 \
+    HostSync host_sync_{s}
 
 extern "C" {
 
@@ -73,6 +82,53 @@ int micv_lk_flow_pyr_host(micv_ctx *ctx, const float *prev, const float *next, i
                                   du.as<float>(), dv.as<float>(), rb, s));
     MICV_TRY(down2d(u, ostride, du.p, rb, rows, s));
     MICV_TRY(down2d(v, ostride, dv.p, rb, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+/* lk::calcOpticalFlowPyr on frames as the ps5 driver hands them over (denseLKWrapper passes the
+ * COLOUR frames, Solution.cpp:63; makeGaussianPyramid converts, Pyramids.cpp:9-15): one upload of
+ * the interleaved frames, grey conversion on the device, then the pyramid chain. */
+int micv_lk_flow_pyr_frames_host(micv_ctx *ctx, const void *prev, const void *next, int rows, int cols,
+                                 size_t stride, int channels, int depth, int win, int levels, float *u,
+                                 float *v, size_t ostride) {
+    HOST_PROLOGUE("micv_lk_flow_pyr_frames_host");
+    MICV_REQUIRE(prev && next && u && v && rows > 0 && cols > 0, "micv_lk_flow_pyr_frames_host: bad argument");
+    MICV_REQUIRE((channels == 1 || channels == 3 || channels == 4) &&
+                     (depth == MICV_DEPTH_8U || depth == MICV_DEPTH_32F),
+                 "micv_lk_flow_pyr_frames_host: frames must be 1/3/4-channel 8U or 32F");
+    const size_t es = depth == MICV_DEPTH_8U ? 1 : 4, srb = (size_t)cols * channels * es;
+    MICV_REQUIRE(stride >= srb && stride_ok(ostride, cols, 4), "micv_lk_flow_pyr_frames_host: bad stride");
+    const size_t rb = (size_t)cols * 4, n = rb * rows;
+    DevBuf cp(srb * rows), cn(srb * rows), dp(n), dn(n), du(n), dv(n);
+    MICV_ALLOC_OK(cp); MICV_ALLOC_OK(cn); MICV_ALLOC_OK(dp); MICV_ALLOC_OK(dn); MICV_ALLOC_OK(du); MICV_ALLOC_OK(dv);
+    MICV_TRY(up2d(cp.p, prev, stride, srb, rows, s));
+    MICV_TRY(up2d(cn.p, next, stride, srb, rows, s));
+    MICV_TRY(micv_to_gray_f32_dev(ctx, cp.p, rows, cols, srb, channels, depth, dp.as<float>(), rb, s));
+    MICV_TRY(micv_to_gray_f32_dev(ctx, cn.p, rows, cols, srb, channels, depth, dn.as<float>(), rb, s));
+    MICV_TRY(micv_lk_flow_pyr_dev(ctx, dp.as<float>(), dn.as<float>(), rows, cols, rb, win, levels,
+                                  du.as<float>(), dv.as<float>(), rb, s));
+    MICV_TRY(down2d(u, ostride, du.p, rb, rows, s));
+    MICV_TRY(down2d(v, ostride, dv.p, rb, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_to_gray_f32_host(micv_ctx *ctx, const void *src, int rows, int cols, size_t sstride, int channels,
+                          int depth, float *dst, size_t dstride) {
+    HOST_PROLOGUE("micv_to_gray_f32_host");
+    MICV_REQUIRE(src && dst && rows > 0 && cols > 0, "micv_to_gray_f32_host: bad argument");
+    MICV_REQUIRE((channels == 1 || channels == 3 || channels == 4) &&
+                     (depth == MICV_DEPTH_8U || depth == MICV_DEPTH_32F),
+                 "micv_to_gray_f32_host: source must be 1/3/4-channel 8U or 32F");
+    const size_t es = depth == MICV_DEPTH_8U ? 1 : 4, srb = (size_t)cols * channels * es;
+    MICV_REQUIRE(sstride >= srb && stride_ok(dstride, cols, 4), "micv_to_gray_f32_host: bad stride");
+    const size_t rb = (size_t)cols * 4;
+    DevBuf cs(srb * rows), dd(rb * rows);
+    MICV_ALLOC_OK(cs); MICV_ALLOC_OK(dd);
+    MICV_TRY(up2d(cs.p, src, sstride, srb, rows, s));
+    MICV_TRY(micv_to_gray_f32_dev(ctx, cs.p, rows, cols, srb, channels, depth, dd.as<float>(), rb, s));
+    MICV_TRY(down2d(dst, dstride, dd.p, rb, rows, s));
     MICV_HIP(hipStreamSynchronize(s));
     return MICV_OK;
 }
@@ -427,7 +483,7 @@ int micv_bf_ratio_filter_host(micv_ctx *ctx, const int32_t *idx2, const float *d
 }
 
 int micv_mhi_frame_difference_host(micv_ctx *ctx, const uint8_t *f1, const uint8_t *f2, int rows,
-                                   int cols, size_t stride, double thresh, int blur_size,
+                                   int cols, size_t stride, double thresh, int blur_w, int blur_h,
                                    double blur_sigma, uint8_t *diff, size_t dstride) {
     HOST_PROLOGUE("micv_mhi_frame_difference_host");
     MICV_REQUIRE(f1 && f2 && diff && rows > 0 && cols > 0 && stride >= (size_t)cols && dstride >= (size_t)cols,
@@ -438,8 +494,23 @@ int micv_mhi_frame_difference_host(micv_ctx *ctx, const uint8_t *f1, const uint8
     MICV_TRY(up2d(d1.p, f1, stride, (size_t)cols, rows, s));
     MICV_TRY(up2d(d2.p, f2, stride, (size_t)cols, rows, s));
     MICV_TRY(micv_mhi_frame_difference_dev(ctx, d1.as<uint8_t>(), d2.as<uint8_t>(), rows, cols, cols, thresh,
-                                           blur_size, blur_sigma, dd.as<uint8_t>(), cols, s));
+                                           blur_w, blur_h, blur_sigma, dd.as<uint8_t>(), cols, s));
     MICV_TRY(down2d(diff, dstride, dd.p, (size_t)cols, rows, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+int micv_mhi_energy_host(micv_ctx *ctx, const uint8_t *mhi, int rows, int cols, size_t sstride,
+                         uint8_t *mei, size_t dstride) {
+    HOST_PROLOGUE("micv_mhi_energy_host");
+    MICV_REQUIRE(mhi && mei && rows > 0 && cols > 0 && sstride >= (size_t)cols && dstride >= (size_t)cols,
+                 "micv_mhi_energy_host: bad argument");
+    const size_t n = (size_t)rows * cols;
+    DevBuf ds(n), dd(n);
+    MICV_ALLOC_OK(ds); MICV_ALLOC_OK(dd);
+    MICV_TRY(up2d(ds.p, mhi, sstride, (size_t)cols, rows, s));
+    MICV_TRY(micv_mhi_energy_dev(ctx, ds.as<uint8_t>(), rows, cols, cols, dd.as<uint8_t>(), cols, s));
+    MICV_TRY(down2d(mei, dstride, dd.p, (size_t)cols, rows, s));
     MICV_HIP(hipStreamSynchronize(s));
     return MICV_OK;
 }

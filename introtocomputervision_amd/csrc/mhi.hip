@@ -55,6 +55,16 @@ __global__ __launch_bounds__(256) void mhi_blur_cols_diff_kernel(const float *__
     mask[(size_t)y * cols + x] = ((double)val >= thresh || (double)(-val) >= thresh) ? 1 : 0;
 }
 
+// mhi::energyFromHistory (MotionHistory.cpp:98-105): any nonzero history value -> 1.
+__global__ __launch_bounds__(256) void mhi_energy_kernel(const uint8_t *__restrict__ mhi, size_t sstride,
+                                                          int rows, int cols, uint8_t *__restrict__ mei,
+                                                          size_t dstride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    mei[(size_t)y * dstride + x] = mhi[(size_t)y * sstride + x] > 0 ? 1 : 0;
+}
+
 struct Ellipse7 {
     unsigned char m[7];  // bit j of m[i] = element (i, j)
 };
@@ -150,15 +160,16 @@ using namespace micv;
 extern "C" {
 
 int micv_mhi_frame_difference_dev(micv_ctx *ctx, const uint8_t *f1, const uint8_t *f2, int rows,
-                                  int cols, size_t stride, double thresh, int blur_size,
+                                  int cols, size_t stride, double thresh, int blur_w, int blur_h,
                                   double blur_sigma, uint8_t *diff, size_t dstride,
                                   micv_stream stream) {
     MICV_REQUIRE(ctx && f1 && f2 && diff, "micv_mhi_frame_difference: null argument");
     MICV_REQUIRE(rows > 0 && cols > 0 && stride >= (size_t)cols && dstride >= (size_t)cols,
                  "micv_mhi_frame_difference: bad size / stride");
-    MICV_REQUIRE(blur_size >= 1 && blur_size <= 31 && (blur_size & 1) && blur_sigma > 0,
-                 "micv_mhi_frame_difference: blur %d / sigma %g not supported (odd size <= 31, sigma > 0)",
-                 blur_size, blur_sigma);
+    MICV_REQUIRE(blur_w >= 1 && blur_w <= 31 && (blur_w & 1) && blur_h >= 1 && blur_h <= 31 && (blur_h & 1) &&
+                     blur_sigma > 0,
+                 "micv_mhi_frame_difference: blur %dx%d / sigma %g not supported (odd sizes <= 31, sigma > 0)",
+                 blur_w, blur_h, blur_sigma);
     MICV_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)rows * cols;
@@ -167,18 +178,31 @@ int micv_mhi_frame_difference_dev(micv_ctx *ctx, const uint8_t *f1, const uint8_
     Carver c(scratch);
     float *buf = c.take<float>(2 * n);
     uint8_t *m0 = c.take<uint8_t>(n), *m1 = c.take<uint8_t>(n);
-    Taps t;
-    gaussian_taps(blur_size, blur_sigma, &t);
+    Taps t, ty;  // cv::Size(width, height): width taps along x, height taps along y
+    gaussian_taps(blur_w, blur_sigma, &t);
+    gaussian_taps(blur_h, blur_sigma, &ty);
     const dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
     mhi_blur_rows_kernel<<<dim3(grid.x, grid.y, 2), 256, 0, s>>>(f1, f2, stride, rows, cols, buf, t);
     MICV_LAUNCH_CHECK();
-    mhi_blur_cols_diff_kernel<<<grid, 256, 0, s>>>(buf, rows, cols, t, thresh, m0);
+    mhi_blur_cols_diff_kernel<<<grid, 256, 0, s>>>(buf, rows, cols, ty, thresh, m0);
     MICV_LAUNCH_CHECK();
     const Ellipse7 e = ellipse7();
     const dim3 mgrid(cdiv(cols, 64), cdiv(rows, 16));
     mhi_morph7_tiled_kernel<<<mgrid, 256, 0, s>>>(m0, rows, cols, 0, e, m1, (size_t)cols);  // erode
     MICV_LAUNCH_CHECK();
     mhi_morph7_tiled_kernel<<<mgrid, 256, 0, s>>>(m1, rows, cols, 1, e, diff, dstride);     // dilate
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int micv_mhi_energy_dev(micv_ctx *ctx, const uint8_t *mhi, int rows, int cols, size_t sstride,
+                        uint8_t *mei, size_t dstride, micv_stream stream) {
+    MICV_REQUIRE(ctx && mhi && mei, "micv_mhi_energy: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0 && sstride >= (size_t)cols && dstride >= (size_t)cols,
+                 "micv_mhi_energy: bad size / stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    mhi_energy_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        mhi, sstride, rows, cols, mei, dstride);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }

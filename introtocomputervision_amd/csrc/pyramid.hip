@@ -209,6 +209,29 @@ __global__ __launch_bounds__(256) void rgb8_to_gray_kernel(const uint8_t *__rest
 }
 
 // dst = a - b (dense a, b of pitch `cols`; dst strided).
+// The general form: 1, 3 or 4 interleaved channels of 8-bit or float samples -> grey f32.
+//   8U : the fixed-point weights above (4-channel input ignores alpha), then convertTo(CV_32F);
+//   32F: cv::cvtColor's float path, (c0*0.299f + c1*0.587f) + c2*0.114f, unfused;
+//   1 channel: convertTo(CV_32F) only (exact for 8-bit, a copy for float).
+template <typename T, int CN>
+__global__ __launch_bounds__(256) void to_gray_kernel(const T *__restrict__ src, size_t sstride_bytes,
+                                                       float *__restrict__ dst, int dstride, int rows,
+                                                       int cols) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const T *s = reinterpret_cast<const T *>(reinterpret_cast<const char *>(src) + (size_t)y * sstride_bytes) + CN * x;
+    float g;
+    if (CN == 1) {
+        g = (float)s[0];
+    } else if (sizeof(T) == 1) {
+        g = (float)(((int)s[0] * 4899 + (int)s[1] * 9617 + (int)s[2] * 1868 + (1 << 13)) >> 14);
+    } else {
+        g = ((float)s[0] * 0.299f + (float)s[1] * 0.587f) + (float)s[2] * 0.114f;
+    }
+    dst[(size_t)y * dstride + x] = g;
+}
+
 __global__ __launch_bounds__(256) void sub_kernel(const float *__restrict__ a,
                                                    const float *__restrict__ b,
                                                    float *__restrict__ dst, int dstride, int rows,
@@ -397,6 +420,36 @@ int micv_rgb8_to_gray_f32_dev(micv_ctx *ctx, const uint8_t *rgb, int rows, int c
     rgb8_to_gray_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0,
                           static_cast<hipStream_t>(stream)>>>(rgb, sstride, dst,
                                                               (int)(dstride / 4), rows, cols);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+int micv_to_gray_f32_dev(micv_ctx *ctx, const void *src, int rows, int cols, size_t sstride,
+                         int channels, int depth, float *dst, size_t dstride, micv_stream stream) {
+    MICV_REQUIRE(ctx && src && dst, "micv_to_gray_f32: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0, "micv_to_gray_f32: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(channels == 1 || channels == 3 || channels == 4,
+                 "micv_to_gray_f32: %d channels (1, 3 or 4 as cv::cvtColor(COLOR_RGB2GRAY) takes them)", channels);
+    MICV_REQUIRE(depth == MICV_DEPTH_8U || depth == MICV_DEPTH_32F,
+                 "micv_to_gray_f32: depth %d (MICV_DEPTH_8U or MICV_DEPTH_32F)", depth);
+    const size_t es = depth == MICV_DEPTH_8U ? 1 : 4;
+    MICV_REQUIRE(sstride >= (size_t)cols * channels * es && sstride % es == 0 && stride_ok(dstride, cols, 4),
+                 "micv_to_gray_f32: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    const dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ds = (int)(dstride / 4);
+#define MICV_GRAY(T, CN) to_gray_kernel<T, CN><<<grid, 256, 0, s>>>(static_cast<const T *>(src), sstride, dst, ds, rows, cols)
+    if (depth == MICV_DEPTH_8U) {
+        if (channels == 1) MICV_GRAY(uint8_t, 1);
+        if (channels == 3) MICV_GRAY(uint8_t, 3);
+        if (channels == 4) MICV_GRAY(uint8_t, 4);
+    } else {
+        if (channels == 1) MICV_GRAY(float, 1);
+        if (channels == 3) MICV_GRAY(float, 3);
+        if (channels == 4) MICV_GRAY(float, 4);
+    }
+#undef MICV_GRAY
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }

@@ -92,6 +92,24 @@ def calcOpticalFlowPyr(prevImg, nextImg, winSize=21, levels=4, ctx=None):
     return u, v
 
 
+def calcOpticalFlowPyrFrames(prevImg, nextImg, winSize=21, levels=4, ctx=None):
+    """lk::calcOpticalFlowPyr as the unchanged ps5 caller uses it (Solution.cpp:63): the frames may be
+    colour ([rows, cols, 3|4]) and 8-bit; makeGaussianPyramid's conversion (Pyramids.cpp:9-15) runs on
+    the device after ONE upload.  Host (numpy) frames only -> (u, v)."""
+    a, b = np.ascontiguousarray(prevImg), np.ascontiguousarray(nextImg)
+    if a.shape != b.shape or a.dtype != b.dtype or a.dtype not in (np.uint8, np.float32) or a.ndim not in (2, 3):
+        raise ValueError("prevImg / nextImg: equal-shape uint8 or float32 frames expected")
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    rows, cols = a.shape[:2]
+    u = np.empty((rows, cols), np.float32)
+    v = np.empty((rows, cols), np.float32)
+    c = ctx if ctx is not None else default_context(0)
+    check(lib.micv_lk_flow_pyr_frames_host(c.handle, a.ctypes.data, b.ctypes.data, rows, cols,
+                                           cols * cn * a.dtype.itemsize, cn, 0 if a.dtype == np.uint8 else 5,
+                                           int(winSize), int(levels), u.ctypes.data, v.ctypes.data, cols * 4))
+    return u, v
+
+
 def calcOpticalFlowPyrBatch(prev, next_, winSize=21, levels=4, ctx=None, out=None, stream=None):
     """Batched device form: prev/next are [B, rows, cols] f32 CUDA tensors (contiguous).
     Returns (u, v) of the same shape.  One set of launches for the whole batch."""

@@ -17,10 +17,19 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def frameDifference(f1, f2, thresh, blurSize=3, blurSigma=1.0, ctx=None):
-    """mhi::frameDifference (MotionHistory.cpp:26-77) -> {0,1} uint8 mask (blurSize = the side of the
-    reference's square cv::Size)."""
+def _blur_wh(blurSize):
+    """cv::Size(width, height) as (w, h); a bare int means a square."""
+    if isinstance(blurSize, (tuple, list)):
+        w, h = blurSize
+        return int(w), int(h)
+    return int(blurSize), int(blurSize)
+
+
+def frameDifference(f1, f2, thresh, blurSize=(3, 3), blurSigma=1.0, ctx=None):
+    """mhi::frameDifference (MotionHistory.cpp:26-77) -> {0,1} uint8 mask.  blurSize is the
+    reference's cv::Size as (width, height) (MotionHistory.h:14; default cv::Size(3, 3))."""
     import numpy as np
+    bw, bh = _blur_wh(blurSize)
     if isinstance(f1, np.ndarray):  # host-pointer entry point
         a1 = np.ascontiguousarray(f1, np.uint8)
         a2 = np.ascontiguousarray(f2, np.uint8)
@@ -29,7 +38,7 @@ def frameDifference(f1, f2, thresh, blurSize=3, blurSigma=1.0, ctx=None):
         out = np.empty_like(a1)
         check(lib.micv_mhi_frame_difference_host((ctx or _host_ctx()).handle, a1.ctypes.data, a2.ctypes.data,
                                                  a1.shape[0], a1.shape[1], a1.strides[0], float(thresh),
-                                                 int(blurSize), float(blurSigma), out.ctypes.data,
+                                                 bw, bh, float(blurSigma), out.ctypes.data,
                                                  out.strides[0]))
         return out
     import torch
@@ -40,7 +49,7 @@ def frameDifference(f1, f2, thresh, blurSize=3, blurSigma=1.0, ctx=None):
     rows, cols = f1.shape
     diff = torch.empty((rows, cols), dtype=torch.uint8, device=f1.device)
     check(lib.micv_mhi_frame_difference_dev(_ctx_for(f1, ctx).handle, f1.data_ptr(), f2.data_ptr(), rows,
-                                            cols, f1.stride(0), float(thresh), int(blurSize),
+                                            cols, f1.stride(0), float(thresh), bw, bh,
                                             float(blurSigma), diff.data_ptr(), cols, _stream(f1)))
     return diff
 
@@ -86,6 +95,24 @@ def calcMotionHistory(history, binaryMask, tau, ctx=None):
     return history
 
 
-def energyFromHistory(mhi):
-    """mhi::energyFromHistory (MotionHistory.cpp:98-105): elementwise `> 0` (plain tensor op)."""
-    return (mhi > 0).to(mhi.dtype)
+def energyFromHistory(mhi, ctx=None):
+    """mhi::energyFromHistory (MotionHistory.cpp:98-112): any nonzero history value -> 1.  A list of
+    histories gives a list of energies (the vector overload, :107-112)."""
+    import numpy as np
+    if isinstance(mhi, (list, tuple)):
+        return [energyFromHistory(m, ctx) for m in mhi]
+    if isinstance(mhi, np.ndarray):
+        a = np.ascontiguousarray(mhi, np.uint8)
+        if a.ndim != 2:
+            raise ValueError("mhi: need a 2-D uint8 array")
+        out = np.empty_like(a)
+        check(lib.micv_mhi_energy_host((ctx or _host_ctx()).handle, a.ctypes.data, a.shape[0], a.shape[1],
+                                       a.strides[0], out.ctypes.data, out.strides[0]))
+        return out
+    import torch
+    _chk(mhi, "mhi")
+    rows, cols = mhi.shape
+    mei = torch.empty((rows, cols), dtype=torch.uint8, device=mhi.device)
+    check(lib.micv_mhi_energy_dev(_ctx_for(mhi, ctx).handle, mhi.data_ptr(), rows, cols, mhi.stride(0),
+                                  mei.data_ptr(), cols, _stream(mhi)))
+    return mei

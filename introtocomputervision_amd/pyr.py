@@ -85,6 +85,34 @@ def resizeLinear(src, drows, dcols, ctx=None):
     return dst
 
 
+def toGray(img, ctx=None):
+    """The colour branch of pyr::makeGaussianPyramid (Pyramids.cpp:9-15): cvtColor(COLOR_RGB2GRAY)
+    for 3/4-channel input, then convertTo(CV_32F).  img: [rows, cols] or [rows, cols, 3|4], uint8 or
+    float32, numpy (host entry point) or a contiguous CUDA tensor (device entry point)."""
+    if B.is_dev(img):
+        import torch
+        if not (img.is_contiguous() and img.dim() in (2, 3) and img.dtype in (torch.uint8, torch.float32)):
+            raise ValueError("toGray: need a contiguous uint8 / float32 CUDA tensor")
+        cn = 1 if img.dim() == 2 else int(img.shape[2])
+        rows, cols = int(img.shape[0]), int(img.shape[1])
+        es = 1 if img.dtype == torch.uint8 else 4
+        dst = torch.empty((rows, cols), dtype=torch.float32, device=img.device)
+        check(lib.micv_to_gray_f32_dev(_ctx_for(dst, ctx).handle, img.data_ptr(), rows, cols, cols * cn * es, cn,
+                                       0 if es == 1 else 5, dst.data_ptr(), cols * 4,
+                                       torch.cuda.current_stream(img.device).cuda_stream))
+        return dst
+    img = np.ascontiguousarray(img)
+    if img.dtype not in (np.uint8, np.float32) or img.ndim not in (2, 3):
+        raise ValueError("toGray: need a uint8 / float32 array of 2 or 3 dimensions")
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    rows, cols = img.shape[:2]
+    dst = np.empty((rows, cols), np.float32)
+    check(lib.micv_to_gray_f32_host(_ctx_for(dst, ctx).handle, img.ctypes.data, rows, cols,
+                                    cols * cn * img.dtype.itemsize, cn, 0 if img.dtype == np.uint8 else 5,
+                                    dst.ctypes.data, cols * 4))
+    return dst
+
+
 def rgb8ToGray(rgb, ctx=None):
     """cvtColor(COLOR_RGB2GRAY) + convertTo(CV_32F) of Pyramids.cpp:10-15 on an [rows, cols, 3]
     uint8 CUDA tensor."""

@@ -16,6 +16,7 @@
 // take the minimal micv::Mat of micv_mat.hpp (this image has no OpenCV).
 #pragma once
 
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -25,46 +26,59 @@
 
 #ifdef MICV_SHIM_WITH_OPENCV
 #include <opencv2/core/core.hpp>
+#include <opencv2/core/cuda.hpp>
 #include <opencv2/core/types.hpp>
 namespace micv_shim {
 using Mat = cv::Mat;
 using KeyPoint = cv::KeyPoint;
+using Size = cv::Size;
+// cv::cuda::GpuMat's data pointer must be memory this library's device can address (an OpenCV
+// built against HIP, or unified memory); the overloads below only pass it through.
+using GpuMat = cv::cuda::GpuMat;
 enum { F32 = CV_32F, S8 = CV_8S, U8 = CV_8U, S32 = CV_32S };
-}  // namespace micv_shim
-#else
-#include "micv_mat.hpp"
-namespace micv_shim {
-using Mat = micv::Mat;
-using KeyPoint = micv::KeyPoint;
-enum { F32 = micv::CV_32F, S8 = micv::CV_8S, U8 = micv::CV_8U, S32 = micv::CV_32S };
-}  // namespace micv_shim
-#endif
-
-namespace micv_shim {
-
 inline micv_ctx *context() {  // one context per thread, like the reference's per-call streams
     thread_local micv_ctx *ctx = nullptr;
     if (!ctx && micv_ctx_create(0, &ctx) != MICV_OK)
         throw std::runtime_error(std::string("micv: ") + micv_last_error());
     return ctx;
 }
+inline void create_continuous(GpuMat &m, int rows, int cols, int type) { cv::cuda::createContinuous(rows, cols, type, m); }
+}  // namespace micv_shim
+#else
+#include "micv_mat.hpp"
+namespace micv_shim {
+using Mat = micv::Mat;
+using KeyPoint = micv::KeyPoint;
+using Size = micv::Size;
+using GpuMat = micv::GpuMat;
+enum { F32 = micv::CV_32F, S8 = micv::CV_8S, U8 = micv::CV_8U, S32 = micv::CV_32S };
+inline micv_ctx *context() { return micv::thread_context(); }
+inline void create_continuous(GpuMat &m, int rows, int cols, int type) { m.create(rows, cols, type); }
+}  // namespace micv_shim
+#endif
+
+namespace micv_shim {
+
 inline void check(int rc) {
     if (rc != MICV_OK) throw std::runtime_error(std::string("micv: ") + micv_last_error());
 }
 inline void require(bool ok, const char *what) {
     if (!ok) throw std::invalid_argument(what);
 }
-// The reference converts with Mat::convertTo(CV_32F) (OpticalFlow.cpp:51-52); the shim accepts
-// CV_32F and CV_8U single-channel input and widens 8-bit on the host.
+inline bool frame_type_ok(const Mat &m) {  // what cvtColor(COLOR_RGB2GRAY) + convertTo(CV_32F) take here
+    return (m.depth() == U8 || m.depth() == F32) && (m.channels() == 1 || m.channels() == 3 || m.channels() == 4);
+}
+inline int depth_code(const Mat &m) { return m.depth() == U8 ? MICV_DEPTH_8U : MICV_DEPTH_32F; }
+// The reference converts its inputs itself: pyr::makeGaussianPyramid runs
+// cv::cvtColor(COLOR_RGB2GRAY) on multi-channel frames and convertTo(CV_32F) (Pyramids.cpp:9-15),
+// lk::calcOpticalFlow convertTo(CV_32F) (OpticalFlow.cpp:51-52).  Single-channel CV_32F passes
+// through untouched; everything else goes through micv_to_gray_f32_host.
 inline Mat to_f32(const Mat &m) {
     if (m.type() == F32) return m;
-    require(m.type() == U8, "micv shim: only CV_32FC1 / CV_8UC1 inputs are supported");
+    require(frame_type_ok(m), "micv shim: 1/3/4-channel CV_8U or CV_32F input expected");
     Mat f(m.rows, m.cols, F32);
-    for (int y = 0; y < m.rows; y++) {
-        const unsigned char *s = m.ptr<unsigned char>(y);
-        float *d = f.ptr<float>(y);
-        for (int x = 0; x < m.cols; x++) d[x] = static_cast<float>(s[x]);
-    }
+    check(micv_to_gray_f32_host(context(), m.data, m.rows, m.cols, m.step, m.channels(), depth_code(m),
+                                f.ptr<float>(), f.step));
     return f;
 }
 
@@ -107,9 +121,22 @@ inline void calcOpticalFlowPyr(const Mat &prevImg, const Mat &nextImg, Mat &u, M
                                const size_t winSize = 21, const size_t levels = 4) {
     micv_shim::require(prevImg.rows == nextImg.rows && prevImg.cols == nextImg.cols,
                        "lk::calcOpticalFlowPyr: size mismatch");
+    Mat uu(prevImg.rows, prevImg.cols, micv_shim::F32), vv(prevImg.rows, prevImg.cols, micv_shim::F32);
+    if (prevImg.type() == nextImg.type() && prevImg.type() != micv_shim::F32 && prevImg.step == nextImg.step) {
+        // the ps5 driver's call (Solution.cpp:63): colour and/or 8-bit frames, converted by
+        // makeGaussianPyramid (Pyramids.cpp:9-15) -- one upload, conversion on the device
+        micv_shim::require(micv_shim::frame_type_ok(prevImg),
+                           "lk::calcOpticalFlowPyr: 1/3/4-channel CV_8U or CV_32F frames expected");
+        micv_shim::check(micv_lk_flow_pyr_frames_host(
+            micv_shim::context(), prevImg.data, nextImg.data, prevImg.rows, prevImg.cols, prevImg.step,
+            prevImg.channels(), micv_shim::depth_code(prevImg), static_cast<int>(winSize),
+            static_cast<int>(levels), uu.ptr<float>(), vv.ptr<float>(), uu.step));
+        u = uu;
+        v = vv;
+        return;
+    }
     const Mat p = micv_shim::to_f32(prevImg), n = micv_shim::to_f32(nextImg);
     micv_shim::require(p.step == n.step, "lk::calcOpticalFlowPyr: inputs need equal row pitch");
-    Mat uu(p.rows, p.cols, micv_shim::F32), vv(p.rows, p.cols, micv_shim::F32);
     micv_shim::check(micv_lk_flow_pyr_host(micv_shim::context(), p.ptr<float>(), n.ptr<float>(),
                                            p.rows, p.cols, p.step, static_cast<int>(winSize),
                                            static_cast<int>(levels), uu.ptr<float>(),
@@ -137,7 +164,7 @@ inline void pyrUp(const Mat &src, Mat &dst) {
     dst = out;
 }
 inline std::vector<Mat> makeGaussianPyramid(const Mat &src, const size_t levels) {
-    const Mat grey = micv_shim::to_f32(src);  // Pyramids.cpp:9-15 (colour input: convert before calling)
+    const Mat grey = micv_shim::to_f32(src);  // Pyramids.cpp:9-15: cvtColor(RGB2GRAY) if colour, convertTo(CV_32F)
     std::vector<Mat> pyramid;
     std::vector<float *> ptrs;
     for (size_t l = 0; l < levels; l++) {
@@ -313,6 +340,48 @@ inline void findLocalMaxima(const Mat &accumulator, const unsigned int numPeaks,
                                            peaks.data(), &n));
     for (int64_t i = 0; i < n; i++) localMaxima.emplace_back(peaks[2 * i], peaks[2 * i + 1]);  // appended, Hough.cu:413
 }
+
+// The cv::cuda::GpuMat overloads (ps1_cpp/src/Hough.h:22-25, 48-51, 73-75; Hough.cu:251-286,
+// 311-340, 366-426): device-resident in and out, nothing crosses PCIe except the peak list.
+using micv_shim::GpuMat;
+inline void houghLinesAccumulate(const GpuMat &edgeMask, const unsigned int rhoBinSize,
+                                 const unsigned int thetaBinSize, GpuMat &accumulator) {
+    micv_shim::require(edgeMask.type() == micv_shim::U8, "cuda::houghLinesAccumulate: CV_8UC1 expected");  // Hough.cu:255
+    int rb = 0, tb = 0;
+    micv_shim::check(micv_hough_lines_dims(edgeMask.rows, edgeMask.cols, rhoBinSize, thetaBinSize, &rb, &tb));
+    micv_shim::create_continuous(accumulator, rb, tb, micv_shim::S32);  // :263
+    micv_shim::check(micv_hough_lines_dev(micv_shim::context(), edgeMask.ptr<uint8_t>(), edgeMask.rows,
+                                          edgeMask.cols, edgeMask.step, rhoBinSize, thetaBinSize,
+                                          accumulator.ptr<int32_t>(), nullptr));
+}
+inline void houghCirclesAccumulate(const GpuMat &edgeMask, const size_t radius, GpuMat &accumulator) {
+    micv_shim::require(edgeMask.type() == micv_shim::U8, "cuda::houghCirclesAccumulate: CV_8UC1 expected");
+    micv_shim::create_continuous(accumulator, edgeMask.rows, edgeMask.cols, micv_shim::S32);  // Hough.cu:318
+    micv_shim::check(micv_hough_circles_dev(micv_shim::context(), edgeMask.ptr<uint8_t>(), edgeMask.rows,
+                                            edgeMask.cols, edgeMask.step, static_cast<unsigned>(radius),
+                                            accumulator.ptr<int32_t>(), nullptr));
+}
+inline void findLocalMaxima(const GpuMat &accumulator, const unsigned int numPeaks, const int threshold,
+                            std::vector<std::pair<unsigned int, unsigned int>> &localMaxima) {
+    micv_shim::require(accumulator.type() == micv_shim::S32 && accumulator.isContinuous(),
+                       "cuda::findLocalMaxima: continuous CV_32SC1 expected");
+    // peaks (2 x u32 each) followed by the int64 count, in one device block
+    const size_t peak_bytes = (static_cast<size_t>(numPeaks) * 2 + 2) * sizeof(uint32_t);
+    void *blk = nullptr;
+    micv_shim::check(micv_device_malloc(micv_shim::context(), peak_bytes + 8, &blk));
+    std::vector<uint32_t> host(peak_bytes / 4 + 2);
+    int rc = micv_hough_peaks_dev(micv_shim::context(), accumulator.ptr<int32_t>(), accumulator.rows,
+                                  accumulator.cols, numPeaks, threshold, static_cast<uint32_t *>(blk),
+                                  reinterpret_cast<int64_t *>(static_cast<char *>(blk) + peak_bytes), nullptr);
+    if (rc == MICV_OK)
+        rc = micv_memcpy2d_d2h(micv_shim::context(), host.data(), peak_bytes + 8, blk, peak_bytes + 8,
+                               peak_bytes + 8, 1);
+    micv_device_free(micv_shim::context(), blk);
+    micv_shim::check(rc);
+    int64_t n = 0;
+    std::memcpy(&n, reinterpret_cast<const char *>(host.data()) + peak_bytes, 8);
+    for (int64_t i = 0; i < n; i++) localMaxima.emplace_back(host[2 * i], host[2 * i + 1]);  // appended, Hough.cu:413
+}
 }  // namespace cuda
 
 namespace serial {
@@ -334,16 +403,16 @@ inline void disparityNCorr(const Mat &left, const Mat &right, const size_t windo
 
 namespace mhi {  // ProblemSets/ps7_cpp/include/MotionHistory.h:7-28 (single-channel CV_8U frames)
 using micv_shim::Mat;
-// `blurSize` is the side of the reference's square cv::Size (MotionHistory.h:14).
+using micv_shim::Size;
 inline void frameDifference(const Mat &f1, const Mat &f2, const double thresh, Mat &diff,
-                            const int blurSize = 3, const double blurSigma = 1.0) {
+                            const Size &blurSize = Size(3, 3), const double blurSigma = 1.0) {  // MotionHistory.h:10-15
     micv_shim::require(f1.type() == micv_shim::U8 && f2.type() == micv_shim::U8 && f1.rows == f2.rows &&
                            f1.cols == f2.cols && f1.step == f2.step,
                        "mhi::frameDifference: two CV_8UC1 frames of one size expected");
     Mat out(f1.rows, f1.cols, micv_shim::U8);
     micv_shim::check(micv_mhi_frame_difference_host(micv_shim::context(), f1.ptr<uint8_t>(), f2.ptr<uint8_t>(),
-                                                    f1.rows, f1.cols, f1.step, thresh, blurSize, blurSigma,
-                                                    out.ptr<uint8_t>(), out.step));
+                                                    f1.rows, f1.cols, f1.step, thresh, blurSize.width,
+                                                    blurSize.height, blurSigma, out.ptr<uint8_t>(), out.step));
     diff = out;
 }
 inline void calcMotionHistory(Mat &history, const Mat &binaryMask, const int tau) {
@@ -353,6 +422,20 @@ inline void calcMotionHistory(Mat &history, const Mat &binaryMask, const int tau
     micv_shim::check(micv_mhi_update_host(micv_shim::context(), history.ptr<uint8_t>(), history.step,
                                           binaryMask.ptr<uint8_t>(), binaryMask.step, history.rows,
                                           history.cols, tau));
+}
+inline void energyFromHistory(const Mat &mhi, Mat &mei) {  // MotionHistory.h:23, MotionHistory.cpp:98-105
+    micv_shim::require(mhi.type() == micv_shim::U8, "mhi::energyFromHistory: CV_8UC1 expected");
+    Mat out(mhi.rows, mhi.cols, micv_shim::U8);
+    micv_shim::check(micv_mhi_energy_host(micv_shim::context(), mhi.ptr<uint8_t>(), mhi.rows, mhi.cols, mhi.step,
+                                          out.ptr<uint8_t>(), out.step));
+    mei = out;
+}
+inline void energyFromHistory(const std::vector<Mat> &mhis, std::vector<Mat> &meis) {  // :27, .cpp:107-112
+    for (const auto &m : mhis) {
+        Mat mei;
+        energyFromHistory(m, mei);
+        meis.push_back(mei);  // appended, like the reference
+    }
 }
 }  // namespace mhi
 

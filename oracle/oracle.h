@@ -92,6 +92,8 @@ int orc_lk_flow_pyr(const float *prev, const float *next, int rows, int cols, si
 
 /* cv::cvtColor(COLOR_RGB2GRAY) on 8-bit 3-channel data followed by convertTo(CV_32F)
  * (Pyramids.cpp:10-15): fixed-point R*4899 + G*9617 + B*1868, +2^13, >>14. */
+int orc_to_gray_f32(const void *src, int rows, int cols, size_t sstride_bytes, int channels, int depth,
+                    float *dst, size_t dstride);
 void orc_rgb8_to_gray_f32(const uint8_t *rgb, int rows, int cols, size_t sstride_bytes,
                           float *dst, size_t dstride);
 
@@ -189,7 +191,7 @@ int64_t orc_bf_ratio_filter(const int32_t *idx2, const float *dist2, int nq, dou
  * (MotionHistory.cpp:98-105). */
 void orc_mhi_threshold(const uint8_t *src, size_t n, double thresh, uint8_t *dst);
 int orc_mhi_frame_difference(const uint8_t *f1, const uint8_t *f2, int rows, int cols, size_t stride,
-                             double thresh, int ksize, double sigma, uint8_t *diff, size_t dstride);
+                             double thresh, int kw, int kh, double sigma, uint8_t *diff, size_t dstride);
 void orc_mhi_update(uint8_t *history, size_t hstride, const uint8_t *mask, size_t mstride, int rows,
                     int cols, int tau);
 void orc_mhi_energy(const uint8_t *mhi, size_t n, uint8_t *mei);

@@ -357,6 +357,39 @@ int orc_lk_flow_pyr(const float *prev, const float *next, int rows, int cols, si
 
 /* cv::cvtColor(COLOR_RGB2GRAY) for CV_8UC3 (OpenCV 3.4.1 imgproc/src/color.cpp RGB2Gray<uchar>:
  * R2Y=4899, G2Y=9617, B2Y=1868, yuv_shift=14) then convertTo(CV_32F). Pyramids.cpp:10-15. */
+/* The general colour entry of the path: pyr::makeGaussianPyramid (ps5_cpp/lib/Pyramids.cpp:9-15)
+ * runs cv::cvtColor(COLOR_RGB2GRAY) on anything with more than one channel and then
+ * convertTo(CV_32F); denseLKWrapper (ps5_cpp/src/Solution.cpp:48-56) does the same for the
+ * single-level mode.  OpenCV 3.4 semantics restated (not verifiable here):
+ *   CV_8U : (c0*4899 + c1*9617 + c2*1868 + 2^13) >> 14, 3 or 4 channels (alpha ignored);
+ *   CV_32F: (c0*0.299f + c1*0.587f) + c2*0.114f, unfused, left to right;
+ *   one channel: the conversion to float only.  depth: 0 = 8U, 5 = 32F (OpenCV's depth codes). */
+int orc_to_gray_f32(const void *src, int rows, int cols, size_t sstride_bytes, int channels, int depth,
+                    float *dst, size_t dstride) {
+    if ((channels != 1 && channels != 3 && channels != 4) || (depth != 0 && depth != 5)) return -1;
+    for (int y = 0; y < rows; y++) {
+        const uint8_t *row = (const uint8_t *)src + (size_t)y * sstride_bytes;
+        for (int x = 0; x < cols; x++) {
+            float g;
+            if (depth == 0) {
+                const uint8_t *s = row + (size_t)channels * x;
+                g = channels == 1 ? (float)s[0]
+                                  : (float)((s[0] * 4899 + s[1] * 9617 + s[2] * 1868 + (1 << 13)) >> 14);
+            } else {
+                const float *s = (const float *)row + (size_t)channels * x;
+                if (channels == 1) {
+                    g = s[0];
+                } else {
+                    const float a = s[0] * 0.299f, b = s[1] * 0.587f, c = s[2] * 0.114f;
+                    g = (a + b) + c;
+                }
+            }
+            AT(dst, dstride, y, x) = g;
+        }
+    }
+    return 0;
+}
+
 void orc_rgb8_to_gray_f32(const uint8_t *rgb, int rows, int cols, size_t sstride_bytes,
                           float *dst, size_t dstride) {
     for (int y = 0; y < rows; y++) {

@@ -18,24 +18,25 @@ static uint8_t sat_u8_rn(float v) { /* saturate_cast<uchar>(float): round-half-e
 /* cv::cuda::createGaussianFilter(CV_8UC1, -1, ksize, sigma) -> separable filter with a CV_32F
  * buffer: row pass u8 -> float (fmaf chain), column pass float -> saturate_cast<uchar>;
  * BORDER_REFLECT_101 (MotionHistory.cpp:50-52). */
-static void gauss_u8(const uint8_t *src, int rows, int cols, size_t stride, int ksize, double sigma,
+static void gauss_u8(const uint8_t *src, int rows, int cols, size_t stride, int kw, int kh, double sigma,
                      uint8_t *dst) {
-    float k[64];
-    orc_gaussian_kernel(ksize, sigma, k);
+    float k[64], ky[64]; /* cv::Size(kw, kh): kw taps along x, kh taps along y, one sigma */
+    orc_gaussian_kernel(kw, sigma, k);
+    orc_gaussian_kernel(kh, sigma, ky);
     float *buf = (float *)malloc((size_t)rows * cols * sizeof(float));
-    int a = ksize / 2;
+    int a = kw / 2, ay = kh / 2;
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
             float acc = 0.f;
-            for (int i = 0; i < ksize; i++)
+            for (int i = 0; i < kw; i++)
                 acc = fmaf((float)AT(src, stride, y, orc_reflect101(x + i - a, cols)), k[i], acc);
             buf[(size_t)y * cols + x] = acc;
         }
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
             float acc = 0.f;
-            for (int i = 0; i < ksize; i++)
-                acc = fmaf(buf[(size_t)orc_reflect101(y + i - a, rows) * cols + x], k[i], acc);
+            for (int i = 0; i < kh; i++)
+                acc = fmaf(buf[(size_t)orc_reflect101(y + i - ay, rows) * cols + x], ky[i], acc);
             dst[(size_t)y * cols + x] = sat_u8_rn(acc);
         }
     free(buf);
@@ -82,12 +83,12 @@ void orc_mhi_threshold(const uint8_t *src, size_t n, double thresh, uint8_t *dst
 
 /* mhi::frameDifference, MotionHistory.cpp:26-77, single-channel CV_8U frames. */
 int orc_mhi_frame_difference(const uint8_t *f1, const uint8_t *f2, int rows, int cols, size_t stride,
-                             double thresh, int ksize, double sigma, uint8_t *diff, size_t dstride) {
-    if (ksize < 1 || ksize > 31 || (ksize & 1) == 0 || !(sigma > 0)) return -1;
+                             double thresh, int kw, int kh, double sigma, uint8_t *diff, size_t dstride) {
+    if (kw < 1 || kw > 31 || (kw & 1) == 0 || kh < 1 || kh > 31 || (kh & 1) == 0 || !(sigma > 0)) return -1;
     size_t n = (size_t)rows * cols;
     uint8_t *b1 = (uint8_t *)malloc(4 * n), *b2 = b1 + n, *d = b1 + 2 * n, *t = b1 + 3 * n;
-    gauss_u8(f1, rows, cols, stride, ksize, sigma, b1); /* :50-52 */
-    gauss_u8(f2, rows, cols, stride, ksize, sigma, b2);
+    gauss_u8(f1, rows, cols, stride, kw, kh, sigma, b1); /* :50-52 */
+    gauss_u8(f2, rows, cols, stride, kw, kh, sigma, b2);
     for (size_t i = 0; i < n; i++) { /* cv::cuda::subtract on CV_8U saturates, :56 */
         int v = (int)b2[i] - (int)b1[i];
         d[i] = (uint8_t)(v < 0 ? 0 : v);

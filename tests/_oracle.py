@@ -65,6 +65,7 @@ _pd = _sig("orc_pyr_down", None, [vp, i32, i32, sz, vp, sz])
 _pu = _sig("orc_pyr_up", None, [vp, i32, i32, sz, vp, sz])
 _lkp = _sig("orc_lk_flow_pyr", i32, [vp, vp, i32, i32, sz, i32, i32, vp, vp, sz])
 _gray = _sig("orc_rgb8_to_gray_f32", None, [vp, i32, i32, sz, vp, sz])
+_togray = _sig("orc_to_gray_f32", i32, [vp, i32, i32, sz, i32, i32, vp, sz])
 
 
 def reflect101(p, n):
@@ -276,18 +277,28 @@ def hough_peaks(acc, num_peaks, threshold):
     return peaks[:n].copy()
 
 
-_mhi_fd = _sig("orc_mhi_frame_difference", i32, [vp, vp, i32, i32, sz, f64, i32, f64, vp, sz])
+_mhi_fd = _sig("orc_mhi_frame_difference", i32, [vp, vp, i32, i32, sz, f64, i32, i32, f64, vp, sz])
+_mhi_en = _sig("orc_mhi_energy", None, [vp, sz, vp])
 _mhi_thr = _sig("orc_mhi_threshold", None, [vp, sz, f64, vp])
 _mhi_upd = _sig("orc_mhi_update", None, [vp, sz, vp, sz, i32, i32, i32])
 
 
 def mhi_frame_difference(f1, f2, thresh, ksize=3, sigma=1.0):
+    """ksize: an int (square) or the reference's cv::Size as (width, height)."""
     f1 = np.ascontiguousarray(f1, dtype=np.uint8); f2 = np.ascontiguousarray(f2, dtype=np.uint8)
     r, c = f1.shape
     out = np.empty((r, c), np.uint8)
-    rc = _mhi_fd(_p(f1), _p(f2), r, c, c, float(thresh), ksize, float(sigma), _p(out), c)
+    kw, kh = ksize if isinstance(ksize, (tuple, list)) else (ksize, ksize)
+    rc = _mhi_fd(_p(f1), _p(f2), r, c, c, float(thresh), int(kw), int(kh), float(sigma), _p(out), c)
     if rc:
         raise ValueError(f"orc_mhi_frame_difference rc={rc}")
+    return out
+
+
+def mhi_energy(mhi):
+    mhi = np.ascontiguousarray(mhi, dtype=np.uint8)
+    out = np.empty_like(mhi)
+    _mhi_en(_p(mhi), mhi.size, _p(out))
     return out
 
 
@@ -304,6 +315,18 @@ def mhi_update(history, mask, tau):
     r, c = h.shape
     _mhi_upd(_p(h), c, _p(m), c, r, c, tau)
     return h
+
+
+def to_gray(img):
+    """[rows, cols] or [rows, cols, 3|4], uint8 or float32 -> grey float32 (Pyramids.cpp:9-15)."""
+    img = np.ascontiguousarray(img)
+    assert img.dtype in (np.uint8, np.float32)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    r, c = img.shape[:2]
+    out = np.empty((r, c), np.float32)
+    rc = _togray(_p(img), r, c, c * cn * img.dtype.itemsize, cn, 0 if img.dtype == np.uint8 else 5, _p(out), c)
+    assert rc == 0
+    return out
 
 
 def rgb8_to_gray(rgb):

@@ -56,6 +56,37 @@ int main(int argc, char **argv) {
         pyr::pyrUp(pyramid[3], up);
         save(dir + "/pyr3_up.f32", up);
 
+        // ---- ps5 as the UNCHANGED driver calls it: denseLKWrapper hands the colour frames (cv::imread:
+        // CV_8UC3) to lk::calcOpticalFlowPyr (Solution.cpp:63), makeGaussianPyramid converts
+        // (Pyramids.cpp:9-15); the single-level mode converts first (Solution.cpp:48-56, 61) -------
+        {
+            Mat prevC = load(dir + "/prev_rgb.u8", rows, cols, micv::CV_8UC3);
+            Mat nextC = load(dir + "/next_rgb.u8", rows, cols, micv::CV_8UC3);
+            if (prevC.channels() != 3 || prevC.step != (size_t)cols * 3) return 3;
+            Mat uc, vc;
+            lk::calcOpticalFlowPyr(prevC, nextC, uc, vc, 15);
+            save(dir + "/lkpyr_rgb_u.f32", uc);
+            save(dir + "/lkpyr_rgb_v.f32", vc);
+            std::vector<Mat> pc = pyr::makeGaussianPyramid(prevC, 3);
+            save(dir + "/pyr_rgb0.f32", pc[0]);
+            save(dir + "/pyr_rgb2.f32", pc[2]);
+            Mat un, vn;  // LKMode::NAIVE branch: grey first, then lk::calcOpticalFlow
+            lk::calcOpticalFlow(pc[0], pyr::makeGaussianPyramid(nextC, 1)[0], un, vn, 15);
+            save(dir + "/lk_rgb_u.f32", un);
+            Mat prevF = load(dir + "/prev_rgbf.f32", rows, cols, micv::CV_32FC3);
+            Mat nextF = load(dir + "/next_rgbf.f32", rows, cols, micv::CV_32FC3);
+            Mat uf, vf;
+            lk::calcOpticalFlowPyr(prevF, nextF, uf, vf, 15);
+            save(dir + "/lkpyr_rgbf_u.f32", uf);
+            Mat prevA = load(dir + "/prev_rgba.u8", rows, cols, micv::CV_8UC4);
+            save(dir + "/pyr_rgba0.f32", pyr::makeGaussianPyramid(prevA, 1)[0]);
+            Mat prev8 = load(dir + "/prev_g8.u8", rows, cols, micv_shim::U8);  // grey 8-bit: convertTo only
+            Mat next8 = load(dir + "/next_g8.u8", rows, cols, micv_shim::U8);
+            Mat u8_, v8_;
+            lk::calcOpticalFlowPyr(prev8, next8, u8_, v8_, 15);
+            save(dir + "/lkpyr_g8_u.f32", u8_);
+        }
+
         // ---- ps4: harrisHelper with config/ps4.yaml parameters ----------------------------------
         Mat chk = load(dir + "/chk.f32", rows, cols, micv_shim::F32);
         Mat gx, gy, R, corners;
@@ -92,6 +123,22 @@ int main(int argc, char **argv) {
         for (auto &p : peaks) { pf.push_back(p.first); pf.push_back(p.second); }
         save(dir + "/peaks.u32", pf.data(), pf.size() * 4);
         save(dir + "/acc.i32", acc);
+        {   // the cv::cuda::GpuMat overloads (Hough.h:22-25, 48-51, 73-75): device-resident chain
+            micv_shim::GpuMat d_mask(mask), d_acc, d_circ;
+            cuda::houghLinesAccumulate(d_mask, 2, 3, d_acc);
+            Mat acc2;
+            d_acc.download(acc2);
+            save(dir + "/acc_gpumat.i32", acc2);
+            std::vector<std::pair<unsigned, unsigned>> peaks2 = {{7u, 7u}};  // appended to (Hough.cu:413)
+            cuda::findLocalMaxima(d_acc, 6, 20, peaks2);
+            std::vector<unsigned> pf2;
+            for (auto &p : peaks2) { pf2.push_back(p.first); pf2.push_back(p.second); }
+            save(dir + "/peaks_gpumat.u32", pf2.data(), pf2.size() * 4);
+            cuda::houghCirclesAccumulate(d_mask, 12, d_circ);
+            Mat circ;
+            d_circ.download(circ);
+            save(dir + "/circ_gpumat.i32", circ);
+        }
 
         // ---- next rows: ps1 edge front-end, ps7 motion history, ps4 matching ----------------------
         Mat img8 = load(dir + "/img8.u8", rows, cols, micv_shim::U8);
@@ -100,11 +147,23 @@ int main(int argc, char **argv) {
         save(dir + "/edges.u8", edges);
         Mat f2 = load(dir + "/img8b.u8", rows, cols, micv_shim::U8);
         Mat diff;
-        mhi::frameDifference(img8, f2, 20, diff, 5, 1.5);
+        mhi::frameDifference(img8, f2, 20, diff, micv_shim::Size(5, 5), 1.5);  // MotionHistory.h:10-15
         save(dir + "/mhi_diff.u8", diff);
+        Mat diff73, diffdef;
+        mhi::frameDifference(img8, f2, 10, diff73, micv_shim::Size(7, 3), 2.0);
+        save(dir + "/mhi_diff73.u8", diff73);
+        mhi::frameDifference(img8, f2, 10, diffdef);  // defaults: cv::Size(3, 3), sigma 1
+        save(dir + "/mhi_diffdef.u8", diffdef);
         Mat hist = load(dir + "/hist.u8", rows, cols, micv_shim::U8);
         mhi::calcMotionHistory(hist, diff, 25);
         save(dir + "/mhi_hist.u8", hist);
+        Mat mei;
+        mhi::energyFromHistory(hist, mei);  // MotionHistory.h:23
+        save(dir + "/mhi_mei.u8", mei);
+        std::vector<Mat> meis;
+        mhi::energyFromHistory(std::vector<Mat>{hist, diff}, meis);  // :27
+        if (meis.size() != 2) return 4;
+        save(dir + "/mhi_mei1.u8", meis[1]);
         Mat d1 = load(dir + "/desc1.f32", 60, 128, micv_shim::F32);
         Mat d2 = load(dir + "/desc2.f32", 75, 128, micv_shim::F32);
         std::vector<std::pair<int, int>> good;

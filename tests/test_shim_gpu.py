@@ -42,6 +42,19 @@ def test_shim_matches_oracle(tmp_path):
     desc1, desc2 = tm.descriptors(60, 75, 128, 9)
     desc2[5] = desc2[3]
     desc1[0] = desc2[3]
+    # colour frames as cv::imread would hand them to the unchanged ps5 driver
+    rng = np.random.default_rng(11)
+    def colourise(g):  # three different, clipped mixtures of the grey texture: R, G, B really differ
+        c = np.stack([g * 0.9 + 10, g * 0.7 + 40, 255 - g * 0.8], axis=-1)
+        return np.clip(c + rng.integers(-3, 4, c.shape), 0, 255)
+    prev_rgb, next_rgb = colourise(prev).astype(np.uint8), colourise(nxt).astype(np.uint8)
+    prev_rgbf, next_rgbf = (colourise(prev) / 3.0).astype(np.float32), (colourise(nxt) / 3.0).astype(np.float32)
+    prev_rgba = np.concatenate([prev_rgb, rng.integers(0, 256, (rows, cols, 1)).astype(np.uint8)], axis=-1)
+    prev_g8, next_g8 = prev.astype(np.uint8), nxt.astype(np.uint8)
+    for name, a in (("prev_rgb.u8", prev_rgb), ("next_rgb.u8", next_rgb), ("prev_rgbf.f32", prev_rgbf),
+                    ("next_rgbf.f32", next_rgbf), ("prev_rgba.u8", prev_rgba), ("prev_g8.u8", prev_g8),
+                    ("next_g8.u8", next_g8)):
+        np.ascontiguousarray(a).tofile(os.path.join(d, name))
     for name, a in (("prev.f32", prev), ("next.f32", nxt), ("chk.f32", chk), ("left.f32", left),
                     ("right.f32", right), ("mask.u8", mask), ("img8.u8", img8), ("img8b.u8", img8b),
                     ("hist.u8", hist), ("desc1.f32", desc1), ("desc2.f32", desc2)):
@@ -61,6 +74,22 @@ def test_shim_matches_oracle(tmp_path):
     p3 = orc.gaussian_pyramid(prev, 4)[3]
     assert np.array_equal(rd("pyr3.f32", np.float32, p3.shape), p3)
     assert np.array_equal(rd("pyr3_up.f32", np.float32, (2 * p3.shape[0], 2 * p3.shape[1])), orc.pyr_up(p3))
+    # the colour branch: Pyramids.cpp:9-15 -> OpticalFlow.cpp:122-167, bit for bit
+    pg, ng = orc.to_gray(prev_rgb), orc.to_gray(next_rgb)
+    assert not np.array_equal(pg, prev) and pg.std() > 5  # a real conversion, not a pass-through
+    assert np.array_equal(pg, orc.rgb8_to_gray(prev_rgb))
+    ecu, ecv = orc.lk_flow_pyr(pg, ng, 15, 4)
+    assert np.array_equal(rd("lkpyr_rgb_u.f32", np.float32, (rows, cols)), ecu)
+    assert np.array_equal(rd("lkpyr_rgb_v.f32", np.float32, (rows, cols)), ecv)
+    assert np.array_equal(rd("pyr_rgb0.f32", np.float32, (rows, cols)), pg)
+    pg2 = orc.gaussian_pyramid(pg, 3)[2]
+    assert np.array_equal(rd("pyr_rgb2.f32", np.float32, pg2.shape), pg2)
+    assert np.array_equal(rd("lk_rgb_u.f32", np.float32, (rows, cols)), orc.lk_flow(pg, ng, 15)[0])
+    efu, _ = orc.lk_flow_pyr(orc.to_gray(prev_rgbf), orc.to_gray(next_rgbf), 15, 4)
+    assert np.array_equal(rd("lkpyr_rgbf_u.f32", np.float32, (rows, cols)), efu)
+    assert np.array_equal(rd("pyr_rgba0.f32", np.float32, (rows, cols)), pg)  # alpha ignored
+    e8u, _ = orc.lk_flow_pyr(prev_g8.astype(np.float32), next_g8.astype(np.float32), 15, 4)
+    assert np.array_equal(rd("lkpyr_g8_u.f32", np.float32, (rows, cols)), e8u)
     gx, gy = orc.sobel(chk, 3, 1.0)
     R = orc.harris_response(gx, gy, 5, 1.5, 0.04)
     assert np.array_equal(rd("harris_R.f32", np.float32, (rows, cols)), R)
@@ -74,11 +103,22 @@ def test_shim_matches_oracle(tmp_path):
     acc = orc.hough_lines(mask, 1, 1)
     assert np.array_equal(rd("acc.i32", np.int32, acc.shape), acc)
     assert np.array_equal(rd("peaks.u32", np.uint32).reshape(-1, 2), orc.hough_peaks(acc, 10, 40))
+    # GpuMat overloads: same accumulators / peaks from device-resident inputs
+    acc2 = orc.hough_lines(mask, 2, 3)
+    assert np.array_equal(rd("acc_gpumat.i32", np.int32, acc2.shape), acc2)
+    pk2 = rd("peaks_gpumat.u32", np.uint32).reshape(-1, 2)
+    assert np.array_equal(pk2[0], [7, 7]) and np.array_equal(pk2[1:], orc.hough_peaks(acc2, 6, 20))
+    assert np.array_equal(rd("circ_gpumat.i32", np.int32, (rows, cols)), orc.hough_circles(mask, 12))
     # next rows through the shim's host-pointer path
     assert np.array_equal(rd("edges.u8", np.uint8, (rows, cols)), tc.oracle_edges(img8, 5, 1.4, 30, 90))
     ediff = orc.mhi_frame_difference(img8, img8b, 20, 5, 1.5)
     assert np.array_equal(rd("mhi_diff.u8", np.uint8, (rows, cols)), ediff)
-    assert np.array_equal(rd("mhi_hist.u8", np.uint8, (rows, cols)), orc.mhi_update(hist, ediff, 25))
+    ehist = orc.mhi_update(hist, ediff, 25)
+    assert np.array_equal(rd("mhi_hist.u8", np.uint8, (rows, cols)), ehist)
+    assert np.array_equal(rd("mhi_diff73.u8", np.uint8, (rows, cols)), orc.mhi_frame_difference(img8, img8b, 10, (7, 3), 2.0))
+    assert np.array_equal(rd("mhi_diffdef.u8", np.uint8, (rows, cols)), orc.mhi_frame_difference(img8, img8b, 10, (3, 3), 1.0))
+    assert np.array_equal(rd("mhi_mei.u8", np.uint8, (rows, cols)), orc.mhi_energy(ehist))
+    assert np.array_equal(rd("mhi_mei1.u8", np.uint8, (rows, cols)), orc.mhi_energy(ediff))
     eidx, edist = tm.oracle_knn2(desc1, desc2)
     em, ed = tm.oracle_ratio(eidx, edist, 0.75)
     assert len(em) > 0 and np.array_equal(rd("good.i32", np.int32).reshape(-1, 2), em)
