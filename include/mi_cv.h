@@ -238,6 +238,22 @@ int micv_sift_keypoints_host(micv_ctx *ctx, const float *gx, const float *gy, in
                              size_t gstride, const int32_t *locs_yx, int64_t n, float size,
                              float *kp_xysa);
 
+/* The SIFT-style descriptor window at those keypoints: the step Solution::siftHelper runs next
+ * (ps4_cpp/src/Solution.cpp:166-169, cv::xfeatures2d::SIFT::compute).  OpenCV's SIFT is third-party
+ * code outside the reference tree (parity unpinned); this is its published per-keypoint algorithm
+ * -- 4 x 4 spatial x 8 orientation bins, window rotated by the keypoint angle, bin width
+ * 3 * size / 2 px, Gaussian weight, trilinear distribution, normalise -> clamp 0.2 -> renormalise to
+ * 512 -> 8-bit values stored as float -- sampled on the harris::getGradients fields, with the
+ * arithmetic fixed as DESIGN.md section 2 states (bit-exact between library and checker).
+ * kp_xysa: n x {x, y, size, angle_deg} as micv_sift_keypoints writes them; desc: n rows of 128
+ * floats, dstride bytes apart.  Keypoints without a positive finite size get an all-zero row. */
+int micv_sift_descriptors_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                              size_t gstride, const float *kp_xysa, int64_t n, float *desc,
+                              size_t dstride, micv_stream stream);
+int micv_sift_descriptors_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                               size_t gstride, const float *kp_xysa, int64_t n, float *desc,
+                               size_t dstride);
+
 /* ------------------------------------------------------------- ps2: stereo --------- */
 
 #define MICV_STEREO_COLS_2R     1 /* window of (2r+1) rows x 2r columns, DisparitySSD.cu:84 */

@@ -100,6 +100,8 @@ SIGNATURES = {
     "micv_sift_angles_host": (i32, [vp, vp, vp, i32, i32, sz, vp, sz]),
     "micv_sift_keypoints_dev": (i32, [vp, vp, vp, i32, i32, sz, vp, i64, f32, vp, vp]),
     "micv_sift_keypoints_host": (i32, [vp, vp, vp, i32, i32, sz, vp, i64, f32, vp]),
+    "micv_sift_descriptors_dev": (i32, [vp, vp, vp, i32, i32, sz, vp, i64, vp, sz, vp]),
+    "micv_sift_descriptors_host": (i32, [vp, vp, vp, i32, i32, sz, vp, i64, vp, sz]),
     # ps2
     "micv_disparity_ssd_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz, vp]),
     "micv_disparity_ssd_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, sz]),

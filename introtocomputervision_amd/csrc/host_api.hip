@@ -341,6 +341,28 @@ int micv_sift_keypoints_host(micv_ctx *ctx, const float *gx, const float *gy, in
     return MICV_OK;
 }
 
+int micv_sift_descriptors_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                               size_t gstride, const float *kp_xysa, int64_t n, float *desc,
+                               size_t dstride) {
+    HOST_PROLOGUE("micv_sift_descriptors_host");
+    MICV_REQUIRE(gx && gy && rows > 0 && cols > 0 && n >= 0 && (n == 0 || (kp_xysa && desc)),
+                 "micv_sift_descriptors_host: bad argument");
+    MICV_REQUIRE(stride_ok(gstride, cols, 4) && dstride % 4 == 0 && dstride >= 512,
+                 "micv_sift_descriptors_host: bad stride");
+    if (n == 0) return MICV_OK;
+    const size_t rb = (size_t)cols * 4, bytes = rb * rows;
+    DevBuf dx(bytes), dy(bytes), dk((size_t)n * 16), dd((size_t)n * 512);
+    MICV_ALLOC_OK(dx); MICV_ALLOC_OK(dy); MICV_ALLOC_OK(dk); MICV_ALLOC_OK(dd);
+    MICV_TRY(up2d(dx.p, gx, gstride, rb, rows, s));
+    MICV_TRY(up2d(dy.p, gy, gstride, rb, rows, s));
+    MICV_HIP(hipMemcpyAsync(dk.p, kp_xysa, (size_t)n * 16, hipMemcpyHostToDevice, s));
+    MICV_TRY(micv_sift_descriptors_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb, dk.as<float>(), n,
+                                       dd.as<float>(), 512, s));
+    MICV_TRY(down2d(desc, dstride, dd.p, 512, (int)n, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
 static int stereo_host(bool ncc, micv_ctx *ctx, const float *left, const float *right, int rows,
                        int cols, size_t stride, int rad, int min_d, int max_d, int flags,
                        int8_t *disp, size_t dstride) {

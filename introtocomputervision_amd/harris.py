@@ -129,3 +129,28 @@ def getKeypoints(gradX, gradY, cornerLocs, size, ctx=None):
                                        B.stride_bytes(gradX), locs.ctypes.data, n, float(size),
                                        kp.ctypes.data))
     return kp
+
+
+def computeDescriptors(gradX, gradY, keypoints, ctx=None):
+    """The descriptor step of Solution::siftHelper (ps4_cpp/src/Solution.cpp:166-169,
+    cv::xfeatures2d::SIFT::compute): [n, 4] keypoints (x, y, size, angle_deg) as getKeypoints returns
+    them -> [n, 128] float32 descriptors (4 x 4 x 8 bins, 8-bit values).  Arithmetic: DESIGN.md §2."""
+    B.check2d(gradX, np.float32, name="gradX")
+    B.check2d(gradY, np.float32, name="gradY")
+    rows, cols = gradX.shape
+    c = _ctx_for(gradX, ctx)
+    if B.is_dev(gradX):
+        import torch
+        kp = keypoints.to(torch.float32).contiguous().reshape(-1, 4)
+        n = int(kp.shape[0])
+        desc = torch.empty((n, 128), dtype=torch.float32, device=gradX.device)
+        check(lib.micv_sift_descriptors_dev(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                            B.stride_bytes(gradX), kp.data_ptr(), n, desc.data_ptr(), 512,
+                                            B.stream_of(gradX)))
+        return desc
+    kp = np.ascontiguousarray(keypoints, dtype=np.float32).reshape(-1, 4)
+    n = kp.shape[0]
+    desc = np.empty((n, 128), np.float32)
+    check(lib.micv_sift_descriptors_host(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                         B.stride_bytes(gradX), kp.ctypes.data, n, desc.ctypes.data, 512))
+    return desc

@@ -280,6 +280,31 @@ inline void getKeypoints(const Mat &gradX, const Mat &gradY,
     for (size_t i = 0; i < cornerLocs.size(); i++)
         keypoints.emplace_back(kp[4 * i], kp[4 * i + 1], kp[4 * i + 2], kp[4 * i + 3], 0.f);  // :45
 }
+// The descriptor step of Solution::siftHelper (ps4_cpp/src/Solution.cpp:166-169): where the
+// reference calls cv::xfeatures2d::SIFT::compute(img, keypoints, descriptors), a build without
+// opencv_contrib calls this on the gradient fields it already has.  descriptors: CV_32F, one row of
+// 128 values per keypoint (the layout of OpenCV's SIFT output, ready for the BFMatcher step).
+inline void computeDescriptors(const Mat &gradX, const Mat &gradY, const std::vector<KeyPoint> &keypoints,
+                               Mat &descriptors) {
+    micv_shim::require(gradX.rows == gradY.rows && gradX.cols == gradY.cols &&
+                           gradX.type() == micv_shim::F32 && gradY.type() == micv_shim::F32 &&
+                           gradX.step == gradY.step,
+                       "sift::computeDescriptors: gradient mismatch");
+    std::vector<float> kp(keypoints.size() * 4);
+    for (size_t i = 0; i < keypoints.size(); i++) {
+        kp[4 * i] = keypoints[i].pt.x;
+        kp[4 * i + 1] = keypoints[i].pt.y;
+        kp[4 * i + 2] = keypoints[i].size;
+        kp[4 * i + 3] = keypoints[i].angle;
+    }
+    Mat out(static_cast<int>(keypoints.size()), 128, micv_shim::F32);
+    if (!keypoints.empty())
+        micv_shim::check(micv_sift_descriptors_host(micv_shim::context(), gradX.ptr<float>(), gradY.ptr<float>(),
+                                                    gradX.rows, gradX.cols, gradX.step, kp.data(),
+                                                    static_cast<int64_t>(keypoints.size()), out.ptr<float>(),
+                                                    out.step));
+    descriptors = out;
+}
 }  // namespace sift
 
 namespace micv_shim {

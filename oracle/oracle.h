@@ -121,6 +121,14 @@ void orc_sift_angles(const float *gx, const float *gy, int rows, int cols, size_
 void orc_sift_keypoints(const float *gx, const float *gy, int rows, int cols, size_t stride,
                         const int32_t *locs_yx, int64_t n, float size, float *kp_xysa);
 
+/* The SIFT-style descriptor window at the keypoints above (call site ps4_cpp/src/Solution.cpp:166-169,
+ * cv::xfeatures2d::SIFT::compute).  PARITY UNPINNED: OpenCV's SIFT is absent third-party code; this is
+ * the published 4x4x8 algorithm sampled on the harris::getGradients fields with every transcendental
+ * and the accumulation order fixed -- see oracle_sift.c.  desc is [n][128] (row pitch dstride floats),
+ * values are the 8-bit quantised descriptor stored as float like cv::xfeatures2d::SIFT's CV_32F output. */
+int orc_sift_descriptors(const float *gx, const float *gy, int rows, int cols, size_t stride,
+                         const float *kp_xysa, int64_t n, float *desc, size_t dstride);
+
 /* ---- ps2: window stereo ---- */
 
 #define ORC_STEREO_COLS_2R     1  /* reproduce CUDA's `i < 2*windowRad` column count (DisparitySSD.cu:84) */

@@ -197,6 +197,21 @@ def harris_refine(resp, threshold, min_distance):
     return corners, locs[:n].copy()
 
 
+_sdesc = _sig("orc_sift_descriptors", i32, [vp, vp, i32, i32, sz, vp, i64, vp, sz])
+
+
+def sift_descriptors(gx, gy, kps):
+    """kps: [n, 4] float32 (x, y, size, angle_deg) -> [n, 128] float32 (8-bit values)."""
+    gx = _f(gx); gy = _f(gy)
+    kps = np.ascontiguousarray(kps, dtype=np.float32).reshape(-1, 4)
+    r, c = gx.shape
+    out = np.zeros((len(kps), 128), np.float32)
+    rc = _sdesc(_p(gx), _p(gy), r, c, c, _p(kps), len(kps), _p(out), 128)
+    if rc:
+        raise ValueError(f"orc_sift_descriptors rc={rc}")
+    return out
+
+
 def sift_angles(gx, gy):
     gx = _f(gx); gy = _f(gy)
     r, c = gx.shape

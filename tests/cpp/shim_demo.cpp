@@ -103,6 +103,16 @@ int main(int argc, char **argv) {
         std::vector<float> kpf;
         for (auto &k : kps) { kpf.push_back(k.pt.x); kpf.push_back(k.pt.y); kpf.push_back(k.size); kpf.push_back(k.angle); }
         save(dir + "/kps.f32", kpf.data(), kpf.size() * 4);
+        Mat sdesc;  // siftHelper's descriptor + matching steps (Solution.cpp:166-184) on the same keypoints
+        sift::computeDescriptors(gx, gy, kps, sdesc);
+        if (sdesc.rows != (int)kps.size() || sdesc.cols != 128) return 5;
+        save(dir + "/sift_desc.f32", sdesc);
+        std::vector<std::pair<int, int>> selfm;
+        std::vector<float> selfd;
+        sol::matchDescriptors(sdesc, sdesc, 0.75, selfm, selfd);
+        std::vector<int> sm;
+        for (auto &g : selfm) { sm.push_back(g.first); sm.push_back(g.second); }
+        save(dir + "/sift_selfmatch.i32", sm.data(), sm.size() * 4);
 
         // ---- ps2: left-reference pass of disparitySSDPair (minD = -range, maxD = 0) ---------------
         Mat left = load(dir + "/left.f32", rows, cols, micv_shim::F32);

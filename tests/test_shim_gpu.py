@@ -98,6 +98,13 @@ def test_shim_matches_oracle(tmp_path):
     kp = rd("kps.f32", np.float32).reshape(-1, 4)
     ekp = orc.sift_keypoints(gx, gy, locs, 10)
     assert np.array_equal(kp[:, :3], ekp[:, :3]) and np.allclose(kp[:, 3], ekp[:, 3], atol=1e-3, rtol=0)
+    edesc = orc.sift_descriptors(gx, gy, ekp)
+    # the shim hands the kernel the keypoint angles IT computed (device atan2f), the oracle its own:
+    # compare on the shim's keypoints so the descriptor stage itself is bit for bit
+    assert np.array_equal(rd("sift_desc.f32", np.float32, (len(kp), 128)), orc.sift_descriptors(gx, gy, kp))
+    assert np.abs(rd("sift_desc.f32", np.float32, (len(kp), 128)) - edesc).max() <= 1
+    sm = rd("sift_selfmatch.i32", np.int32).reshape(-1, 2)
+    assert len(sm) > 0 and np.array_equal(sm[:, 0], sm[:, 1])  # every descriptor's nearest neighbour is itself
     assert np.array_equal(rd("disp_cuda.i8", np.int8, (rows, cols)), orc.disparity_ssd(left, right, 5, -30, 0, 3))
     assert np.array_equal(rd("disp_serial.i8", np.int8, (rows, cols)), orc.disparity_ssd_serial(left, right, 5, -30, 0))
     acc = orc.hough_lines(mask, 1, 1)

@@ -1,0 +1,165 @@
+"""The SIFT-style descriptor window (call site ps4_cpp/src/Solution.cpp:166-169; spec DESIGN.md §2).
+PARITY UNPINNED against OpenCV's SIFT (absent third-party code); what is tested: the oracle's own
+known-answer properties on the CPU, and bit-exact agreement of the HIP kernel with the oracle."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+from introtocomputervision_amd import synth
+
+
+def scene(rows, cols, seed=7):
+    return synth.smooth_noise(seed, rows, cols) + synth.checkerboard(rows, cols, square=30) * 0.5
+
+
+def harris_keypoints(img, thr=1e8, size=10):
+    gx, gy = orc.sobel(img, 3, 1.0)
+    R = orc.harris_response(gx, gy, 5, 1.5, 0.04)
+    _, locs = orc.harris_refine(R, thr, 5)
+    return gx, gy, locs, orc.sift_keypoints(gx, gy, locs, size)
+
+
+def test_oracle_descriptor_shape_norm_and_clamp():
+    gx, gy, locs, kps = harris_keypoints(scene(240, 320))
+    d = orc.sift_descriptors(gx, gy, kps)
+    assert d.shape == (len(kps), 128) and len(kps) > 40
+    assert np.array_equal(d, np.round(d)) and d.min() >= 0 and d.max() <= 255      # 8-bit values
+    nrm = np.linalg.norm(d, axis=1)
+    assert np.all(np.abs(nrm - 512) < 8)                                            # renormalised to 512 (+- rounding)
+    assert d.max() <= np.ceil(0.2 * 512 * 1.45)   # clamp at 0.2 before the renormalisation: no bin can dominate
+    assert np.array_equal(orc.sift_descriptors(gx, gy, kps), d)                     # deterministic
+
+
+def test_oracle_descriptor_is_rotation_invariant():
+    """np.rot90 maps the gradient fields and the keypoint angles exactly; the descriptors of
+    corresponding keypoints must agree up to the final 8-bit rounding."""
+    img = scene(240, 320)
+    gx, gy, locs, kps = harris_keypoints(img)
+    d = orc.sift_descriptors(gx, gy, kps)
+    rows, cols = img.shape
+    inner = (locs[:, 0] > 60) & (locs[:, 0] < rows - 60) & (locs[:, 1] > 60) & (locs[:, 1] < cols - 60)
+    assert inner.sum() >= 10
+    h, w, l = rows, cols, locs.copy()
+    for k in (1, 2, 3):
+        l = np.stack([w - 1 - l[:, 1], l[:, 0]], 1)
+        h, w = w, h
+        gx2, gy2 = orc.sobel(np.ascontiguousarray(np.rot90(img, k)), 3, 1.0)
+        kps2 = orc.sift_keypoints(gx2, gy2, l.astype(np.int32), 10)
+        da = (kps[:, 3] - kps2[:, 3] - 90.0 * k) % 360  # rot90 turns every keypoint angle by -90 degrees
+        assert np.all(np.minimum(da, 360 - da)[inner] < 1e-3)
+        d2 = orc.sift_descriptors(gx2, gy2, kps2)
+        assert np.abs(d - d2)[inner].max() <= 1
+
+
+def test_oracle_descriptor_scale_of_gradients_and_edge_cases():
+    gx, gy, locs, kps = harris_keypoints(scene(200, 260))
+    d = orc.sift_descriptors(gx, gy, kps)
+    # the descriptor is normalised: scaling both gradient fields by a power of two changes nothing
+    assert np.array_equal(orc.sift_descriptors(gx * 4, gy * 4, kps), d)
+    assert np.array_equal(orc.sift_descriptors(gx * 2.0 ** -30, gy * 2.0 ** -30, kps), d)
+    # flat gradients / invalid keypoints / keypoints whose window leaves the image
+    z = np.zeros_like(gx)
+    assert not orc.sift_descriptors(z, z, kps[:3]).any()
+    bad = np.array([[50, 50, 0, 10], [50, 50, -3, 10], [np.nan, 50, 10, 0], [50, 50, 10, np.inf],
+                    [50, 50, np.inf, 0]], np.float32)
+    assert not orc.sift_descriptors(gx, gy, bad).any()
+    edge = np.array([[0, 0, 10, 30], [259, 199, 10, -170], [-40, 100, 10, 0], [130, 100, 400, 45],
+                     [130, 100, 0.5, 45], [130.4, 99.6, 8 / 3, 400]], np.float32)
+    e = orc.sift_descriptors(gx, gy, edge)
+    assert e[0].any() and e[1].any() and e[3].any() and e[5].any()
+    # angles are taken modulo 360 (sift::getKeypoints hands over (-180, 180])
+    a = orc.sift_descriptors(gx, gy, np.array([[130, 100, 10, -170]], np.float32))
+    b = orc.sift_descriptors(gx, gy, np.array([[130, 100, 10, 190]], np.float32))
+    assert np.abs(a - b).max() <= 1
+    # matching a scene against a shifted copy: the descriptors of corresponding corners are nearest
+    img = scene(200, 260)
+    img2 = np.ascontiguousarray(np.roll(img, (3, -4), (0, 1)))
+    gx2, gy2, locs2, kps2 = harris_keypoints(img2)
+    d2 = orc.sift_descriptors(gx2, gy2, kps2)
+    rows, cols = img.shape
+    ok = 0
+    for i, (y, x) in enumerate(locs):
+        if not (70 < y < rows - 70 and 70 < x < cols - 70):
+            continue
+        j = np.argmin(((d2 - d[i]) ** 2).sum(1))
+        ok += (abs(locs2[j][0] - (y + 3)) <= 1 and abs(locs2[j][1] - (x - 4)) <= 1)
+    assert ok >= 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols,size,thr", [(240, 320, 10, 1e8), (135, 241, 10, 1e7), (480, 640, 8 / 3, 1e8),
+                                                (97, 131, 21.5, 1e6), (300, 500, 4, 1e8)])
+def test_descriptors_gpu_match_oracle(rows, cols, size, thr):
+    import torch
+    from introtocomputervision_amd import harris
+    img = scene(rows, cols, seed=rows)
+    gx, gy, locs, kps = harris_keypoints(img, thr, size)
+    assert len(kps) > 5
+    extra = np.array([[0, 0, size, 30], [cols - 1, rows - 1, size, -170], [-40, 10, size, 0], [10, 10, 0, 0],
+                      [cols / 2 + 0.4, rows / 2 - 0.4, size, 400], [cols / 2, rows / 2, np.nan, 1],
+                      [cols / 2, rows / 2, 3 * max(rows, cols), 77]], np.float32)
+    kps = np.concatenate([kps, extra])
+    exp = orc.sift_descriptors(gx, gy, kps)
+    dgx, dgy = torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda()
+    got = harris.computeDescriptors(dgx, dgy, torch.from_numpy(kps).cuda())
+    assert np.array_equal(got.cpu().numpy(), exp)
+    assert np.array_equal(harris.computeDescriptors(gx, gy, kps), exp)  # host-pointer flavour
+    # pitched gradient fields (cv::Mat ROI)
+    big = torch.zeros((rows, cols + 24), device="cuda")
+    bx, by = big.clone(), big.clone()
+    bx[:, 8:8 + cols] = dgx
+    by[:, 8:8 + cols] = dgy
+    got2 = harris.computeDescriptors(bx[:, 8:8 + cols], by[:, 8:8 + cols], torch.from_numpy(kps).cuda())
+    assert np.array_equal(got2.cpu().numpy(), exp)
+    assert harris.computeDescriptors(dgx, dgy, torch.zeros((0, 4), device="cuda")).shape == (0, 128)
+
+
+@pytest.mark.gpu
+def test_c5_4k_harris_descriptors_match_lk():
+    """BASELINE config C5 (3840x2160): Harris -> keypoints -> DESCRIPTORS -> knn2 + ratio test -> LK
+    refine, the chain of Solution::siftHelper (ps4_cpp/src/Solution.cpp:141-184) + ps5's LK on a frame
+    and its translated copy.  Every stage bit-exact against the oracle chain; the matches must pair
+    each corner with its translated twin."""
+    import torch
+    import test_match as tm
+    from introtocomputervision_amd import harris, lk, match
+    rows, cols = 2160, 3840
+    tex = synth.smooth_noise(0x5EED0004, rows, cols)
+    chk = synth.checkerboard(rows, cols, square=40)
+    prev = np.round(tex * (chk / 192.0)).astype(np.float32)
+    nxt = np.ascontiguousarray(np.roll(prev, shift=(-2, 3), axis=(0, 1)))
+    dp, dn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
+    # the oracle is run on a crop for the descriptor / matching stages (the full-frame Harris list has
+    # ~5000 corners; 107x107 windows each are seconds on the CPU, the matcher is O(n^2))
+    stages = []
+    for d_img, h_img in ((dp, prev), (dn, nxt)):
+        gx, gy = harris.getGradients(d_img, 3)
+        R = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04)
+        _, locs = harris.refineCorners(R, 5e8, 5, capacity=1 << 20)
+        kp = harris.getKeypoints(gx, gy, locs, 10)
+        desc = harris.computeDescriptors(gx, gy, kp)
+        stages.append((gx, gy, locs, kp, desc))
+    (gx1, gy1, l1, kp1, d1), (gx2, gy2, l2, kp2, d2) = stages
+    n1 = len(l1)
+    assert n1 > 1000 and d1.shape == (n1, 128)
+    egx, egy = orc.sobel(prev, 3, 1.0)
+    sel = np.arange(0, n1, max(1, n1 // 300))  # every k-th keypoint against the oracle, full-size fields
+    ed = orc.sift_descriptors(egx, egy, kp1.cpu().numpy()[sel])
+    assert np.array_equal(d1.cpu().numpy()[sel], ed)
+    idx, dist = match.knnMatch2(d1, d2)
+    eidx, edist = tm.oracle_knn2(d1.cpu().numpy(), d2.cpu().numpy())
+    assert np.array_equal(idx.cpu().numpy(), eidx) and np.array_equal(dist.cpu().numpy(), edist)
+    m, dd = match.ratioTest(idx, dist, 0.75)
+    em, _ = tm.oracle_ratio(eidx, edist, 0.75)
+    m = m.cpu().numpy()
+    assert np.array_equal(m, em) and len(m) > 100
+    # matched pairs are the translated twins: next(y, x) = prev(y + 2, x - 3)
+    a, b = l1.cpu().numpy()[m[:, 0]], l2.cpu().numpy()[m[:, 1]]
+    inner = (a[:, 0] > 100) & (a[:, 0] < rows - 100) & (a[:, 1] > 100) & (a[:, 1] < cols - 100)
+    good = (np.abs(b[:, 0] - (a[:, 0] - 2)) <= 1) & (np.abs(b[:, 1] - (a[:, 1] + 3)) <= 1)
+    assert good[inner].mean() > 0.95
+    # LK refine at the matched corners: the flow there is the translation
+    u, v = lk.calcOpticalFlowPyr(dp, dn, 15, 5)
+    fu = u.cpu().numpy()[a[inner, 0], a[inner, 1]]
+    fv = v.cpu().numpy()[a[inner, 0], a[inner, 1]]
+    assert abs(np.median(fu) - 3.0) < 0.3 and abs(np.median(fv) + 2.0) < 0.75
