@@ -58,7 +58,7 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 #define MICV_OPT_HARRIS_GENERIC    5 /* Harris response: one-thread-per-pixel kernel */
 #define MICV_OPT_NMS_SCAN          6 /* Harris NMS: scanning kernel instead of the separable one */
 #define MICV_OPT_STEREO_ROWS       7 /* rows per stereo strip: 0 = automatic, 8 or 10 */
-#define MICV_OPT_LK_GRAPH          8 /* batch-1 pyramid as a captured hipGraph: 0 = default (on), -1 = off */
+#define MICV_OPT_LK_CHAIN          8 /* fused LK tile chains: 0 = automatic, 1 = off, n = longest chain (<= 32) */
 #define MICV_OPT_COUNT             9
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
 int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value);

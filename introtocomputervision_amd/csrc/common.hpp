@@ -109,6 +109,13 @@ struct micv_ctx {
         bool busy;
     };
     std::vector<IoBlock> io_cache;
+    // Tile-chain schedules of the fused LK level kernel (lk_fused.hip), one per launch shape.
+    struct LkSched {
+        int rows, cols, batch, r, max_chain;
+        void *dev;
+        int nblocks;
+    };
+    std::vector<LkSched> lk_sched;
     // Hough trig tables (hough.hip), uploaded once per context: [0] theta = -90.., [1] theta = 0..
     void *trig_tables[2] = {nullptr, nullptr};
     void *io_acquire(size_t bytes);

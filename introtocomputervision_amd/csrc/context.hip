@@ -208,6 +208,7 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (auto &b : ctx->io_cache) (void)hipFree(b.p);
+    for (auto &e : ctx->lk_sched) (void)hipFree(e.dev);
     for (void *t : ctx->trig_tables)
         if (t) (void)hipFree(t);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -252,6 +253,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= 0 && value <= 4, "micv_ctx_set_option: stream groups must be 0..4");
     if (option == MICV_OPT_STEREO_ROWS)
         MICV_REQUIRE(value == 0 || value == 8 || value == 10, "micv_ctx_set_option: stereo rows must be 0, 8 or 10");
+    if (option == MICV_OPT_LK_CHAIN)
+        MICV_REQUIRE(value >= -1 && value <= 32, "micv_ctx_set_option: chain length must be -1..32");
     ctx->opt[option] = value;
     return MICV_OK;
 }

@@ -171,6 +171,8 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.row_begin = 0; a.row_end = R;
         a.stamps = (last && c.profile) ? ctx->stamps : nullptr;  // phase stamps: level 0 only
         a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
+        a.ctx = ctx;
+        a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         bool out_in_cur = false;
         if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
         if (level == 0) {
@@ -404,6 +406,8 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
         a.add_base = 0;
         a.row_begin = 0; a.row_end = rows;
         a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
+        a.ctx = ctx;
+        a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         return launch_lk_level_fused(s, a);
     }
     void *scratch;
@@ -443,6 +447,8 @@ int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int r
         a.add_base = 1;
         a.row_begin = row_begin; a.row_end = row_end;
         a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
+        a.ctx = ctx;
+        a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         a.flow_pair = 0;
         if (!flow_u) {
             a.mode = LK_FLOW_NONE;

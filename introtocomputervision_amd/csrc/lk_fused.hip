@@ -26,6 +26,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 #include "lk_device.hpp"
 
@@ -49,11 +50,15 @@ struct LkCfg {
     static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;  // image region
     static constexpr int PS = RW;                           // LDS row stride of P / Wp
     static constexpr int GW = TW + 2 * R, GH = TH + 2 * R;  // gradient region
-    // Row stride of the gradient planes: 16-B aligned.  With GS/4 = 4 (mod 16) (GS = 80 for
-    // R = 7) the row pass's ds_read_b128 pattern (4 rows x 16 groups per wave) is conflict-free.
-    static constexpr int GS = (GW + 3) & ~3;
+    // The three gradient planes are interleaved by ROW: row q of Ix, Iy, It sit side by side
+    // (GP floats each, 16-B aligned), GS floats per row.  Rows [0, k) of all three planes are then one
+    // contiguous block at the start of the area -- what a tile chain carries over (below).  With
+    // GP/4 = 4 (mod 16) (GP = 80 for R = 7) GS/4 = 12 = -4 (mod 16): the row pass's ds_read_b128
+    // pattern (4 rows x 16 groups per wave) is conflict-free, as it is with separate planes.
+    static constexpr int GP = (GW + 3) & ~3;
+    static constexpr int GS = 3 * GP;
     static constexpr int WV = (4 + 2 * R + 3) / 4;          // float4 loads per row-pass window
-    static_assert(4 * (TW / 4 - 1) + 4 * WV <= GS, "row-pass window reads stay inside a plane row");
+    static_assert(4 * (TW / 4 - 1) + 4 * WV <= GP, "row-pass window reads stay inside a plane row");
     static constexpr int RBS = TW;                          // row-buffer stride (XOR-swizzled chunks)
     static constexpr int CW = RW / 2 + 3, CH = RH / 2 + 3;  // coarse flow block
     static constexpr int M = 8;                             // margin of the staged `next` window
@@ -64,7 +69,19 @@ struct LkCfg {
     static constexpr int C_F = (2 * CH * CW + 3) & ~3;         // coarse block, both fields, 16-B padded
     static constexpr int FLOW_F = C_F + 2 * CH * RW;           // border tiles: C + R
     static constexpr int STAGE_F = C_F + NW * NH;              // interior tiles: C + next window
-    static constexpr int GRAD_F = 3 * GH * GS;
+    static constexpr int GRAD_F = GH * GS;
+    // Tile chains (vertically adjacent tiles run by one workgroup): the lower tile keeps the upper
+    // tile's last QC gradient rows (its own first QC rows) and computes phases 0-3 only for region
+    // rows [LYC, RH).  CARRY_F floats at the start of the gradient area hold them; the lower tile's
+    // staging (coarse block + `next` window, both QC.. rows shorter) goes behind them.
+    static constexpr int QC = GH - TH;                       // carried gradient rows (2R)
+    static constexpr int LYC = QC + (H - R) - 1;             // first region row a carry tile needs
+    static constexpr int CARRY_F = QC * GS;
+    static constexpr int CHC = (RH - H) / 2 + 3;             // coarse rows of a carry tile: base flow from its own first row on
+    static constexpr int NHC = RH - LYC + 2 * M;             // `next` window rows of a carry tile
+    static constexpr int CC_F = (2 * CHC * CW + 3) & ~3;
+    static constexpr bool CHAIN_OK = (RH * (RW / 4)) % 64 == 0 && NT_ == 512 && (LYC % 2 == 0) &&
+                                     CARRY_F + CC_F + NW * NHC <= (GRAD_F > STAGE_F ? GRAD_F : STAGE_F);
     static constexpr int X_F = (FLOW_F > GRAD_F ? FLOW_F : GRAD_F) > STAGE_F
                                    ? (FLOW_F > GRAD_F ? FLOW_F : GRAD_F)
                                    : STAGE_F;
@@ -137,25 +154,40 @@ __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S
 
 // ---- the tile body ---------------------------------------------------------------------------
 
-template <int R, int MODE, bool INT, int NTV>
+// CARRY: this tile is not the first of its chain -- gradient rows [0, QC) are already in LDS (the
+// tile above left them there), phases 0-3 cover region rows [LYC, RH) only.  MORE: another tile of
+// the chain follows -- the last QC gradient rows are moved to the front of the gradient area once
+// the row passes are done with them.
+template <int R, int MODE, bool INT, int NTV, bool CARRY = false>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
-                                        float *lds, int tile_x, int tile_y, int pair) {
+                                        float *lds, int tile_x, int tile_y, int pair, bool more = false) {
     using C = LkCfg<R, NTV>;
     constexpr int RPT = C::RPT;
     constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
-    constexpr int GW = C::GW, GH = C::GH, GS = C::GS, CW = C::CW, CH = C::CH, NT = C::NT;
-    constexpr int M = C::M, NW = C::NW, NH = C::NH;
+    constexpr int GW = C::GW, GH = C::GH, GS = C::GS, GP = C::GP, CW = C::CW, NT = C::NT;
+    constexpr int M = C::M, NW = C::NW;
+    static_assert(!CARRY || (INT && C::FAST && MODE == LK_FLOW_COARSE && C::CHAIN_OK), "carry tiles: interior, coarse flow");
+    constexpr int LY0 = CARRY ? C::LYC : 0;            // first region row this tile stages / warps
+    constexpr int Q0 = CARRY ? C::QC : 0;              // first gradient row this tile computes
+    constexpr int CH = CARRY ? C::CHC : C::CH;         // coarse block rows
+    constexpr int NH = CARRY ? C::NHC : C::NH;         // `next` window rows
+    constexpr int CBF = CARRY ? C::CC_F : C::C_F;      // floats of the coarse block (both fields)
     constexpr bool STAGED = INT && C::FAST && MODE != LK_FLOW_NONE;  // next window in LDS
     float *P = lds;
     float *Wp = lds + RH * PS;
     float *X = lds + C::IMG_F;
-    float *Cu = X, *Cv = X + CH * CW;
-    float *Ru = X + C::C_F, *Rv = Ru + CH * RW;  // border tiles
-    float *Nx = X + C::C_F;                       // interior tiles (aliases Ru/Rv)
-    float *Gx = X, *Gy = X + GH * GS, *Gt = X + 2 * GH * GS;
+    float *Xs = X + (CARRY ? C::CARRY_F : 0);     // staging area (behind the carried rows)
+    float *Cu = Xs, *Cv = Xs + CH * CW;
+    float *Ru = Xs + CBF, *Rv = Ru + CH * RW;     // border tiles
+    float *Nx = Xs + CBF;                         // interior tiles (aliases Ru/Rv)
+    float *Gx = X, *Gy = X + GP, *Gt = X + 2 * GP;
     float *rb0 = lds, *rb1 = lds + GH * C::RBS, *rb2 = lds + 2 * GH * C::RBS;  // alias P / Wp
 
-    const int tid = threadIdx.x;
+    // Carry tiles run inside the chain loop: an opaque copy of the thread index keeps the compiler
+    // from hoisting every lane-derived address out of that loop (which costs ~70 spilled VGPRs).
+    int tid_ = threadIdx.x;
+    if (CARRY) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int rows = a.rows, cols = a.cols;
     const int x0 = tile_x * TW, y0 = tile_y * TH;
     const int rx0 = x0 - H, ry0 = y0 - H;
@@ -192,7 +224,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         const float *__restrict__ fv = a.flow_v + pair * a.flow_pair;
         const int fr = a.flow_rows, fc = a.flow_cols;
         cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
-        cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
+        // carry tiles: the coarse block starts at the rows the tile's own first output row needs
+        cy0 = (ry0 + (CARRY ? H : 0) - 2 > 0 ? ry0 + (CARRY ? H : 0) - 2 : 0) >> 1;
 #pragma unroll
         for (int k = 0; k < NC; k++) {
             // unconditional loads from clamped (always valid) addresses: no branch, so the
@@ -206,18 +239,20 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     }
     const bool vec_ok = INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
-    constexpr bool DMA_OK = ((RH * (RW / 4)) % 64 == 0) && ((NH * (NW / 4)) % 64 == 0);  // whole waves
+    // whole waves for the first tile of a chain / single tiles; carry tiles start mid-wave (the
+    // transfers of lanes beyond the range are masked off, the wave's LDS base stays uniform)
+    constexpr bool DMA_OK = CARRY || (((RH * (RW / 4)) % 64 == 0) && ((NH * (NW / 4)) % 64 == 0));
     if (INT && DMA_OK && vec_ok) {
         // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip
         // and no ds_write; every transfer of the tile is in flight at once.  The LDS images are
         // dense (P: 80-float rows, window: 96-float rows), so element i of the tile lives at
         // float4 slot i and one wave-instruction covers slots [i0, i0 + 64).
-        constexpr int V = RW / 4, NP = (RH * V + NT - 1) / NT;
+        constexpr int V = RW / 4, NP = ((RH - LY0) * V + NT - 1) / NT;
         constexpr int VN = NW / 4, NN = (NH * VN + NT - 1) / NT;
         const int lane = tid & 63;
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-            const int i = tid + k * NT;
+            const int i = LY0 * V + tid + k * NT;  // carry tiles: region rows [LYC, RH) only
             if (i < RH * V) {
                 const int ly = i / V, lv = i - ly * V;
                 const size_t goff = (size_t)(ry0 + ly) * istride + rx0 + 4 * lv;
@@ -235,7 +270,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 if (i < NH * VN) {
                     const int ly = i / VN, lv = i - ly * VN;
                     __builtin_amdgcn_global_load_lds(
-                        (glb_cvoid *)(next + (size_t)(ry0 - M + ly) * istride + rx0 - M + 4 * lv),
+                        (glb_cvoid *)(next + (size_t)(ry0 - M + LY0 + ly) * istride + rx0 - M + 4 * lv),
                         (lds_void *)(Nx + 4 * (i - lane)), 16, 0, 0);
                 }
             }
@@ -287,7 +322,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         if (STAGED) {
             for (int i = tid; i < NH * NW; i += NT) {
                 const int ly = i / NW, lx = i - ly * NW;
-                Nx[i] = next[(size_t)(ry0 - M + ly) * istride + rx0 - M + lx];
+                Nx[i] = next[(size_t)(ry0 - M + LY0 + ly) * istride + rx0 - M + lx];
             }
         }
     }
@@ -368,9 +403,11 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         }
                         bu8[j] = bu;
                         bv8[j] = bv;
-                        // warp right away: the flow pair's live range ends here
-                        Wp[(ly0 + j) * PS + lx] = warp_sample_staged<NW, NH>(
-                            Nx, rx0 - M, ry0 - M, next, rows, cols, istride, gx, gy0 + j, bu, bv);
+                        // warp right away: the flow pair's live range ends here.  Carry tiles need
+                        // the warped image from region row LYC on (the base flow of every own row)
+                        if (!CARRY || ly0 + j >= LY0)
+                            Wp[(ly0 + j) * PS + lx] = warp_sample_staged<NW, NH>(
+                                Nx, rx0 - M, ry0 - M + LY0, next, rows, cols, istride, gx, gy0 + j, bu, bv);
                         // 512-thread tiles run at a 128-VGPR budget: keep the rows from interleaving
                         if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -379,16 +416,19 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             march(H + (tid & (TW - 1)), H + RPT * (tid / TW), base_u, base_v);  // own outputs
             // halo jobs: top / bottom bands (H/RPT segments x RW columns each), left / right bands
             // (H columns each x TH/RPT segments)
-            constexpr int BS = H / RPT, NJ = 2 * BS * RW + 2 * H * (TH / RPT);
+            // carry tiles: no top band, and of the side bands only the segments that reach row LYC
+            constexpr int BS = H / RPT, NB = CARRY ? BS : 2 * BS;
+            constexpr int SEG0 = CARRY ? (LY0 - H) / RPT : 0, NJ = NB * RW + 2 * H * (TH / RPT - SEG0);
+            static_assert(!CARRY || (LY0 >= H && LY0 < H + TH), "carry rows start inside the tile's own rows");
             for (int n = tid; n < NJ; n += NT) {
                 int lx, ly0;
-                if (n < 2 * BS * RW) {
-                    const int band = n / RW;
-                    lx = n - band * RW;
+                if (n < NB * RW) {
+                    const int band = n / RW + (CARRY ? BS : 0);
+                    lx = n - (band - (CARRY ? BS : 0)) * RW;
                     ly0 = band < BS ? band * RPT : H + TH + (band - BS) * RPT;
                 } else {
-                    const int m = n - 2 * BS * RW;
-                    const int seg = m / (2 * H), cc = m - seg * (2 * H);
+                    const int m = n - NB * RW;
+                    const int seg = m / (2 * H) + SEG0, cc = m - (seg - SEG0) * (2 * H);
                     lx = cc < H ? cc : TW + cc;
                     ly0 = H + RPT * seg;
                 }
@@ -498,10 +538,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // Marching job: gradient column qx, a run of gradient rows.  Row pass of the Sobel
             // pair (tx = right - left, ty = [s,2s,s]) is computed once per image row and kept in
             // a 3-row register window; the column pass finishes one output per step.
-            constexpr int SEG = NT >= 512 ? 8 : 16, NSEG = (GH + SEG - 1) / SEG;
+            // carry tiles compute 2R fewer rows: shorter segments keep every thread's job short
+            constexpr int SEG = CARRY ? 6 : (NT >= 512 ? 8 : 16), NSEG = (GH - Q0 + SEG - 1) / SEG;
+            static_assert(GW * NSEG <= NT || !CARRY, "one trip");
             for (int n = tid; n < GW * NSEG; n += NT) {
                 const int seg = n / GW, qx = n - seg * GW;
-                const int q0 = seg * SEG, q1 = q0 + SEG < GH ? q0 + SEG : GH;
+                const int q0 = Q0 + seg * SEG, q1 = q0 + SEG < GH ? q0 + SEG : GH;
                 const int lx = qx + (H - R);
                 float ptx[3], pty[3], wtx[3], wty[3], pc[3], wc[3];
                 auto rowpass = [&](int ly, int slot) {
@@ -619,6 +661,13 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         }
         __syncthreads();
         MICV_STOP(43)
+        if (INT && C::CHAIN_OK && MODE == LK_FLOW_COARSE && more) {
+            // the row passes are done with the gradient planes: hand the last QC rows (all three
+            // planes, one contiguous block) to the next tile of the chain as its first QC rows
+            const v4f *src = reinterpret_cast<const v4f *>(X + TH * GS);
+            v4f *dst = reinterpret_cast<v4f *>(X);
+            for (int i = tid; i < C::CARRY_F / 4; i += NT) dst[i] = src[i];
+        }
         col_pass<C>(rb0, Sxt, g, c, r0);
         col_pass<C>(rb1, Syt, g, c, r0);
     }
@@ -726,6 +775,85 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a,
         lk_tile<R, MODE, false, NTV>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
+// Chain launch: workgroup b runs the `count` vertically adjacent tiles of sched[b] (tile_x, first
+// tile_y, count, pair), carrying the gradient rows from one tile to the next.  A 1-D grid: the
+// host-built schedule already contains the batch, the XCD-aware placement and the order of issue.
+template <int R, int NTV>
+__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_chain_kernel(LkLevelArgs a, TapsN<2 * R + 1> g,
+                                                                        const int4 *__restrict__ sched) {
+    using C = LkCfg<R, NTV>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int E = C::M > 2 ? C::M : 2;
+    const int4 e = sched[blockIdx.x];
+    if (e.z <= 0) return;  // padding entry
+    const int rx0 = e.x * C::TW - C::H, ry0 = e.y * C::TH - C::H;
+    const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
+                          ry0 + C::RH + E <= a.rows;
+    if (!interior) {  // border tiles are never chained
+        lk_tile<R, LK_FLOW_COARSE, false, NTV>(a, g, lds, e.x, e.y, e.w);
+        return;
+    }
+    lk_tile<R, LK_FLOW_COARSE, true, NTV, false>(a, g, lds, e.x, e.y, e.w, e.z > 1);
+    for (int t = 1; t < e.z; t++) {
+        __syncthreads();  // the tile above is done with the row buffers / staged images this one overwrites
+        lk_tile<R, LK_FLOW_COARSE, true, NTV, true>(a, g, lds, e.x, e.y + t, e.w, t + 1 < e.z);
+    }
+}
+
+// Host: the chain schedule of one level launch.  Interior tiles of every column are cut into chains
+// of decreasing length (max_chain first, halving towards the bottom of the column), border tiles
+// stay single.  Order of issue = expected duration, longest first (list scheduling: the short items
+// at the end fill the slots the long ones leave); inside a class neighbouring columns are
+// neighbours in the list, and every class is dealt to the 8 XCDs in contiguous runs (workgroup b
+// lands on XCD b % 8), so chains that share halo columns run at the same time on the same L2.
+template <typename C>
+static void build_chain_schedule(int rows, int cols, int batch, int max_chain, std::vector<int4> *out) {
+    constexpr int E = C::M > 2 ? C::M : 2;
+    const int tiles_x = cdiv(cols, C::TW), tiles_y = cdiv(rows, C::TH);
+    auto interior = [&](int tx, int ty) {
+        const int rx0 = tx * C::TW - C::H, ry0 = ty * C::TH - C::H;
+        return rx0 - E >= 0 && rx0 + C::RW + E <= cols && ry0 - E >= 0 && ry0 + C::RH + E <= rows;
+    };
+    // classes by chain length (index = length), plus the border singles
+    std::vector<std::vector<int4>> cls(max_chain + 1);
+    std::vector<int4> border;
+    for (int p = 0; p < batch; p++) {
+        for (int ty = 0; ty < tiles_y; ty++)
+            for (int tx = 0; tx < tiles_x; tx++)
+                if (!interior(tx, ty)) border.push_back(make_int4(tx, ty, 1, p));
+        // interior rows of a column are contiguous (the predicate is separable); cut them per segment so
+        // that one segment's chains of all columns are neighbours in the class list
+        int iy0 = 0;
+        while (iy0 < tiles_y && !interior(tiles_x / 2, iy0)) iy0++;
+        int iy1 = iy0;
+        while (iy1 < tiles_y && interior(tiles_x / 2, iy1)) iy1++;
+        int y = iy0;
+        while (y < iy1) {
+            const int rem = iy1 - y;
+            int len = rem / 2 > max_chain ? max_chain : rem / 2;
+            if (len < 1) len = 1;
+            if (rem <= max_chain && rem <= 2) len = 1;
+            for (int tx = 0; tx < tiles_x; tx++)
+                if (interior(tx, y)) cls[len].push_back(make_int4(tx, y, len, p));
+            y += len;
+        }
+    }
+    std::vector<int4> per_xcd[8];
+    auto deal = [&](const std::vector<int4> &v) {
+        const size_t n = v.size();
+        for (int x = 0; x < 8; x++)
+            for (size_t i = n * x / 8; i < n * (x + 1) / 8; i++) per_xcd[x].push_back(v[i]);
+    };
+    for (int len = max_chain; len >= 2; len--) deal(cls[len]);
+    deal(border);  // ~1.5 tile times each: after the chains, before the interior singles
+    if (max_chain >= 1) deal(cls[1]);
+    size_t longest = 0;
+    for (auto &v : per_xcd) longest = v.size() > longest ? v.size() : longest;
+    out->clear();
+    for (size_t i = 0; i < longest; i++)
+        for (int x = 0; x < 8; x++) out->push_back(i < per_xcd[x].size() ? per_xcd[x][i] : make_int4(0, 0, 0, 0));
+}
+
 bool lk_fused_supports(int win) { return win == 15 || win == 7 || win == 21 || win == 11; }
 
 template <int R, int NTV>
@@ -759,6 +887,59 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     if (a.row_begin < 0 || a.row_end > a.rows || a.row_begin >= a.row_end) {
         set_error("lk fused: bad row band [%d, %d) for %d rows", a.row_begin, a.row_end, a.rows);
         return MICV_EINVAL;
+    }
+    if constexpr (C::CHAIN_OK) {
+        if (a.mode == LK_FLOW_COARSE && a.ctx && a.max_chain != 1 && a.row_begin == 0 && a.row_end == a.rows &&
+            a.rows == 2 * a.flow_rows && a.cols == 2 * a.flow_cols) {
+            // Measured on MI355X (8 x 1080p, tools/chain_bench.py): pairs of tiles are the best chain
+            // length (level 0: 0.243 -> 0.233 ms; longer chains lose to the coarser work items), and the
+            // schedule alone (all pairs' border tiles first, one 1-D grid) is worth as much again on the
+            // levels that fill the GPU only once or twice.  Launches below one round stay on the plain grid.
+            const long tiles = (long)cdiv(a.cols, C::TW) * cdiv(a.rows, C::TH) * a.batch;
+            int max_chain = a.max_chain > 1 ? a.max_chain : (tiles >= 512 ? 2 : 1);
+            if (max_chain > 32) max_chain = 32;
+            if (a.max_chain < 0) max_chain = 1;  // diagnostic: the chain kernel and its schedule, single tiles only
+            if (max_chain > 1 || a.max_chain < 0) {
+                const int4 *sched = nullptr;
+                int nblocks = 0;
+                for (auto &e : a.ctx->lk_sched)
+                    if (e.rows == a.rows && e.cols == a.cols && e.batch == a.batch && e.r == R && e.max_chain == max_chain) {
+                        sched = static_cast<const int4 *>(e.dev);
+                        nblocks = e.nblocks;
+                    }
+                if (!sched) {
+                    std::vector<int4> host;
+                    build_chain_schedule<C>(a.rows, a.cols, a.batch, max_chain, &host);
+                    void *dev = nullptr;
+                    MICV_HIP(hipMalloc(&dev, host.size() * sizeof(int4)));
+                    hipError_t ce = hipMemcpy(dev, host.data(), host.size() * sizeof(int4), hipMemcpyHostToDevice);
+                    if (ce != hipSuccess) {
+                        (void)hipFree(dev);
+                        MICV_HIP(ce);
+                    }
+                    if (a.ctx->lk_sched.size() >= 32) {  // shapes keep changing: start over
+                        for (auto &e : a.ctx->lk_sched) (void)hipFree(e.dev);
+                        a.ctx->lk_sched.clear();
+                    }
+                    a.ctx->lk_sched.push_back({a.rows, a.cols, a.batch, R, max_chain, dev, (int)host.size()});
+                    sched = static_cast<const int4 *>(dev);
+                    nblocks = (int)host.size();
+                }
+                {
+                    static thread_local int chain_dev = -1;
+                    int dev = 0;
+                    MICV_HIP(hipGetDevice(&dev));
+                    if (chain_dev != dev) {
+                        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_chain_kernel<R, NTV>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+                        chain_dev = dev;
+                    }
+                }
+                lk_level_chain_kernel<R, NTV><<<nblocks, C::NT, C::LDS_BYTES, s>>>(a, taps, sched);
+                MICV_LAUNCH_CHECK();
+                return MICV_OK;
+            }
+        }
     }
     const int tile_rows = cdiv(a.row_end, C::TH) - a.row_begin / C::TH;
     const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);

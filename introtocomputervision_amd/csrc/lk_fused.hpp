@@ -26,6 +26,10 @@ struct LkLevelArgs {
     // Output rows [row_begin, row_end) only (row-sharded execution); 0 / rows = everything.
     int row_begin = 0, row_end = 0;
     int narrow = 0;  // MICV_OPT_LK_NARROW_TILES: 256-thread form of the win-15 kernel
+    // Tile chains (lk_fused.hip): ctx owns the cached schedules; max_chain = MICV_OPT_LK_CHAIN
+    // (0 = automatic, 1 = off, n = longest chain).  Host side only.
+    micv_ctx *ctx = nullptr;
+    int max_chain = 0;
     // -DMICV_DIAG builds only (the default build compiles neither in):
     //  * stamps (micv_profile_lk_phases): when non-null, wave 0 of every workgroup adds the
     //    s_memtime ticks it spent in each phase to stamps[phase];

@@ -345,3 +345,29 @@ def test_lk_pyr_on_colour_frames_one_upload(mods):
     g8u, g8v = lk.calcOpticalFlowPyrFrames(prev.astype(np.uint8), nxt.astype(np.uint8), 15, 4)
     e8 = orc.lk_flow_pyr(prev.astype(np.uint8).astype(np.float32), nxt.astype(np.uint8).astype(np.float32), 15, 4)
     assert np.array_equal(g8u, e8[0]) and np.array_equal(g8v, e8[1])
+
+
+@pytest.mark.parametrize("rows,cols,levels,batch", [(270, 480, 2, 1), (540, 960, 3, 2), (1080, 1920, 5, 1), (330, 700, 3, 3),
+                                                    (200, 210, 2, 1), (97, 400, 2, 2)])
+@pytest.mark.parametrize("max_chain", [2, 3, 4, 8, 32])
+def test_tile_chains_are_bit_exact(mods, rows, cols, levels, batch, max_chain):
+    """Tile chains of the fused level kernel (one workgroup walks down a column of tiles and keeps the
+    last 14 gradient rows in LDS for the tile below): any chain length, any image size, the same bits
+    as single tiles and as the oracle.  MICV_OPT_LK_CHAIN forces chains at sizes the automatic rule
+    would run as single tiles."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(4000 + i + rows, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_CHAIN, max_chain)
+    u = torch.full((batch, rows, cols), float("nan"), device="cuda")
+    v = torch.full((batch, rows, cols), float("nan"), device="cuda")
+    for rep in range(2):  # second call: the cached schedule
+        lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx, out=(u, v))
+    for i in range(batch):
+        eu, ev = orc.lk_flow_pyr(prev[i], nxt[i], 15, levels)
+        assert np.array_equal(host(u[i]), eu) and np.array_equal(host(v[i]), ev), (i, max_chain)
+    ctx.set_option(_capi.OPT_LK_CHAIN, 1)  # chains off: identical
+    su, sv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
+    assert torch.equal(su, u) and torch.equal(sv, v)

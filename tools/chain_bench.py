@@ -1,0 +1,21 @@
+import sys, time, json
+sys.path.insert(0, '.')
+import numpy as np, torch
+from introtocomputervision_amd import lk, synth, _capi
+B=8
+prev = np.stack([synth.lk_pair(0x5EED0005+i,1080,1920,3,-2)[0] for i in range(B)]); nxt = np.stack([synth.lk_pair(0x5EED0005+i,1080,1920,3,-2)[1] for i in range(B)])
+dp, dn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
+out = (torch.empty_like(dp), torch.empty_like(dp))
+for groups in (1, 2):
+  for mc in (1, -1, 2, 3, 4, 8):
+    ctx = _capi.Context(0); ctx.set_option(_capi.OPT_LK_CHAIN, mc); ctx.set_lk_groups(groups)
+    for _ in range(5): lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out)
+    torch.cuda.synchronize(); t=time.perf_counter()
+    N=100
+    for _ in range(N): lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out)
+    torch.cuda.synchronize(); ms=(time.perf_counter()-t)/N*1e3
+    ctx.profile(True); ctx.profile_reset()
+    for _ in range(20): lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out)
+    torch.cuda.synchronize()
+    lv=[ctx.profile_lk_level(l) for l in range(5)]
+    print(json.dumps({"groups":groups,"max_chain":mc,"ms_per_step":round(ms,4),"level_ms":[round(a/max(n,1),4) for a,n in lv]}), flush=True)
