@@ -173,6 +173,7 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
         a.ctx = ctx;
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
+        a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
         bool out_in_cur = false;
         if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
         if (level == 0) {
@@ -408,6 +409,7 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
         a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
         a.ctx = ctx;
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
+        a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
         return launch_lk_level_fused(s, a);
     }
     void *scratch;
@@ -449,6 +451,7 @@ int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int r
         a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
         a.ctx = ctx;
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
+        a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
         a.flow_pair = 0;
         if (!flow_u) {
             a.mode = LK_FLOW_NONE;

@@ -41,11 +41,14 @@ struct TapsN {
     float k[N];
 };
 
-template <int R_, int NT_ = 256>
+// TH_ = 32 is the throughput tile; TH_ = 16 (512 threads, 2 output rows per thread) halves every
+// thread's share of every phase: the form for launches that do not fill the GPU once, where the
+// time of a level is one tile's latency.
+template <int R_, int NT_ = 256, int TH_ = 32>
 struct LkCfg {
     static constexpr int R = R_;
     static constexpr int W = 2 * R + 1;
-    static constexpr int TW = 64, TH = 32, NT = NT_;
+    static constexpr int TW = 64, TH = TH_, NT = NT_;
     static constexpr int H = R + 1;                         // image halo (Sobel + window)
     static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;  // image region
     static constexpr int PS = RW;                           // LDS row stride of P / Wp
@@ -80,12 +83,12 @@ struct LkCfg {
     static constexpr int CHC = (RH - H) / 2 + 3;             // coarse rows of a carry tile: base flow from its own first row on
     static constexpr int NHC = RH - LYC + 2 * M;             // `next` window rows of a carry tile
     static constexpr int CC_F = (2 * CHC * CW + 3) & ~3;
-    static constexpr bool CHAIN_OK = (RH * (RW / 4)) % 64 == 0 && NT_ == 512 && (LYC % 2 == 0) &&
+    static constexpr bool CHAIN_OK = (RH * (RW / 4)) % 64 == 0 && NT_ == 512 && TH_ == 32 && (LYC % 2 == 0) &&
                                      CARRY_F + CC_F + NW * NHC <= (GRAD_F > STAGE_F ? GRAD_F : STAGE_F);
     static constexpr int X_F = (FLOW_F > GRAD_F ? FLOW_F : GRAD_F) > STAGE_F
                                    ? (FLOW_F > GRAD_F ? FLOW_F : GRAD_F)
                                    : STAGE_F;
-    static_assert(RPT == 8 || RPT == 4, "256 or 512 threads per 64x32 tile");
+    static_assert(RPT == 8 || RPT == 4 || RPT == 2, "256 or 512 threads per 64x32 tile, 512 per 64x16 tile");
     static constexpr int LDS_FLOATS = IMG_F + X_F;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
     // The marching body of phase 2 is written for 8-row segments and 16-B rows.
@@ -158,10 +161,10 @@ __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S
 // tile above left them there), phases 0-3 cover region rows [LYC, RH) only.  MORE: another tile of
 // the chain follows -- the last QC gradient rows are moved to the front of the gradient area once
 // the row passes are done with them.
-template <int R, int MODE, bool INT, int NTV, bool CARRY = false>
+template <int R, int MODE, bool INT, int NTV, bool CARRY = false, int THV = 32>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
                                         float *lds, int tile_x, int tile_y, int pair, bool more = false) {
-    using C = LkCfg<R, NTV>;
+    using C = LkCfg<R, NTV, THV>;
     constexpr int RPT = C::RPT;
     constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
     constexpr int GW = C::GW, GH = C::GH, GS = C::GS, GP = C::GP, CW = C::CW, NT = C::NT;
@@ -539,7 +542,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // pair (tx = right - left, ty = [s,2s,s]) is computed once per image row and kept in
             // a 3-row register window; the column pass finishes one output per step.
             // carry tiles compute 2R fewer rows: shorter segments keep every thread's job short
-            constexpr int SEG = CARRY ? 6 : (NT >= 512 ? 8 : 16), NSEG = (GH - Q0 + SEG - 1) / SEG;
+            constexpr int SEG = CARRY ? 6 : (TH == 16 ? 5 : (NT >= 512 ? 8 : 16)), NSEG = (GH - Q0 + SEG - 1) / SEG;
             static_assert(GW * NSEG <= NT || !CARRY, "one trip");
             for (int n = tid; n < GW * NSEG; n += NT) {
                 const int seg = n / GW, qx = n - seg * GW;
@@ -632,7 +635,11 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 load_window<C>(Gy, qy, c0, wy);
                 const int o = rb_off(qy, grp);
                 row_taps<C>(wx, wx, g, rb0 + o);
+                // 64x16 tiles: the sweep is a single (peeled) trip; keep its three products from
+                // interleaving so the body stays inside the 128-VGPR budget
+                if (TH == 16) __builtin_amdgcn_sched_barrier(0);
                 row_taps<C>(wx, wy, g, rb1 + o);
+                if (TH == 16) __builtin_amdgcn_sched_barrier(0);
                 row_taps<C>(wy, wy, g, rb2 + o);
             }
         }
@@ -641,6 +648,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         col_pass<C>(rb0, Sxx, g, c, r0);
         col_pass<C>(rb1, Sxy, g, c, r0);
         col_pass<C>(rb2, Syy, g, c, r0);
+        // 64x16 tiles: finish the three column chains here instead of letting them sink below the
+        // barrier into sweep B (their 48 loaded values would be spilled there)
+        if (TH == 16) __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         MICV_STOP(42)
         // sweep B: Ix*It, Iy*It
@@ -758,9 +768,11 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
     }
 }
 
-template <int R, int MODE, int NTV>
-__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
-    using C = LkCfg<R, NTV>;
+// The 64x16 form serves launches of at most one workgroup per CU: it may use the whole register
+// file of its two waves per SIMD (no spills at 128+ VGPRs), occupancy is not what limits it.
+template <int R, int MODE, int NTV, int THV = 32>
+__global__ __launch_bounds__(NTV, THV == 16 ? 2 : NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+    using C = LkCfg<R, NTV, THV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int E = C::M > 2 ? C::M : 2;
     int tile_x, tile_y;
@@ -770,9 +782,9 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a,
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
     if (interior)
-        lk_tile<R, MODE, true, NTV>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, true, NTV, false, THV>(a, g, lds, tile_x, tile_y, blockIdx.y);
     else
-        lk_tile<R, MODE, false, NTV>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, false, NTV, false, THV>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
 // Chain launch: workgroup b runs the `count` vertically adjacent tiles of sched[b] (tile_x, first
@@ -856,9 +868,9 @@ static void build_chain_schedule(int rows, int cols, int batch, int max_chain, s
 
 bool lk_fused_supports(int win) { return win == 15 || win == 7 || win == 21 || win == 11; }
 
-template <int R, int NTV>
+template <int R, int NTV, int THV = 32>
 static int launch_r(hipStream_t s, const LkLevelArgs &a) {
-    using C = LkCfg<R, NTV>;
+    using C = LkCfg<R, NTV, THV>;
     static TapsN<2 * R + 1> taps;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -872,13 +884,13 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         int dev = 0;
         MICV_HIP(hipGetDevice(&dev));
         if (done_dev != dev) {
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0, NTV>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0, NTV, THV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1, NTV>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1, NTV, THV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2, NTV>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2, NTV, THV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
             done_dev = dev;
@@ -896,10 +908,14 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             // schedule alone (all pairs' border tiles first, one 1-D grid) is worth as much again on the
             // levels that fill the GPU only once or twice.  Launches below one round stay on the plain grid.
             const long tiles = (long)cdiv(a.cols, C::TW) * cdiv(a.rows, C::TH) * a.batch;
-            int max_chain = a.max_chain > 1 ? a.max_chain : (tiles >= 512 ? 2 : 1);
+            // A single 1080p pair (1020 tiles = two exact rounds) is slower with chains (0.041 -> 0.045 ms):
+            // chains from four rounds on; between one and four rounds a batch still gains from the
+            // schedule's order (every pair's border tiles first), with single tiles.
+            int max_chain = a.max_chain > 1 ? a.max_chain : (tiles >= 2048 ? 2 : 1);
             if (max_chain > 32) max_chain = 32;
-            if (a.max_chain < 0) max_chain = 1;  // diagnostic: the chain kernel and its schedule, single tiles only
-            if (max_chain > 1 || a.max_chain < 0) {
+            const bool sched_only = a.max_chain < 0 || (a.max_chain == 0 && max_chain == 1 && tiles >= 512 && a.batch >= 2);
+            if (sched_only) max_chain = 1;  // the schedule kernel with single tiles only
+            if (max_chain > 1 || sched_only) {
                 const int4 *sched = nullptr;
                 int nblocks = 0;
                 for (auto &e : a.ctx->lk_sched)
@@ -945,7 +961,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
     switch (a.mode) {
         case LK_FLOW_NONE:
-            lk_level_kernel<R, 0, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 0, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
             break;
         case LK_FLOW_COARSE:
             if (a.rows != 2 * a.flow_rows || a.cols != 2 * a.flow_cols) {
@@ -953,10 +969,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
                           a.flow_cols, a.rows, a.cols);
                 return MICV_EINVAL;
             }
-            lk_level_kernel<R, 1, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 1, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
             break;
         case LK_FLOW_FULL:
-            lk_level_kernel<R, 2, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 2, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
             break;
         default:
             set_error("lk fused: bad mode %d", a.mode);
@@ -979,7 +995,12 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             // 512 threads per tile (4 waves per SIMD at 2 workgroups per CU) vs 256 (2 waves per SIMD)
             // Measured on MI355X (8 pairs of 1080p): 512 threads 0.377 ms per level-0 launch vs 0.406 ms,
             // and the latency-bound coarse levels gain more.  MICV_OPT_LK_NARROW_TILES selects the narrow form.
-            return a.narrow ? launch_r<7, 256>(s, a) : launch_r<7, 512>(s, a);
+            if (a.narrow) return launch_r<7, 256>(s, a);
+            // a launch of at most one 64x16 tile per CU costs one tile's latency: half-height tiles shorten it
+            // (batch 1, 1080p: levels 2-4)
+            const long short_tiles = (long)cdiv(a.cols, 64) * (cdiv(a.row_end > 0 ? a.row_end : a.rows, 16)) * a.batch;
+            if (short_tiles <= 256 && a.short_tiles >= 0) return launch_r<7, 512, 16>(s, a);
+            return launch_r<7, 512>(s, a);
         }
         case 7: return launch_r<3, 256>(s, a);
         case 21: return launch_r<10, 256>(s, a);  // the reference's default winSize (OpticalFlow.h:9,18)

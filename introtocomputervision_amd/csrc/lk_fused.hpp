@@ -30,6 +30,7 @@ struct LkLevelArgs {
     // (0 = automatic, 1 = off, n = longest chain).  Host side only.
     micv_ctx *ctx = nullptr;
     int max_chain = 0;
+    int short_tiles = 0;  // MICV_OPT_LK_SHORT_TILES: 0 = automatic (64x16 tiles under one round), -1 = never
     // -DMICV_DIAG builds only (the default build compiles neither in):
     //  * stamps (micv_profile_lk_phases): when non-null, wave 0 of every workgroup adds the
     //    s_memtime ticks it spent in each phase to stamps[phase];

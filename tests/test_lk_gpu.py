@@ -371,3 +371,23 @@ def test_tile_chains_are_bit_exact(mods, rows, cols, levels, batch, max_chain):
     ctx.set_option(_capi.OPT_LK_CHAIN, 1)  # chains off: identical
     su, sv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
     assert torch.equal(su, u) and torch.equal(sv, v)
+
+
+@pytest.mark.parametrize("rows,cols,levels,batch", [(270, 480, 3, 1), (135, 240, 2, 8), (67, 120, 1, 3), (1080, 1920, 5, 1), (100, 333, 3, 2)])
+def test_short_tiles_are_bit_exact(mods, rows, cols, levels, batch):
+    """Launches of at most one 64x16 tile per CU run the half-height form of the win-15 level kernel
+    (MICV_OPT_LK_SHORT_TILES = 0, the default); -1 keeps 64x32 tiles.  Same bits either way."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(7000 + i + cols, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    exp = [orc.lk_flow_pyr(prev[i], nxt[i], 15, levels) for i in range(batch)]
+    for opt in (0, -1):
+        ctx = _capi.Context(0)
+        ctx.set_option(_capi.OPT_LK_SHORT_TILES, opt)
+        u, v = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
+        for i in range(batch):
+            assert np.array_equal(host(u[i]), exp[i][0]) and np.array_equal(host(v[i]), exp[i][1]), (opt, i)
+    su, sv = lk.calcOpticalFlow(dev(prev[0]), dev(nxt[0]), 15)  # single level, NONE mode, short tiles when small
+    e1 = orc.lk_flow(prev[0], nxt[0], 15)
+    assert np.array_equal(host(su), e1[0]) and np.array_equal(host(sv), e1[1])

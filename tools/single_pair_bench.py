@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""One 1080p pair per call (BASELINE configs[1] literally): ms per call and per level for the
+kernel variants (64x16 tiles on the small levels, tile chains).  GPU box: python tools/single_pair_bench.py"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from introtocomputervision_amd import lk, synth, _capi
+p, n = synth.lk_pair(0x5EED0005, 1080, 1920, 3, -2)
+dp, dn = torch.from_numpy(p[None]).cuda(), torch.from_numpy(n[None]).cuda()
+out = (torch.empty_like(dp), torch.empty_like(dp))
+for short, chain in ((-1, 1), (0, 1), (-1, 0), (0, 0)):
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_SHORT_TILES, short)
+    ctx.set_option(_capi.OPT_LK_CHAIN, chain)
+    for _ in range(10): lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out)
+    torch.cuda.synchronize(); t = time.perf_counter(); N = 300
+    for _ in range(N): lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out)
+    torch.cuda.synchronize(); ms = (time.perf_counter() - t) / N * 1e3
+    # one call at a time with a sync between (latency of a single call as a driver would see it)
+    t = time.perf_counter()
+    for _ in range(100):
+        lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out); torch.cuda.synchronize()
+    ms_sync = (time.perf_counter() - t) / 100 * 1e3
+    ctx.profile(True); ctx.profile_reset()
+    for _ in range(30): lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out)
+    torch.cuda.synchronize()
+    lv = [ctx.profile_lk_level(l) for l in range(5)]
+    print(json.dumps({"short_tiles": short, "chain": chain, "ms_back_to_back": round(ms, 4), "ms_with_sync": round(ms_sync, 4),
+                      "level_ms": [round(a / max(k, 1), 4) for a, k in lv]}), flush=True)
