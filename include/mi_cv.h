@@ -134,6 +134,14 @@ int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int r
                       size_t stride, int win, const float *flow_u, const float *flow_v,
                       int flow_rows, int flow_cols, int row_begin, int row_end, float *u, float *v,
                       size_t ostride, micv_stream stream);
+/* The same over `batch` pairs in one launch per level (pair i at prev + i*pair_stride bytes, its
+ * coarse flow at flow_u + i*flow_pair_stride, its output at u + i*opair_stride): what a rank of a
+ * row-sharded batch runs per level. */
+int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next, int batch,
+                            size_t pair_stride, int rows, int cols, size_t stride, int win,
+                            const float *flow_u, const float *flow_v, int flow_rows, int flow_cols,
+                            size_t flow_pair_stride, int row_begin, int row_end, float *u, float *v,
+                            size_t opair_stride, size_t ostride, micv_stream stream);
 
 /* lk::calcOpticalFlow, OpticalFlow.cpp:41-104 (a2; includes computeGradients :12-39, a3). */
 int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
@@ -173,6 +181,14 @@ int micv_gaussian_pyramid_host(micv_ctx *ctx, const float *src, int rows, int co
 int micv_laplacian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int cols,
                                size_t sstride, int levels, float *const *dst_levels,
                                micv_stream stream);
+/* The same for `batch` images in one launch (image i at src + i*image_stride bytes; level l of image i
+ * at dst_levels[l] + i*rows_l*cols_l floats, dense; dst_levels[0] may be NULL = no level-0 copy).
+ * row_begin / row_end (both NULL = everything): level l is written for rows
+ * [row_begin[l], row_end[l]) only -- a rank of a row-sharded run builds just the rows its band and
+ * halos touch. */
+int micv_gaussian_pyramid_batch_dev(micv_ctx *ctx, const float *src, int batch, size_t image_stride,
+                                    int rows, int cols, size_t sstride, int levels, float *const *dst_levels,
+                                    const int *row_begin, const int *row_end, micv_stream stream);
 /* cv::cvtColor(COLOR_RGB2GRAY) + convertTo(CV_32F) for 8-bit 3-channel input
  * (Pyramids.cpp:10-15). */
 int micv_rgb8_to_gray_f32_dev(micv_ctx *ctx, const uint8_t *rgb, int rows, int cols,

@@ -73,6 +73,8 @@ SIGNATURES = {
     "micv_lk_flow_pyr_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz]),
     "micv_lk_flow_pyr_batch_dev": (i32, [vp, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
     "micv_lk_level_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "micv_lk_level_batch_dev": (i32, [vp, vp, vp, i32, sz, i32, i32, sz, i32, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
+    "micv_gaussian_pyramid_batch_dev": (i32, [vp, vp, i32, sz, i32, i32, sz, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp]),
     "micv_lk_flow_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, vp, vp, sz, vp]),
     "micv_lk_flow_host": (i32, [vp, vp, vp, i32, i32, sz, i32, vp, vp, sz]),
     "micv_lk_warp_dev": (i32, [vp, vp, sz, vp, vp, sz, i32, i32, vp, sz, vp]),

@@ -30,7 +30,8 @@ int launch_pyr_build(hipStream_t s, const float *src, size_t img_elems, int sstr
 // Two image sets (prev / next) in one launch; dst_a[l] == nullptr skips level l in both.
 int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, size_t img_elems,
                       int sstride, int rows, int cols, int levels, float *const *dst_a,
-                      float *const *dst_b, int batch);
+                      float *const *dst_b, int batch, const int *row_lo = nullptr,
+                      const int *row_hi = nullptr);
 int launch_resize_linear(hipStream_t s, const float *src, int srows, int scols, int sstride,
                          float *dst, int drows, int dcols, int dstride);
 // du = resize(2 * pyrUp(du_coarse), drows x dcols) for `batch` pairs and both fields, one launch.

@@ -419,33 +419,41 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
                             static_cast<float *>(scratch));
 }
 
-int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
-                      size_t stride, int win, const float *flow_u, const float *flow_v,
-                      int flow_rows, int flow_cols, int row_begin, int row_end, float *u, float *v,
-                      size_t ostride, micv_stream stream) {
+int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next, int batch,
+                            size_t pair_stride, int rows, int cols, size_t stride, int win,
+                            const float *flow_u, const float *flow_v, int flow_rows, int flow_cols,
+                            size_t flow_pair_stride, int row_begin, int row_end, float *u, float *v,
+                            size_t opair_stride, size_t ostride, micv_stream stream) {
     MICV_TRY(check_lk_args("micv_lk_level", ctx, prev, next, u, v, rows, cols, stride, ostride, win));
+    MICV_REQUIRE(batch >= 1 && batch <= 32767, "micv_lk_level: bad batch %d", batch);
     MICV_REQUIRE((flow_u == nullptr) == (flow_v == nullptr), "micv_lk_level: give both flow fields or none");
     MICV_REQUIRE(!flow_u || (flow_rows > 0 && flow_cols > 0), "micv_lk_level: bad coarse flow size");
     MICV_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= rows,
                  "micv_lk_level: bad row band [%d, %d)", row_begin, row_end);
+    MICV_REQUIRE(pair_stride % 4 == 0 && opair_stride % 4 == 0 && flow_pair_stride % 4 == 0 &&
+                     (batch == 1 || (pair_stride >= stride * (size_t)rows && opair_stride >= ostride * (size_t)rows &&
+                                     (!flow_u || flow_pair_stride >= (size_t)flow_rows * flow_cols * 4))),
+                 "micv_lk_level: bad pair stride");
     MICV_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)rows * cols;
     const bool doubles = flow_u && 2 * flow_rows == rows && 2 * flow_cols == cols;
     const bool fused = lk_fused_supports(win) && !ctx->opt[MICV_OPT_LK_FORCE_GENERIC];
-    void *scratch;
-    MICV_TRY(ctx->reserve(Carver::need(n, 4) * 4 + Carver::need(lk_generic_scratch(rows, cols), 4) +
-                              (flow_u ? Carver::need((size_t)flow_rows * flow_cols * 2, 4) : 0),
-                          &scratch));
-    Carver carve(scratch);
-    float *bu = carve.take<float>(n), *bv = carve.take<float>(n);
-    float *warped = carve.take<float>(n), *tmp = carve.take<float>(n);
-    float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
+    const size_t pe = pair_stride / 4, ope = opair_stride / 4, fpe = flow_pair_stride / 4;
     if (fused) {
+        // odd-sized levels: the expanded + resized base flow of every pair goes to scratch first
+        float *bu = nullptr, *bv = nullptr;
+        if (flow_u && !doubles) {
+            void *scratch;
+            MICV_TRY(ctx->reserve(Carver::need(n * batch, 4) * 2, &scratch));
+            Carver carve(scratch);
+            bu = carve.take<float>(n * batch);
+            bv = carve.take<float>(n * batch);
+        }
         LkLevelArgs a;
-        a.rows = rows; a.cols = cols; a.batch = 1; a.win = win;
-        a.prev = prev; a.next = next; a.img_stride = (int)(stride / 4); a.img_pair = 0;
-        a.out_u = u; a.out_v = v; a.out_stride = (int)(ostride / 4); a.out_pair = 0;
+        a.rows = rows; a.cols = cols; a.batch = batch; a.win = win;
+        a.prev = prev; a.next = next; a.img_stride = (int)(stride / 4); a.img_pair = pe;
+        a.out_u = u; a.out_v = v; a.out_stride = (int)(ostride / 4); a.out_pair = ope;
         a.add_base = 1;
         a.row_begin = row_begin; a.row_end = row_end;
         a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
@@ -459,28 +467,48 @@ int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int r
         } else if (doubles) {
             a.mode = LK_FLOW_COARSE;
             a.flow_u = flow_u; a.flow_v = flow_v; a.flow_rows = flow_rows; a.flow_cols = flow_cols;
+            a.flow_pair = fpe;
         } else {
-            MICV_TRY(launch_flow_expand_resize(s, flow_u, flow_v, flow_rows, flow_cols, 0, bu, bv, rows,
-                                               cols, 0, 1));
+            MICV_TRY(launch_flow_expand_resize(s, flow_u, flow_v, flow_rows, flow_cols, fpe, bu, bv, rows,
+                                               cols, n, batch));
             a.mode = LK_FLOW_FULL;
             a.flow_u = bu; a.flow_v = bv; a.flow_rows = rows; a.flow_cols = cols;
+            a.flow_pair = n;
         }
         return launch_lk_level_fused(s, a);
     }
-    // generic kernels compute the whole level; rows outside the band are simply not needed
-    if (!flow_u) {
-        MICV_HIP(hipMemsetAsync(bu, 0, n * 4, s));
-        MICV_HIP(hipMemsetAsync(bv, 0, n * 4, s));
-    } else if (doubles) {
-        MICV_TRY(launch_pyr_up(s, flow_u, flow_rows, flow_cols, flow_cols, bu, cols, 2.f, tmp));
-        MICV_TRY(launch_pyr_up(s, flow_v, flow_rows, flow_cols, flow_cols, bv, cols, 2.f, tmp));
-    } else {
-        MICV_TRY(launch_flow_expand_resize(s, flow_u, flow_v, flow_rows, flow_cols, 0, bu, bv, rows, cols,
-                                           0, 1));
+    // generic kernels compute the whole level, pair by pair; rows outside the band are simply not needed
+    void *scratch;
+    MICV_TRY(ctx->reserve(Carver::need(n, 4) * 4 + Carver::need(lk_generic_scratch(rows, cols), 4), &scratch));
+    Carver carve(scratch);
+    float *bu = carve.take<float>(n), *bv = carve.take<float>(n);
+    float *warped = carve.take<float>(n), *tmp = carve.take<float>(n);
+    float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
+    for (int b = 0; b < batch; b++) {
+        const float *pb = prev + b * pe, *nb = next + b * pe;
+        const float *fub = flow_u ? flow_u + b * fpe : nullptr, *fvb = flow_v ? flow_v + b * fpe : nullptr;
+        if (!flow_u) {
+            MICV_HIP(hipMemsetAsync(bu, 0, n * 4, s));
+            MICV_HIP(hipMemsetAsync(bv, 0, n * 4, s));
+        } else if (doubles) {
+            MICV_TRY(launch_pyr_up(s, fub, flow_rows, flow_cols, flow_cols, bu, cols, 2.f, tmp));
+            MICV_TRY(launch_pyr_up(s, fvb, flow_rows, flow_cols, flow_cols, bv, cols, 2.f, tmp));
+        } else {
+            MICV_TRY(launch_flow_expand_resize(s, fub, fvb, flow_rows, flow_cols, 0, bu, bv, rows, cols, 0, 1));
+        }
+        MICV_TRY(launch_warp(s, nb, (int)(stride / 4), bu, bv, cols, rows, cols, warped, cols));
+        MICV_TRY(lk_level_generic(s, pb, (int)(stride / 4), warped, cols, rows, cols, win, bu, bv, cols,
+                                  u + b * ope, v + b * ope, (int)(ostride / 4), gen));
     }
-    MICV_TRY(launch_warp(s, next, (int)(stride / 4), bu, bv, cols, rows, cols, warped, cols));
-    return lk_level_generic(s, prev, (int)(stride / 4), warped, cols, rows, cols, win, bu, bv, cols, u, v,
-                            (int)(ostride / 4), gen);
+    return MICV_OK;
+}
+
+int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
+                      size_t stride, int win, const float *flow_u, const float *flow_v,
+                      int flow_rows, int flow_cols, int row_begin, int row_end, float *u, float *v,
+                      size_t ostride, micv_stream stream) {
+    return micv_lk_level_batch_dev(ctx, prev, next, 1, 0, rows, cols, stride, win, flow_u, flow_v, flow_rows,
+                                   flow_cols, 0, row_begin, row_end, u, v, 0, ostride, stream);
 }
 
 int micv_lk_warp_dev(micv_ctx *ctx, const float *src, size_t sstride, const float *du,

@@ -22,6 +22,10 @@ struct PyrLevels {
     int tiles_before[17];  // prefix sum of 64x4-tiles per level (levels 1..n-1 and level 0 copy)
     int n;
     int chain;  // levels >= 2 are emitted by the level-1 tiles
+    // Row-sharded builds: level l is written for rows [row_lo[l], row_hi[l]) only, and the level-1
+    // tiles start at tile row l1_tile0 (full builds: 0 .. rows, 0).
+    int row_lo[16], row_hi[16];
+    int l1_tile0;
 };
 
 // One block = 64x4 output pixels of some level; blockIdx.x indexes tiles over all levels,
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict_
     if (L.dst[l] == nullptr) return;
     const int t = bid - L.tiles_before[l];
     const int tw = (L.cols[l] + 63) >> 6;
-    const int tx = t % tw, ty = t / tw;
+    const int tx = t % tw, ty = t / tw + (l == 1 ? L.l1_tile0 : 0);
     const int x = tx * 64 + (threadIdx.x & 63);
     const int y = ty * 4 + (threadIdx.x >> 6);
     if (x >= L.cols[l] || y >= L.rows[l]) return;
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict_
     const float *s = src + blockIdx.y * img_elems;
     float *d = L.dst[l] + blockIdx.y * (size_t)L.rows[l] * L.cols[l];
     const float v = s[(size_t)((y << l) + sh) * sstride + (x << l) + sh];
-    d[(size_t)y * L.cols[l] + x] = v;
+    if (y >= L.row_lo[l] && y < L.row_hi[l]) d[(size_t)y * L.cols[l] + x] = v;
     // Every level is a decimation of the previous one at odd coordinates, so the level-1 tiles
     // also emit the deeper levels (which then have no tiles of their own): the source is read
     // once, on its odd rows only.
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict_
             yy >>= 1;
             xx >>= 1;
             ll++;
-            if (L.dst[ll] && yy < L.rows[ll] && xx < L.cols[ll])
+            if (L.dst[ll] && yy >= L.row_lo[ll] && yy < L.row_hi[ll] && xx < L.cols[ll])
                 L.dst[ll][blockIdx.y * (size_t)L.rows[ll] * L.cols[ll] + (size_t)yy * L.cols[ll] + xx] = v;
         }
     }
@@ -208,7 +212,6 @@ __global__ __launch_bounds__(256) void rgb8_to_gray_kernel(const uint8_t *__rest
     dst[(size_t)y * dstride + x] = (float)g;
 }
 
-// dst = a - b (dense a, b of pitch `cols`; dst strided).
 // The general form: 1, 3 or 4 interleaved channels of 8-bit or float samples -> grey f32.
 //   8U : the fixed-point weights above (4-channel input ignores alpha), then convertTo(CV_32F);
 //   32F: cv::cvtColor's float path, (c0*0.299f + c1*0.587f) + c2*0.114f, unfused;
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(256) void to_gray_kernel(const T *__restrict__ src,
     dst[(size_t)y * dstride + x] = g;
 }
 
+// dst = a - b (dense a, b of pitch `cols`; dst strided).
 __global__ __launch_bounds__(256) void sub_kernel(const float *__restrict__ a,
                                                    const float *__restrict__ b,
                                                    float *__restrict__ dst, int dstride, int rows,
@@ -277,22 +281,47 @@ int launch_resize_linear(hipStream_t s, const float *src, int srows, int scols, 
 // image b of level l at dst[l] + b*rows_l*cols_l.
 int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, size_t img_elems,
                       int sstride, int rows, int cols, int levels, float *const *dst_a,
-                      float *const *dst_b, int batch) {
+                      float *const *dst_b, int batch, const int *row_lo, const int *row_hi) {
     PyrLevels L[2];
     int total = 0;
+    // Row-restricted builds need the level-1 tiles (they emit the deeper levels): level-l row yy comes
+    // from level-1 row 2^(l-1) (yy + 1) - 1.
+    int l1_lo = 0, l1_hi = levels > 1 ? rows >> 1 : 0;
+    const bool restricted = row_lo && row_hi && levels > 1 && dst_a[1] != nullptr;
+    if (restricted) {
+        l1_lo = rows;
+        l1_hi = 0;
+        for (int l = 1; l < levels; l++) {
+            if (row_lo[l] >= row_hi[l]) continue;
+            const int a = ((row_lo[l] + 1) << (l - 1)) - 1, b = (row_hi[l] << (l - 1));  // [a, b)
+            l1_lo = a < l1_lo ? a : l1_lo;
+            l1_hi = b > l1_hi ? b : l1_hi;
+        }
+        if (l1_lo < 0) l1_lo = 0;
+        if (l1_hi > (rows >> 1)) l1_hi = rows >> 1;
+        if (l1_lo >= l1_hi) return MICV_OK;
+    }
     for (int k = 0; k < 2; k++) {
         float *const *dst = k ? dst_b : dst_a;
         L[k].n = levels;
         total = 0;
+        L[k].l1_tile0 = restricted ? l1_lo / 4 : 0;
         for (int l = 0; l < levels; l++) {
             L[k].rows[l] = rows >> l;
             L[k].cols[l] = cols >> l;
             L[k].dst[l] = dst ? dst[l] : nullptr;
             L[k].tiles_before[l] = total;
+            L[k].row_lo[l] = (row_lo && row_hi) ? row_lo[l] : 0;
+            L[k].row_hi[l] = (row_lo && row_hi) ? row_hi[l] : L[k].rows[l];
             // both sets use the same tiling (a skipped level must be skipped in both); with level 1
             // present its tiles emit every deeper level
             L[k].chain = levels > 1 && dst_a[1] != nullptr;
-            if (dst_a[l] && !(L[k].chain && l >= 2)) total += cdiv(L[k].cols[l], 64) * cdiv(L[k].rows[l], 4);
+            if (dst_a[l] && !(L[k].chain && l >= 2)) {
+                if (restricted && l == 1)
+                    total += cdiv(L[k].cols[l], 64) * (cdiv(l1_hi, 4) - l1_lo / 4);
+                else
+                    total += cdiv(L[k].cols[l], 64) * cdiv(L[k].rows[l], 4);
+            }
         }
         L[k].tiles_before[levels] = total;
     }
@@ -306,7 +335,7 @@ int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, siz
 int launch_pyr_build(hipStream_t s, const float *src, size_t img_elems, int sstride, int rows,
                      int cols, int levels, float *const *dst, int batch) {
     return launch_pyr_build2(s, src, nullptr, img_elems, sstride, rows, cols, levels, dst, nullptr,
-                             batch);
+                             batch, nullptr, nullptr);
 }
 
 }  // namespace micv
@@ -365,6 +394,28 @@ int micv_gaussian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int col
     MICV_HIP(hipSetDevice(ctx->device));
     return launch_pyr_build(static_cast<hipStream_t>(stream), src, 0, (int)(sstride / 4), rows,
                             cols, levels, dst_levels, 1);
+}
+
+int micv_gaussian_pyramid_batch_dev(micv_ctx *ctx, const float *src, int batch, size_t image_stride,
+                                    int rows, int cols, size_t sstride, int levels, float *const *dst_levels,
+                                    const int *row_begin, const int *row_end, micv_stream stream) {
+    MICV_REQUIRE(ctx && src && dst_levels, "micv_gaussian_pyramid_batch: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0 && batch >= 1 && batch <= 32767, "micv_gaussian_pyramid_batch: bad size");
+    MICV_REQUIRE(levels >= 1 && levels <= 16 && (rows >> (levels - 1)) > 0 && (cols >> (levels - 1)) > 0,
+                 "micv_gaussian_pyramid_batch: %d levels do not fit a %dx%d image", levels, rows, cols);
+    MICV_REQUIRE(stride_ok(sstride, cols, 4) && image_stride % 4 == 0 &&
+                     (batch == 1 || image_stride >= sstride * (size_t)rows),
+                 "micv_gaussian_pyramid_batch: bad stride");
+    MICV_REQUIRE((row_begin == nullptr) == (row_end == nullptr), "micv_gaussian_pyramid_batch: give both row arrays or none");
+    for (int l = 1; l < levels; l++)
+        MICV_REQUIRE(dst_levels[l] != nullptr, "micv_gaussian_pyramid_batch: dst_levels[%d] is null", l);
+    if (row_begin)
+        for (int l = 0; l < levels; l++)
+            MICV_REQUIRE(row_begin[l] >= 0 && row_begin[l] <= row_end[l] && row_end[l] <= (rows >> l),
+                         "micv_gaussian_pyramid_batch: bad row range at level %d", l);
+    MICV_HIP(hipSetDevice(ctx->device));
+    return launch_pyr_build2(static_cast<hipStream_t>(stream), src, nullptr, image_stride / 4, (int)(sstride / 4),
+                             rows, cols, levels, dst_levels, nullptr, batch, row_begin, row_end);
 }
 
 int micv_laplacian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int cols,

@@ -78,6 +78,33 @@ class DistComm:
     def __init__(self, rank, world):
         import torch.distributed as dist
         self.dist, self.rank, self.world = dist, rank, world
+        self._slabs = {}
+
+    def exchange_batch(self, plan, level, flow):
+        """Halo rows of level `level` for ALL pairs of a batch in one batch_isend_irecv: `flow` is the
+        [B, 2, rows, cols] (u, v stacked) tensor of that level.  Send / receive slabs are allocated once
+        per (level, peer) and reused; packing and unpacking are one strided copy each."""
+        dist = self.dist
+        ops, recvs = [], []
+        for src, dst, r0, r1 in plan.transfers(level):
+            if src != self.rank and dst != self.rank:
+                continue
+            key = (level, src, dst, r0, r1, tuple(flow.shape), flow.device)
+            buf = self._slabs.get(key)
+            if buf is None:
+                buf = flow.new_empty((flow.shape[0], 2, r1 - r0, flow.shape[3]))
+                self._slabs[key] = buf
+            if src == self.rank:
+                buf.copy_(flow[:, :, r0:r1])
+                ops.append(dist.P2POp(dist.isend, buf, dst))
+            else:
+                recvs.append((buf, r0, r1))
+                ops.append(dist.P2POp(dist.irecv, buf, src))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for buf, r0, r1 in recvs:
+            flow[:, :, r0:r1].copy_(buf)
 
     def exchange(self, plan, level, fu, fv):
         import torch
@@ -203,25 +230,124 @@ class _NoComm:
     def exchange(self, *a):
         pass
 
+    def exchange_batch(self, *a):
+        pass
+
+
+IMAGE_MARGIN = 16  # level rows of `prev` a band reads beyond itself: Sobel 1 + window radius (<= 15 here)
+
 
 class RowShardBatch:
     """A batch of frame pairs, every pair split by rows over `world` ranks: what `bench.py --mode
-    rowshard` runs.  Inputs are replicated ([B, rows, cols] on every rank); run() writes this rank's
-    band of every pair into u / v."""
+    rowshard` runs.  Per step and rank: ONE pyramid launch per image set restricted to the rows the
+    band touches, ONE level launch for the band of all pairs (micv_lk_level_batch_dev), ONE batched
+    halo exchange per level.  All buffers are allocated once.  Inputs are [B, rows, cols] tensors
+    addressed by absolute row; run() writes this rank's band of every pair into u / v.
 
-    def __init__(self, ctx, rows, cols, levels, win, batch, rank, world, comm=None):
-        self.ctx, self.levels, self.win, self.batch, self.rank = ctx, levels, win, batch, rank
+    Static halos: of `prev` a band reads only IMAGE_MARGIN rows beyond itself (a deployment ships
+    band + margin, and the rank builds only those pyramid rows).  `next` is read at (y + dv) by the
+    warp, and LK's flow is unbounded where the window is nearly degenerate (isolated pixels with
+    |dv| of hundreds occur on the synthetic pairs): exact parity needs the whole `next` level on
+    every rank, so its pyramid is built in full (SURVEY.md section 8e's "declared bound" would trade
+    those pixels' parity for memory; it is not taken)."""
+
+    def __init__(self, ctx, rows, cols, levels, win, batch, rank, world, comm=None, device=None):
+        import torch
+        self.ctx, self.levels, self.win, self.batch, self.rank, self.world = ctx, levels, win, batch, rank, world
+        if win // 2 + 1 > IMAGE_MARGIN:
+            raise ValueError(f"window {win} reads more than IMAGE_MARGIN = {IMAGE_MARGIN} rows of prev beyond a band")
         self.plan = RowShardPlan(rows, cols, levels, world, win)
         self.comm = comm if comm is not None else _NoComm()
         self.band0 = self.plan.band(0, rank)
-        self.level_fn = gpu_level_fn(ctx, win)
+        dev = device if device is not None else torch.device("cuda", ctx.device)
+        dims = self.plan.dims
+        self.ppyr = [None] + [torch.empty((batch,) + dims[l], device=dev) for l in range(1, levels)]
+        self.npyr = [None] + [torch.empty((batch,) + dims[l], device=dev) for l in range(1, levels)]
+        self.flow = [None] + [torch.zeros((batch, 2) + dims[l], device=dev) for l in range(1, levels)]
+        lo, hi = [], []
+        for l in range(levels):
+            a, b = self.plan.band(l, rank)
+            lo.append(max(0, a - IMAGE_MARGIN))
+            hi.append(min(dims[l][0], b + IMAGE_MARGIN))
+        self.img_rows = (lo, hi)
+
+    def _pyr_ptrs(self, pyr):
+        import ctypes as C
+        arr = (C.c_void_p * self.levels)()
+        arr[0] = None
+        for l in range(1, self.levels):
+            arr[l] = pyr[l].data_ptr()
+        return arr
+
+    def build_pyramids(self, prev, nxt, stream, restrict=True):
+        import ctypes as C
+        from ._capi import check, lib
+        if self.levels < 2:
+            return
+        B, rows, cols = prev.shape
+        lo = hi = None
+        if restrict:
+            lo = (C.c_int * self.levels)(*self.img_rows[0])
+            hi = (C.c_int * self.levels)(*self.img_rows[1])
+        for src, pyr, a, b in ((prev, self.ppyr, lo, hi), (nxt, self.npyr, None, None)):
+            check(lib.micv_gaussian_pyramid_batch_dev(self.ctx.handle, src.data_ptr(), B, rows * cols * 4, rows, cols,
+                                                      cols * 4, self.levels, self._pyr_ptrs(pyr), a, b, stream))
+
+    def level(self, l, prev, nxt, u, v, stream):
+        """The band of level l for all pairs: one launch (+ one for the base flow on odd-sized levels)."""
+        from ._capi import check, lib
+        rows, cols = self.plan.dims[l]
+        a, b = self.plan.band(l, self.rank)
+        p = prev if l == 0 else self.ppyr[l]
+        n = nxt if l == 0 else self.npyr[l]
+        if l == 0:
+            ou, ov, ostride = u.data_ptr(), v.data_ptr(), rows * cols * 4
+        else:
+            f = self.flow[l]
+            ou, ov, ostride = f.data_ptr(), f.data_ptr() + rows * cols * 4, 2 * rows * cols * 4
+        if l == self.levels - 1:
+            fu = fv = None
+            fr = fc = fstride = 0
+        else:
+            c = self.flow[l + 1]
+            fr, fc = self.plan.dims[l + 1]
+            fu, fv, fstride = c.data_ptr(), c.data_ptr() + fr * fc * 4, 2 * fr * fc * 4
+        check(lib.micv_lk_level_batch_dev(self.ctx.handle, p.data_ptr(), n.data_ptr(), self.batch, rows * cols * 4,
+                                          rows, cols, cols * 4, self.win, fu, fv, fr, fc, fstride, a, b, ou, ov,
+                                          ostride, cols * 4, stream))
 
     def run(self, prev, nxt, u, v, stream=None):
-        from . import pyr
-        a0, b0 = self.band0
-        for i in range(self.batch):
-            pp = pyr.makeGaussianPyramid(prev[i], self.levels, ctx=self.ctx)
-            npyr = pyr.makeGaussianPyramid(nxt[i], self.levels, ctx=self.ctx)
-            bu, bv = lk_pyr_band(pp, npyr, self.plan, self.rank, self.win, self.level_fn, self.comm)
-            u[i, a0:b0] = bu[a0:b0]
-            v[i, a0:b0] = bv[a0:b0]
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+        self.build_pyramids(prev, nxt, s)
+        for l in range(self.levels - 1, -1, -1):
+            if l < self.levels - 1:
+                self.comm.exchange_batch(self.plan, l + 1, self.flow[l + 1])
+            self.level(l, prev, nxt, u, v, s)
+
+
+def run_virtual_batch(runners, prev, nxt, u, v, stream=None, poison=None, shared_pyramids=True):
+    """All ranks of a row-sharded batch on ONE device ("virtual shards"): the same
+    band launches and the same transfer list as the distributed run, the exchange done by row copies
+    between the ranks' private flow buffers.  The pyramids are built once and shared (the virtual
+    ranks share the device's memory) unless shared_pyramids=False; `poison` overwrites rows a rank does not own after every level."""
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+    r0 = runners[0]
+    if shared_pyramids:
+        r0.build_pyramids(prev, nxt, s, restrict=False)
+        for r in runners[1:]:
+            r.ppyr, r.npyr = r0.ppyr, r0.npyr
+    else:  # as distributed ranks do: every rank builds the rows its band touches, into its own buffers
+        for r in runners:
+            r.build_pyramids(prev, nxt, s, restrict=True)
+    for l in range(r0.levels - 1, -1, -1):
+        if l < r0.levels - 1:
+            for src, dst, a, b in r0.plan.transfers(l + 1):
+                runners[dst].flow[l + 1][:, :, a:b].copy_(runners[src].flow[l + 1][:, :, a:b])
+        for r in runners:
+            r.level(l, prev, nxt, u, v, s)
+            if poison is not None and l > 0:
+                a, b = r.plan.band(l, r.rank)
+                r.flow[l][:, :, :a] = poison
+                r.flow[l][:, :, b:] = poison
