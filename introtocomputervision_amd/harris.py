@@ -51,9 +51,11 @@ def getCornerResponse(gradX, gradY, windowSize, gaussianSigma, harrisScore, ctx=
     return resp
 
 
-def refineCorners(cornerResponse, threshold, minDistance, capacity=None, ctx=None):
+def refineCorners(cornerResponse, threshold, minDistance, capacity=None, ctx=None, lazy=False):
     """harris::{cpu,gpu}::refineCorners (Harris.cpp:99-147 / Harris.cu:243-329) ->
-    (corners, cornerLocs) with cornerLocs an [n, 2] int32 array of (y, x) in row-major order."""
+    (corners, cornerLocs) with cornerLocs an [n, 2] int32 array of (y, x) in row-major order.
+    Device input with lazy=True: returns (corners, locs[capacity, 2], count) without reading the
+    count back (no host synchronisation)."""
     B.check2d(cornerResponse, np.float32, name="cornerResponse")
     rows, cols = cornerResponse.shape
     cap = int(capacity) if capacity is not None else rows * cols
@@ -68,6 +70,8 @@ def refineCorners(cornerResponse, threshold, minDistance, capacity=None, ctx=Non
                                          int(minDistance), B.ptr(corners), B.stride_bytes(corners),
                                          locs.data_ptr(), cap, cnt.data_ptr(),
                                          B.stream_of(cornerResponse)))
+        if lazy:
+            return corners, locs, cnt
         n = min(int(cnt.item()), cap)
         return corners, locs[:n]
     locs = np.empty((cap, 2), np.int32)

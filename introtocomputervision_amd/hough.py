@@ -49,9 +49,11 @@ def houghCirclesAccumulate(edgeMask, radius, ctx=None):
     return acc
 
 
-def findLocalMaxima(accumulator, numPeaks, threshold, ctx=None):
+def findLocalMaxima(accumulator, numPeaks, threshold, ctx=None, lazy=False):
     """cuda::findLocalMaxima (Hough.cu:366-426) -> [n, 2] uint32 (row, col) pairs ordered by
-    votes descending (stable)."""
+    votes descending (stable).  Device input with lazy=True: returns (peaks[numPeaks, 2], count) as
+    device tensors without reading the count back (no host synchronisation; rows >= count are
+    unspecified) -- for pipelines that keep consuming on the device."""
     B.check2d(accumulator, np.int32, name="accumulator")
     if B.is_dev(accumulator) and not accumulator.is_contiguous():
         raise ValueError("accumulator must be contiguous")
@@ -66,6 +68,8 @@ def findLocalMaxima(accumulator, numPeaks, threshold, ctx=None):
         cnt = torch.zeros((1,), dtype=torch.int64, device=accumulator.device)
         check(lib.micv_hough_peaks_dev(c.handle, B.ptr(accumulator), rows, cols, k, int(threshold),
                                        peaks.data_ptr(), cnt.data_ptr(), B.stream_of(accumulator)))
+        if lazy:
+            return peaks, cnt
         return peaks[:int(cnt.item())]
     peaks = np.empty((max(k, 1), 2), np.uint32)
     cnt = i64(0)

@@ -61,6 +61,13 @@ for rows, cols in ((2160, 3840), (480, 640)):
     line(f"sobel3 pair {cols}x{rows}", ms_s, rows * cols, 12)
     line(f"harris response 5x5 {cols}x{rows} (ref 480x640: 0.80 ms GTX1080)", ms_r, rows * cols, 12)
     line(f"harris NMS + ordered list {cols}x{rows} (ref 480x640: 0.59 ms)", ms_n, rows * cols, 8)
+    ms_l = timeit(lambda: harris.refineCorners(Rr, 5e8, 5, capacity=1 << 16, ctx=ctx, lazy=True))
+    line(f"harris NMS + ordered list {cols}x{rows}, count left on the device (lazy)", ms_l, rows * cols, 8)
+    kp_ = harris.getKeypoints(gx, gy, harris.refineCorners(Rr, 5e8, 5, capacity=1 << 16, ctx=ctx)[1], 10, ctx=ctx)
+    if len(kp_):
+        ms_d = timeit(lambda: harris.computeDescriptors(gx, gy, kp_, ctx=ctx))
+        line(f"SIFT-style descriptors, {len(kp_)} keypoints of size 10 (107x107 windows) {cols}x{rows}", ms_d, len(kp_) * 107 * 107,
+             8, {"keypoints": int(len(kp_)), "us_per_keypoint": round(ms_d * 1e3 / len(kp_), 3)})
 
 # Hough on a 1080p mask
 mask, lines_, circles = synth.hough_mask(1080, 1920)
@@ -73,6 +80,8 @@ ms = timeit(lambda: hough.houghCirclesAccumulate(Mk, 30, ctx=ctx))
 line("hough circles 1080p r=30", ms, 1080 * 1920, 5, {"Mvotes_per_s": round(n_edge * 360 / ms / 1e3, 1)})
 ms = timeit(lambda: hough.findLocalMaxima(acc, 10, 300, ctx=ctx))
 line("hough peaks top-10 of 4406x180", ms, 4406 * 180, 4)
+ms = timeit(lambda: hough.findLocalMaxima(acc, 10, 300, ctx=ctx, lazy=True))
+line("hough peaks top-10, count left on the device (lazy)", ms, 4406 * 180, 4)
 
 # single-level LK and pyramid pieces at 1080p
 prev, nxt = synth.lk_pair(0x5EED0005, 1080, 1920)
