@@ -386,19 +386,20 @@ def main(argv=None):
         pairs_per_launch = ctx.profile_lk_pairs() or B  # the library splits the batch into stream groups
         k_bytes = level0_kernel_bytes_pair(ROWS, COLS, LEVELS) * pairs_per_launch
         achieved = k_bytes / (lvl_ms[0] * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, kernel_name = None, None, ctx.lk_level_kernel_name()
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from rocprofv3 --pmc runs
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("pairs_per_launch") == pairs_per_launch:
                     traffic = tj.get("level0_hbm_bytes_per_launch")
+                    kernel_name = tj.get("kernel", kernel_name).replace("micv::", "")
                     traffic_source = (f"profiles/traffic.json ({tj.get('profile', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}"
                                       ", separate passes, gfx950 x2 FETCH correction; not measured in this run)")
             except Exception:
                 traffic = None
         roofline = {
-            "bound": "hbm", "kernel": ctx.lk_level_kernel_name() + " (pyramid level 0)",
+            "bound": "hbm", "kernel": kernel_name + " (pyramid level 0)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "frac_of_measured_copy_bw": achieved / HBM_COPY_GBS, "measured_copy_bw": HBM_COPY_GBS,

@@ -71,9 +71,10 @@ for (k, g), d in sorted(pmc.items(), key=lambda kv: -kv[0][1]):
         print(f"      {c:26s} {v[0] / max(v[1], 1):18.1f}  (n={v[1]})")
 res["pmc_mean_per_dispatch"] = summ
 
-lvl0 = [kg for kg in pmc if "lk_level_kernel<7, 1" in kg[0]]
+# the level-0 launch = the lk_level* dispatch that writes the most (the plain kernel or the chain kernel)
+lvl0 = [kg for kg in pmc if "lk_level" in kg[0] and "WRITE_SIZE" in pmc[kg]]
 if lvl0:
-    kg = max(lvl0, key=lambda t: t[1])
+    kg = max(lvl0, key=lambda t: pmc[t]["WRITE_SIZE"][0] / pmc[t]["WRITE_SIZE"][1])
     d = pmc[kg]
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         fetch = d["FETCH_SIZE"][0] / d["FETCH_SIZE"][1] * 1024
