@@ -26,6 +26,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "lk_device.hpp"
@@ -136,6 +137,71 @@ __device__ __forceinline__ void row_taps(const float (&a)[4 * C::WV], const floa
         o[j] = acc;
     }
     *reinterpret_cast<float4 *>(out) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ---- the row pass with every FMA packed and no operand shuffles ---------------------------------
+// v_pk_fma_f32 wants its operands as aligned register pairs.  Pairing outputs (j, j+1) tap by tap
+// needs (p[j+k], p[j+k+1]), which is an aligned pair only for even j+k: the compiler fills the odd
+// half with ~54 v_mov / v_pk_mov and 9 duplicate v_pk_mul per 4-output job.  Skewing the pair by one
+// tap removes them: at step s output j takes tap s and output j+1 takes tap s-1, so BOTH lanes
+// multiply the SAME product p[j+s] (op_sel broadcasts one half of an aligned pair) and the taps come
+// as the pair (g[s-1], g[s]) from SGPRs.  Every output still runs its own fmaf chain over taps
+// 0..2R in order, so the bits are those of row_taps().  Steps 0 and 2R+1 touch one lane only.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int SEL>
+__device__ __forceinline__ void pk_fma_skew(v2f &acc, v2f p, v2f gpair) {
+    // lanes: acc.x += p[SEL] * gpair.y (tap s);  acc.y += p[SEL] * gpair.x (tap s - 1)
+    if (SEL == 0)
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "v"(p), "s"(gpair));
+    else
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(p), "s"(gpair));
+}
+
+template <typename C, int J, int S>
+__device__ __forceinline__ void skew_step(v2f &acc, const v2f (&P)[C::WV * 2], const TapsN<C::W> &g) {
+    constexpr int I = J + S;  // index of the product both lanes use at this step
+    const float pv = (I & 1) ? P[I >> 1].y : P[I >> 1].x;
+    if (S == 0) {
+        acc.x = fmaf(pv, g.k[0], 0.f);  // output J, tap 0; output J+1 has not started
+        acc.y = 0.f;
+    } else if (S == C::W) {
+        acc.y = fmaf(pv, g.k[C::W - 1], acc.y);  // output J+1, last tap; output J is complete
+    } else {
+        const v2f gp = {g.k[S - 1], g.k[S]};
+        pk_fma_skew<I & 1>(acc, P[I >> 1], gp);
+    }
+}
+
+template <typename C, int J, int... S>
+__device__ __forceinline__ void skew_chain(v2f &acc, const v2f (&P)[C::WV * 2], const TapsN<C::W> &g,
+                                           std::integer_sequence<int, S...>) {
+    (skew_step<C, J, S>(acc, P, g), ...);
+}
+
+// Four adjacent outputs of the row pass of the product field a*b, windows given as aligned pairs.
+template <typename C>
+__device__ __forceinline__ void row_taps_skew(const v2f (&a)[C::WV * 2], const v2f (&b)[C::WV * 2],
+                                              const TapsN<C::W> &g, float *__restrict__ out) {
+    v2f P[C::WV * 2];
+#pragma unroll
+    for (int i = 0; i < C::WV * 2; i++) P[i] = a[i] * b[i];  // v_pk_mul_f32, each product once
+    v2f acc0, acc1;
+    skew_chain<C, 0>(acc0, P, g, std::make_integer_sequence<int, C::W + 1>{});
+    skew_chain<C, 2>(acc1, P, g, std::make_integer_sequence<int, C::W + 1>{});
+    *reinterpret_cast<float4 *>(out) = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+}
+
+template <typename C>
+__device__ __forceinline__ void load_window_pairs(const float *__restrict__ A, int qy, int c0,
+                                                  v2f (&w)[C::WV * 2]) {
+    const v4f *a4 = reinterpret_cast<const v4f *>(A + qy * C::GS + c0);
+#pragma unroll
+    for (int i = 0; i < C::WV; i++) {
+        const v4f v = a4[i];
+        w[2 * i + 0] = (v2f){v.x, v.y};
+        w[2 * i + 1] = (v2f){v.z, v.w};
+    }
 }
 
 // Column pass: thread (c, r0) produces 8 vertically adjacent window sums from one row buffer.
@@ -543,22 +609,27 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // a 3-row register window; the column pass finishes one output per step.
             // carry tiles compute 2R fewer rows: shorter segments keep every thread's job short
             constexpr int SEG = CARRY ? 6 : (TH == 16 ? 5 : (NT >= 512 ? 8 : 16)), NSEG = (GH - Q0 + SEG - 1) / SEG;
-            static_assert(GW * NSEG <= NT || !CARRY, "one trip");
-            for (int n = tid; n < GW * NSEG; n += NT) {
-                const int seg = n / GW, qx = n - seg * GW;
+            // A job covers TWO adjacent gradient columns: the pair rides the two lanes of packed f32
+            // instructions (v_pk_add / v_pk_mul / v_pk_fma), so the Sobel arithmetic of both images costs
+            // half the VALU instructions per pixel, and every LDS access is a two-element one.
+            static_assert(GW % 2 == 0, "gradient columns in pairs");
+            constexpr int GW2 = GW / 2;
+            const v2f s1v = {s1, s1}, s2v = {s2, s2}, halfv = {0.5f, 0.5f};
+            for (int n = tid; n < GW2 * NSEG; n += NT) {
+                const int seg = n / GW2, qx = 2 * (n - seg * GW2);
                 const int q0 = Q0 + seg * SEG, q1 = q0 + SEG < GH ? q0 + SEG : GH;
                 const int lx = qx + (H - R);
-                float ptx[3], pty[3], wtx[3], wty[3], pc[3], wc[3];
+                v2f ptx[3], pty[3], wtx[3], wty[3], pcc[3], wcc[3];
                 auto rowpass = [&](int ly, int slot) {
                     const float *pr = P + ly * PS + lx, *wr = Wp + ly * PS + lx;
-                    const float pa = pr[-1], pb = pr[0], pcv = pr[1];
-                    const float wa = wr[-1], wb = wr[0], wcv = wr[1];
-                    ptx[slot] = pcv - pa;
-                    pty[slot] = fmaf(pcv, s1, fmaf(pb, s2, pa * s1));
-                    wtx[slot] = wcv - wa;
-                    wty[slot] = fmaf(wcv, s1, fmaf(wb, s2, wa * s1));
-                    pc[slot] = pb;
-                    wc[slot] = wb;
+                    const v2f pa = {pr[-1], pr[0]}, pb = {pr[0], pr[1]}, pc = {pr[1], pr[2]};
+                    const v2f wa = {wr[-1], wr[0]}, wb = {wr[0], wr[1]}, wc = {wr[1], wr[2]};
+                    ptx[slot] = pc - pa;
+                    pty[slot] = __builtin_elementwise_fma(pc, s1v, __builtin_elementwise_fma(pb, s2v, pa * s1v));
+                    wtx[slot] = wc - wa;
+                    wty[slot] = __builtin_elementwise_fma(wc, s1v, __builtin_elementwise_fma(wb, s2v, wa * s1v));
+                    pcc[slot] = pb;
+                    wcc[slot] = wb;
                 };
                 const int lyb = q0 + (H - R);  // image row of gradient row q0
                 rowpass(lyb - 1, 0);
@@ -571,13 +642,16 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         if (qy + t < q1) {
                             const int s_new = (t + 2) % 3, s_top = t % 3, s_mid = (t + 1) % 3;
                             rowpass(qy + t + (H - R) + 1, s_new);
-                            const float pgx = fmaf(ptx[s_new], s1, fmaf(ptx[s_mid], s2, ptx[s_top] * s1));
-                            const float pgy = pty[s_new] - pty[s_top];
-                            const float ngx = fmaf(wtx[s_new], s1, fmaf(wtx[s_mid], s2, wtx[s_top] * s1));
-                            const float ngy = wty[s_new] - wty[s_top];
-                            Gx[(qy + t) * GS + qx] = avg2(ngx, pgx);
-                            Gy[(qy + t) * GS + qx] = avg2(ngy, pgy);
-                            Gt[(qy + t) * GS + qx] = wc[s_mid] - pc[s_mid];
+                            const v2f pgx = __builtin_elementwise_fma(
+                                ptx[s_new], s1v, __builtin_elementwise_fma(ptx[s_mid], s2v, ptx[s_top] * s1v));
+                            const v2f pgy = pty[s_new] - pty[s_top];
+                            const v2f ngx = __builtin_elementwise_fma(
+                                wtx[s_new], s1v, __builtin_elementwise_fma(wtx[s_mid], s2v, wtx[s_top] * s1v));
+                            const v2f ngy = wty[s_new] - wty[s_top];
+                            // OpticalFlow.cpp:62-64: avg2(next, prev) = next * .5f + prev * .5f, It = next - prev
+                            *reinterpret_cast<v2f *>(Gx + (qy + t) * GS + qx) = ngx * halfv + pgx * halfv;
+                            *reinterpret_cast<v2f *>(Gy + (qy + t) * GS + qx) = ngy * halfv + pgy * halfv;
+                            *reinterpret_cast<v2f *>(Gt + (qy + t) * GS + qx) = wcc[s_mid] - pcc[s_mid];
                         }
                     }
                 }
@@ -630,17 +704,17 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
             const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
-                float wx[4 * C::WV], wy[4 * C::WV];
-                load_window<C>(Gx, qy, c0, wx);
-                load_window<C>(Gy, qy, c0, wy);
+                v2f wx[2 * C::WV], wy[2 * C::WV];
+                load_window_pairs<C>(Gx, qy, c0, wx);
+                load_window_pairs<C>(Gy, qy, c0, wy);
                 const int o = rb_off(qy, grp);
-                row_taps<C>(wx, wx, g, rb0 + o);
+                row_taps_skew<C>(wx, wx, g, rb0 + o);
                 // 64x16 tiles: the sweep is a single (peeled) trip; keep its three products from
                 // interleaving so the body stays inside the 128-VGPR budget
                 if (TH == 16) __builtin_amdgcn_sched_barrier(0);
-                row_taps<C>(wx, wy, g, rb1 + o);
+                row_taps_skew<C>(wx, wy, g, rb1 + o);
                 if (TH == 16) __builtin_amdgcn_sched_barrier(0);
-                row_taps<C>(wy, wy, g, rb2 + o);
+                row_taps_skew<C>(wy, wy, g, rb2 + o);
             }
         }
         __syncthreads();
@@ -658,15 +732,15 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
             const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
-                float wx[4 * C::WV], wt[4 * C::WV];
-                load_window<C>(Gx, qy, c0, wx);
-                load_window<C>(Gt, qy, c0, wt);
+                v2f wx[2 * C::WV], wt[2 * C::WV];
+                load_window_pairs<C>(Gx, qy, c0, wx);
+                load_window_pairs<C>(Gt, qy, c0, wt);
                 const int o = rb_off(qy, grp);
-                row_taps<C>(wx, wt, g, rb0 + o);
+                row_taps_skew<C>(wx, wt, g, rb0 + o);
                 // 128-VGPR budget at 512 threads: the Iy window reuses the Ix window's registers
                 if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
-                load_window<C>(Gy, qy, c0, wx);
-                row_taps<C>(wx, wt, g, rb1 + o);
+                load_window_pairs<C>(Gy, qy, c0, wx);
+                row_taps_skew<C>(wx, wt, g, rb1 + o);
             }
         }
         __syncthreads();

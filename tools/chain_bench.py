@@ -7,7 +7,7 @@ prev = np.stack([synth.lk_pair(0x5EED0005+i,1080,1920,3,-2)[0] for i in range(B)
 dp, dn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
 out = (torch.empty_like(dp), torch.empty_like(dp))
 for groups in (1, 2):
-  for mc in (1, -1, 2, 3, 4, 8):
+  for mc in (0, 1):
     ctx = _capi.Context(0); ctx.set_option(_capi.OPT_LK_CHAIN, mc); ctx.set_lk_groups(groups)
     for _ in range(5): lk.calcOpticalFlowPyrBatch(dp, dn, 15, 5, ctx=ctx, out=out)
     torch.cuda.synchronize(); t=time.perf_counter()
