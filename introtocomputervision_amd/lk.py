@@ -12,16 +12,22 @@ from ._capi import Context, check, lib
 _default_ctx = {}
 
 
-def default_context(device=0):
-    if device not in _default_ctx:
-        _default_ctx[device] = Context(device)
-    return _default_ctx[device]
+def default_context(device=0, stream=0):
+    """One default context per (device, stream): a context owns ONE scratch arena and its auxiliary
+    streams, so launches from two streams must not share it (they would race on the arena with no
+    error).  Callers that manage streams themselves pass their own Context per stream."""
+    key = (int(device), int(stream or 0))
+    if key not in _default_ctx:
+        _default_ctx[key] = Context(device)
+    return _default_ctx[key]
 
 
 def _ctx_for(a, ctx):
     if ctx is not None:
         return ctx
-    return default_context(a.device.index or 0 if B.is_dev(a) else 0)
+    if B.is_dev(a):
+        return default_context(a.device.index or 0, B.stream_of(a))
+    return default_context(0)
 
 
 def calcOpticalFlow(prevImg, nextImg, winSize=21, ctx=None):
@@ -117,17 +123,25 @@ def calcOpticalFlowPyrBatch(prev, next_, winSize=21, levels=4, ctx=None, out=Non
     if not (B.is_dev(prev) and prev.is_cuda and prev.dim() == 3 and prev.is_contiguous()
             and prev.dtype == torch.float32):
         raise ValueError("prev: need a contiguous [B, rows, cols] float32 CUDA tensor")
-    if tuple(next_.shape) != tuple(prev.shape) or not next_.is_contiguous() or next_.dtype != prev.dtype:
-        raise ValueError("next: must match prev")
+    if not (isinstance(next_, torch.Tensor) and next_.is_cuda and next_.device == prev.device
+            and tuple(next_.shape) == tuple(prev.shape) and next_.is_contiguous() and next_.dtype == prev.dtype):
+        raise ValueError("next: must be a contiguous CUDA tensor matching prev (shape, dtype, device)")
     nb, rows, cols = prev.shape
     if out is None:
         u = torch.empty_like(prev)
         v = torch.empty_like(prev)
     else:
         u, v = out
-    c = _ctx_for(prev, ctx)
+        for t, name in ((u, "out[0]"), (v, "out[1]")):
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == prev.device and t.dtype == torch.float32
+                    and tuple(t.shape) == tuple(prev.shape) and t.is_contiguous()):
+                raise ValueError(f"{name}: must be a contiguous float32 CUDA tensor of prev's shape on prev's device")
+        if u.data_ptr() == v.data_ptr() or u.data_ptr() in (prev.data_ptr(), next_.data_ptr()) \
+                or v.data_ptr() in (prev.data_ptr(), next_.data_ptr()):
+            raise ValueError("out: u, v, prev and next must be four different buffers")
     if stream is None:
         stream = torch.cuda.current_stream(prev.device).cuda_stream
+    c = ctx if ctx is not None else default_context(prev.device.index or 0, stream)
     check(lib.micv_lk_flow_pyr_batch_dev(c.handle, prev.data_ptr(), next_.data_ptr(), nb,
                                          rows * cols * 4, rows, cols, cols * 4, int(winSize),
                                          int(levels), u.data_ptr(), v.data_ptr(), rows * cols * 4,
