@@ -115,8 +115,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--inflight", type=int, default=2, help="passes in flight (contexts/streams), pairs mode")
     ap.add_argument("--lk-groups", type=int, default=0,
-                    help="stream groups the library splits a batch into (0 = its default, 2); the PMC "
+                    help="stream groups the library splits a batch into (0 = its default, 1); the PMC "
                          "passes of tools/profile.sh use 1 so a level-0 dispatch covers the whole batch")
+    ap.add_argument("--lk-chain", type=int, default=0,
+                    help="MICV_OPT_LK_CHAIN of every context: 0 = the library's rule, 1 = no tile chains, n = longest chain")
     ap.add_argument("--sustained-s", type=float, default=2.0,
                     help="seconds of back-to-back steps for the `sustained` field (0 = skip)")
     ap.add_argument("--mode", choices=["pairs", "rowshard"], default="pairs",
@@ -270,6 +272,8 @@ def main(argv=None):
     v = torch.empty_like(prev)
     ctx = Context(local_rank)
     ctx.set_lk_groups(args.lk_groups)
+    from introtocomputervision_amd import _capi as _c
+    ctx.set_option(_c.OPT_LK_CHAIN, args.lk_chain)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     if args.mode == "rowshard":
@@ -295,6 +299,7 @@ def main(argv=None):
         for _ in range(1, F):
             lanes.append((Context(local_rank), torch.cuda.Stream(dev), (torch.empty_like(prev), torch.empty_like(prev))))
             lanes[-1][0].set_lk_groups(args.lk_groups)
+            lanes[-1][0].set_option(_c.OPT_LK_CHAIN, args.lk_chain)
         counter = [0]
 
         def step():

@@ -51,14 +51,14 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 /* Execution options of a context.  None of them changes a result: they select between kernels
  * that produce identical bits (tests compare the alternatives) or how a batch is scheduled.
  * The library reads NO environment variables. */
-#define MICV_OPT_LK_STREAM_GROUPS  1 /* stream groups a batch is split into: 0 = default (2), 1..4 */
+#define MICV_OPT_LK_STREAM_GROUPS  1 /* stream groups a batch is split into: 0 = default (1), 1..4 */
 #define MICV_OPT_LK_FORCE_GENERIC  2 /* LK through the generic multi-launch kernels */
 #define MICV_OPT_LK_NARROW_TILES   3 /* win-15 level kernel: 256-thread tiles instead of 512 */
 #define MICV_OPT_SOBEL_GENERIC     4 /* Sobel through the generic row / column passes */
 #define MICV_OPT_HARRIS_GENERIC    5 /* Harris response: one-thread-per-pixel kernel */
 #define MICV_OPT_NMS_SCAN          6 /* Harris NMS: scanning kernel instead of the separable one */
 #define MICV_OPT_STEREO_ROWS       7 /* rows per stereo strip: 0 = automatic, 8 or 10 */
-#define MICV_OPT_LK_CHAIN          8 /* fused LK tile chains: 0 = automatic, 1 = off, n = longest chain (<= 32) */
+#define MICV_OPT_LK_CHAIN          8 /* fused LK tile chains: 0 / 1 = off (default), n = longest chain (<= 32), -1 = schedule only */
 #define MICV_OPT_LK_SHORT_TILES    9 /* win-15 level kernel on launches under one round: 0 = 64x16 tiles, -1 = 64x32 */
 #define MICV_OPT_COUNT            10
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
@@ -96,7 +96,7 @@ int micv_profile_enable(micv_ctx *ctx, int on);
 int micv_profile_reset(micv_ctx *ctx);
 int micv_profile_lk_level(micv_ctx *ctx, int level, double *total_ms, int64_t *launches);
 /* Frame pairs covered by each profiled level launch: micv_lk_flow_pyr_batch_dev splits a batch
- * into groups that run on separate streams (MICV_OPT_LK_STREAM_GROUPS, default 2); the events bracket
+ * into groups that run on separate streams (MICV_OPT_LK_STREAM_GROUPS, default 1 = no split); the events bracket
  * the launches of the first group. */
 int micv_profile_lk_pairs(micv_ctx *ctx, int *pairs_per_launch);
 /* In-kernel phase stamps of the fused LK level kernel.  Compiled in only with -DMICV_DIAG (a

@@ -327,7 +327,9 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // 8-pair step on MI355X).  Groups share nothing but the read-only pyramids.
     int groups = 1;
     if (batch >= 2) {
-        groups = ctx->opt[MICV_OPT_LK_STREAM_GROUPS] > 0 ? ctx->opt[MICV_OPT_LK_STREAM_GROUPS] : 2;
+        // one group by default: with the r02 level kernels a second group buys nothing for a single pass
+        // (0.4217 vs 0.4228 ms) and costs 2.5 % when passes overlap across contexts (bench.py --inflight 2)
+        groups = ctx->opt[MICV_OPT_LK_STREAM_GROUPS] > 0 ? ctx->opt[MICV_OPT_LK_STREAM_GROUPS] : 1;
         groups = groups > 4 ? 4 : groups;
         if (groups > batch) groups = batch;
     }

@@ -985,9 +985,13 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             // A single 1080p pair (1020 tiles = two exact rounds) is slower with chains (0.041 -> 0.045 ms):
             // chains from four rounds on; between one and four rounds a batch still gains from the
             // schedule's order (every pair's border tiles first), with single tiles.
-            int max_chain = a.max_chain > 1 ? a.max_chain : (tiles >= 2048 ? 2 : 1);
+            // With the shuffle-free packed row pass (r02) the chain kernel no longer beats the plain one
+            // (A/B on one box, bench.py: 41.6 vs 41.6 Gpix/s, sustained 0.372 vs 0.368 ms): chains are
+            // an option (MICV_OPT_LK_CHAIN > 1), not the default.
+            (void)tiles;
+            int max_chain = a.max_chain > 1 ? a.max_chain : 1;
             if (max_chain > 32) max_chain = 32;
-            const bool sched_only = a.max_chain < 0 || (a.max_chain == 0 && max_chain == 1 && tiles >= 512 && a.batch >= 2);
+            const bool sched_only = a.max_chain < 0;
             if (sched_only) max_chain = 1;  // the schedule kernel with single tiles only
             if (max_chain > 1 || sched_only) {
                 const int4 *sched = nullptr;
