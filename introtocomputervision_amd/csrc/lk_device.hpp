@@ -58,7 +58,17 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
     float v0, v1, v2, v3;
     const int lx = ix - nx0, ly = iy - ny0;
     if ((unsigned)lx < (unsigned)(NW - 1) && (unsigned)ly < (unsigned)(NH - 1)) {
-        const float *p = N + ly * NW + lx;
+        // row offset by shifts where the window width allows (96 = 64 + 32: two full-rate ops instead
+        // of the quarter-rate v_mul_lo_u32 a plain `ly * NW` turns into)
+        int row_off;
+        if (NW == 96) {
+            int hi = ly << 6;
+            asm("" : "+v"(hi));  // keeps LLVM from folding the two shifts back into one multiply
+            row_off = hi + (ly << 5);
+        } else {
+            row_off = ly * NW;
+        }
+        const float *p = N + row_off + lx;
         v0 = p[0];
         v1 = p[1];
         v2 = p[NW];
