@@ -68,6 +68,42 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict_
     }
 }
 
+// The same build for the common case (levels >= 2, 16-byte aligned rows, no level-0 copy, all rows):
+// a thread loads FOUR source floats with one 16-byte load and keeps the two odd ones, so a wave
+// reads 1 KiB of contiguous bytes per row instead of 64 scattered dwords (1080p x 8 pairs: 43 -> see
+// DESIGN.md).  blockIdx.z = image set * batch + image.
+__global__ __launch_bounds__(256) void pyr_build_vec_kernel(const float *__restrict__ src_a,
+                                                             const float *__restrict__ src_b,
+                                                             size_t img_elems, int sstride, int batch,
+                                                             PyrLevels La, PyrLevels Lb) {
+    const int set = blockIdx.z / batch, img = blockIdx.z - set * batch;
+    const float *__restrict__ src = (set ? src_b : src_a) + img * img_elems;
+    const PyrLevels &L = set ? Lb : La;
+    const int x2 = blockIdx.x * 64 + (threadIdx.x & 63);  // pair of level-1 columns (2*x2, 2*x2 + 1)
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (2 * x2 >= L.cols[1] || y >= L.rows[1]) return;
+    // source row 2y+1, columns 4*x2 .. 4*x2+3: elements 1 and 3 are level-1 columns 2*x2, 2*x2+1
+    const float4 v4 = *reinterpret_cast<const float4 *>(src + (size_t)(2 * y + 1) * sstride + 4 * x2);
+    float *d1 = L.dst[1] + img * (size_t)L.rows[1] * L.cols[1] + (size_t)y * L.cols[1] + 2 * x2;
+    if (2 * x2 + 1 < L.cols[1])
+        *reinterpret_cast<float2 *>(d1) = make_float2(v4.y, v4.w);
+    else
+        d1[0] = v4.y;
+    // deeper levels: level-1 pixel (y, x) with y and x odd is level-2 pixel (y/2, x/2), and so on;
+    // of the two columns only the odd one (2*x2 + 1) can continue
+    if ((y & 1) && 2 * x2 + 1 < L.cols[1]) {
+        int yy = y, xx = 2 * x2 + 1, ll = 1;
+        const float v = v4.w;
+        while (ll + 1 < L.n && (yy & 1) && (xx & 1)) {
+            yy >>= 1;
+            xx >>= 1;
+            ll++;
+            if (L.dst[ll] && yy < L.rows[ll] && xx < L.cols[ll])
+                L.dst[ll][img * (size_t)L.rows[ll] * L.cols[ll] + (size_t)yy * L.cols[ll] + xx] = v;
+        }
+    }
+}
+
 // pyr::pyrUp step 1+2a (Pyramids.cu:86-91 replicate, :126 row filter): the replicated image's
 // rows 2yc and 2yc+1 are identical, so the row pass is evaluated once per COARSE row:
 //   R(yc, x) = chain_k fmaf(src(yc, reflect101(x+k-2, 2w) / 2), g5[k], acc)
@@ -187,13 +223,98 @@ __global__ __launch_bounds__(256) void flow_expand_resize_kernel(
     dst[(size_t)dy * dcols + dx] = h0 * b0 + h1 * b1;
 }
 
+// The same result with the expanded field shared through LDS: a 64x4 output tile touches at most
+// TE_R x TE_C samples of 2*pyrUp(src); their row-pass values (one per COARSE row and column) and then
+// the samples themselves are computed once per tile -- 10 FMAs per sample instead of 25 per use, 4 uses
+// per output.  Same fmaf chains (row pass per coarse row, then the column taps), same blend: same bits.
+// Used when the resize does not shrink by more than 2 (the tile's footprint is bounded).
+constexpr int TE_R = 12, TE_C = 72, TE_CR = TE_R / 2 + 3;
+__global__ __launch_bounds__(256) void flow_expand_resize_tiled_kernel(
+    const float *__restrict__ src_u, const float *__restrict__ src_v, int fr, int fc,
+    size_t src_pair, float *__restrict__ dst_u, float *__restrict__ dst_v, int drows, int dcols,
+    size_t dst_pair, double scale_x, double scale_y) {
+    __shared__ float Rp[TE_CR][TE_C];  // row pass of coarse row cr0 + i at expanded column ex0 + j
+    __shared__ float Ex[TE_R][TE_C];   // 2 * pyrUp(src) at (ey0 + i, ex0 + j)
+    const int tid = threadIdx.x;
+    const int pair = blockIdx.z >> 1;
+    const float *__restrict__ src = ((blockIdx.z & 1) ? src_v : src_u) + pair * src_pair;
+    float *__restrict__ dst = ((blockIdx.z & 1) ? dst_v : dst_u) + pair * dst_pair;
+    const int ur = 2 * fr, uc = 2 * fc;
+    const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    // source coordinates of an output row / column, exactly as resize_linear_kernel computes them
+    auto src_y = [&](int dy, float &fy) { fy = (float)((dy + 0.5) * scale_y - 0.5); const int sy = (int)floorf(fy); fy -= sy; return sy; };
+    auto src_x = [&](int dx, float &fx) {
+        fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= uc - 1) { fx = 0.f; sx = uc - 1; }
+        return sx;
+    };
+    const int dx0 = blockIdx.x * 64, dy0 = blockIdx.y * 4;
+    const int dx1 = min(dx0 + 63, dcols - 1), dy1 = min(dy0 + 3, drows - 1);
+    float t;
+    const int ey0 = clampi(src_y(dy0, t), 0, ur - 1), ey1 = clampi(src_y(dy1, t) + 1, 0, ur - 1);
+    const int ex0 = src_x(dx0, t), ex1 = min(src_x(dx1, t) + 1, uc - 1);
+    const int ner = ey1 - ey0 + 1, nec = ex1 - ex0 + 1;            // expanded samples the tile reads
+    // coarse rows the column taps of those samples read: reflect101(y + k - 2, ur) >> 1
+    int cr0 = fr, cr1 = -1;
+    for (int y = ey0 - 2; y <= ey1 + 2; y++) {
+        const int cr = reflect101(y, ur) >> 1;
+        cr0 = cr < cr0 ? cr : cr0;
+        cr1 = cr > cr1 ? cr : cr1;
+    }
+    const int ncr = cr1 - cr0 + 1;
+    // ner <= 4 * scale_y + 2 <= 10, nec <= 64 * scale_x + 3 <= 71, ncr <= (ner + 4) / 2 + 1 <= 8: the
+    // launcher admits only scales for which these bounds hold
+    for (int i = tid; i < ncr * nec; i += 256) {
+        const int ci = i / nec, j = i - ci * nec;
+        const float *srow = src + (size_t)(cr0 + ci) * fc;
+        float r = 0.f;
+#pragma unroll
+        for (int q = 0; q < 5; q++) r = fmaf(srow[reflect101(ex0 + j + q - 2, uc) >> 1], g5[q], r);
+        Rp[ci][j] = r;
+    }
+    __syncthreads();
+    for (int i = tid; i < ner * nec; i += 256) {
+        const int ei = i / nec, j = i - ei * nec;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc = fmaf(Rp[(reflect101(ey0 + ei + k - 2, ur) >> 1) - cr0][j], g5[k], acc);
+        Ex[ei][j] = acc * 2.f;
+    }
+    __syncthreads();
+    const int dx = dx0 + (tid & 63), dy = dy0 + (tid >> 6);
+    if (dx >= dcols || dy >= drows) return;
+    float fx, fy;
+    const int sx = src_x(dx, fx), sy = src_y(dy, fy);
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const int y0 = clampi(sy, 0, ur - 1) - ey0, y1 = clampi(sy + 1, 0, ur - 1) - ey0;
+    float h0, h1;
+    if (sx + 1 >= uc) {
+        h0 = Ex[y0][sx - ex0] * 1.f;
+        h1 = Ex[y1][sx - ex0] * 1.f;
+    } else {
+        h0 = Ex[y0][sx - ex0] * a0 + Ex[y0][sx + 1 - ex0] * a1;
+        h1 = Ex[y1][sx - ex0] * a0 + Ex[y1][sx + 1 - ex0] * a1;
+    }
+    dst[(size_t)dy * dcols + dx] = h0 * b0 + h1 * b1;
+}
+
 int launch_flow_expand_resize(hipStream_t s, const float *src_u, const float *src_v, int fr, int fc,
                               size_t src_pair, float *dst_u, float *dst_v, int drows, int dcols,
                               size_t dst_pair, int batch) {
     const double scale_x = 1. / ((double)dcols / (2 * fc));
     const double scale_y = 1. / ((double)drows / (2 * fr));
-    flow_expand_resize_kernel<<<dim3(cdiv(dcols, 64), cdiv(drows, 4), 2 * batch), 256, 0, s>>>(
-        src_u, src_v, fr, fc, src_pair, dst_u, dst_v, drows, dcols, dst_pair, scale_x, scale_y);
+    const dim3 grid(cdiv(dcols, 64), cdiv(drows, 4), 2 * batch);
+    // tile footprint: 64 output columns span <= 64 * scale + 2 source columns, 4 rows <= 4 * scale + 2
+    if (scale_x <= 1.05 && scale_y <= 2.0 && scale_x > 0 && scale_y > 0) {
+        flow_expand_resize_tiled_kernel<<<grid, 256, 0, s>>>(src_u, src_v, fr, fc, src_pair, dst_u, dst_v, drows,
+                                                             dcols, dst_pair, scale_x, scale_y);
+    } else {
+        flow_expand_resize_kernel<<<grid, 256, 0, s>>>(src_u, src_v, fr, fc, src_pair, dst_u, dst_v, drows, dcols,
+                                                       dst_pair, scale_x, scale_y);
+    }
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
@@ -326,6 +447,17 @@ int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, siz
         L[k].tiles_before[levels] = total;
     }
     if (total == 0) return MICV_OK;
+    const bool vec_ok = L[0].chain && !restricted && dst_a[0] == nullptr && (!dst_b || dst_b[0] == nullptr) &&
+                        (sstride & 3) == 0 && (img_elems & 3) == 0 && (cols & 3) == 0 && (L[0].cols[1] & 1) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(src_b)) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(dst_a[1]) & 7) == 0 && (!dst_b || (reinterpret_cast<uintptr_t>(dst_b[1]) & 7) == 0) &&
+                        (long)batch * (src_b ? 2 : 1) <= 65535;
+    if (vec_ok) {
+        pyr_build_vec_kernel<<<dim3(cdiv(L[0].cols[1], 128), cdiv(L[0].rows[1], 4), batch * (src_b ? 2 : 1)), 256, 0, s>>>(
+            src_a, src_b, img_elems, sstride, batch, L[0], L[1]);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     pyr_build_kernel<<<dim3(total, batch, src_b ? 2 : 1), 256, 0, s>>>(src_a, src_b, img_elems, sstride,
                                                                       L[0], L[1]);
     MICV_LAUNCH_CHECK();

@@ -431,3 +431,25 @@ def test_batch_wrapper_validates_its_buffers(mods):
     torch.cuda.synchronize()
     for (gu, gv), (eu, ev) in zip(res, exp):
         assert np.array_equal(host(gu[0]), eu) and np.array_equal(host(gv[0]), ev)
+
+
+@pytest.mark.parametrize("fr,fc,drows,dcols", [(67, 120, 135, 240), (67, 120, 135, 241), (33, 60, 67, 121), (5, 7, 11, 15),
+                                              (1, 1, 3, 3), (100, 37, 201, 75), (8, 300, 17, 600)])
+def test_level_on_odd_sizes_uses_the_resized_base_flow(mods, fr, fc, drows, dcols):
+    """OpticalFlow.cpp:139-151 for levels that are not twice the coarser one: 2 * pyrUp then cv::resize.
+    micv_lk_level_dev against the oracle composition (pyr_up -> resize_linear -> warp -> lk_flow), with
+    the tiled expand + resize kernel behind it; several pairs through the batch entry point too."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, shard, _capi
+    rng = np.random.default_rng(fr * 31 + dcols)
+    prev, nxt = synth.lk_pair(50 + fr, drows, dcols, 2, -1)
+    fu = (rng.standard_normal((fr, fc)) * 1.5).astype(np.float32)
+    fv = (rng.standard_normal((fr, fc)) * 1.5).astype(np.float32)
+    du = orc.resize_linear(2.0 * orc.pyr_up(fu), drows, dcols)
+    dv = orc.resize_linear(2.0 * orc.pyr_up(fv), drows, dcols)
+    ex, ey = orc.lk_flow(prev, orc.lk_warp(nxt, du, dv), 15)
+    eu, ev = du + ex, dv + ey
+    ctx = _capi.Context(0)
+    fn = shard.gpu_level_fn(ctx, 15)
+    gu, gv = fn(dev(prev), dev(nxt), dev(fu), dev(fv), 0, drows)
+    assert np.array_equal(host(gu), eu) and np.array_equal(host(gv), ev)
