@@ -246,7 +246,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     float *Wp = lds + RH * PS;
     float *X = lds + C::IMG_F;
     float *Xs = X + (CARRY ? C::CARRY_F : 0);     // staging area (behind the carried rows)
-    float *Cu = Xs, *Cv = Xs + CH * CW;
+    // coarse flow block, (u, v) interleaved: both fields go through pyrUp as the two lanes of packed f32 ops
+    v2f *Cuv = reinterpret_cast<v2f *>(Xs);
     float *Ru = Xs + CBF, *Rv = Ru + CH * RW;     // border tiles
     float *Nx = Xs + CBF;                         // interior tiles (aliases Ru/Rv)
     float *Gx = X, *Gy = X + GP, *Gt = X + 2 * GP;
@@ -349,8 +350,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             for (int k = 0; k < NC; k++) {
                 const int i = tid + k * NT;
                 if (i < CH * CW) {
-                    Cu[i] = rcu[k];
-                    Cv[i] = rcv[k];
+                    Cuv[i] = (v2f){rcu[k], rcv[k]};
                 }
             }
         }
@@ -360,8 +360,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             for (int k = 0; k < NC; k++) {
                 const int i = tid + k * NT;
                 if (i < CH * CW) {
-                    Cu[i] = rcu[k];
-                    Cv[i] = rcv[k];
+                    Cuv[i] = (v2f){rcu[k], rcv[k]};
                 }
             }
         }
@@ -411,28 +410,21 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // field, built from 3 coarse columns each, serve all 8 rows.
             auto march = [&](int lx, int ly0, float *bu8, float *bv8) {
                 const int gx = rx0 + lx, gy0 = ry0 + ly0;
-                float ru[RPT / 2 + 2], rv[RPT / 2 + 2];
+                v2f ruv[RPT / 2 + 2];  // row-pass values of both fields, (u, v) per coarse row
                 if (MODE == LK_FLOW_COARSE) {
                     const int cyb = ((gy0 >> 1) - 1) - cy0;
                     const int ccb = ((gx >> 1) - 1) - cx0;
                     const bool odd = gx & 1;
 #pragma unroll
                     for (int i = 0; i < RPT / 2 + 2; i++) {
-                        const float *cu = Cu + (cyb + i) * CW + ccb, *cv = Cv + (cyb + i) * CW + ccb;
-                        const float u0 = cu[0], u1 = cu[1], u2 = cu[2];
-                        const float v0 = cv[0], v1 = cv[1], v2 = cv[2];
-                        const float ua = odd ? u1 : u0, ub = odd ? u2 : u1;
-                        const float va = odd ? v1 : v0, vb = odd ? v2 : v1;
-                        float t = u0 * g5[0];
-                        t = fmaf(ua, g5[1], t);
-                        t = fmaf(u1, g5[2], t);
-                        t = fmaf(ub, g5[3], t);
-                        ru[i] = fmaf(u2, g5[4], t);
-                        t = v0 * g5[0];
-                        t = fmaf(va, g5[1], t);
-                        t = fmaf(v1, g5[2], t);
-                        t = fmaf(vb, g5[3], t);
-                        rv[i] = fmaf(v2, g5[4], t);
+                        const v2f *c = Cuv + (cyb + i) * CW + ccb;
+                        const v2f c0 = c[0], c1 = c[1], c2 = c[2];
+                        const v2f ca = odd ? c1 : c0, cb = odd ? c2 : c1;
+                        v2f t = c0 * (v2f){g5[0], g5[0]};
+                        t = __builtin_elementwise_fma(ca, (v2f){g5[1], g5[1]}, t);
+                        t = __builtin_elementwise_fma(c1, (v2f){g5[2], g5[2]}, t);
+                        t = __builtin_elementwise_fma(cb, (v2f){g5[3], g5[3]}, t);
+                        ruv[i] = __builtin_elementwise_fma(c2, (v2f){g5[4], g5[4]}, t);
                     }
                 }
                 // FULL mode reads the (already expanded + resized) base flow from global memory:
@@ -454,18 +446,14 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         float bu, bv;
                         if (MODE == LK_FLOW_COARSE) {
                             const int i1 = o ? p + 1 : p, i3 = o ? p + 2 : p + 1;
-                            float au = ru[p] * g5[0];
-                            au = fmaf(ru[i1], g5[1], au);
-                            au = fmaf(ru[p + 1], g5[2], au);
-                            au = fmaf(ru[i3], g5[3], au);
-                            au = fmaf(ru[p + 2], g5[4], au);
-                            float av = rv[p] * g5[0];
-                            av = fmaf(rv[i1], g5[1], av);
-                            av = fmaf(rv[p + 1], g5[2], av);
-                            av = fmaf(rv[i3], g5[3], av);
-                            av = fmaf(rv[p + 2], g5[4], av);
-                            bu = au * 2.f;  // OpticalFlow.cpp:142,144
-                            bv = av * 2.f;
+                            v2f auv = ruv[p] * (v2f){g5[0], g5[0]};
+                            auv = __builtin_elementwise_fma(ruv[i1], (v2f){g5[1], g5[1]}, auv);
+                            auv = __builtin_elementwise_fma(ruv[p + 1], (v2f){g5[2], g5[2]}, auv);
+                            auv = __builtin_elementwise_fma(ruv[i3], (v2f){g5[3], g5[3]}, auv);
+                            auv = __builtin_elementwise_fma(ruv[p + 2], (v2f){g5[4], g5[4]}, auv);
+                            auv = auv * (v2f){2.f, 2.f};  // OpticalFlow.cpp:142,144
+                            bu = auv.x;
+                            bv = auv.y;
                         } else {
                             bu = fu_[j];
                             bv = fv_[j];
@@ -516,8 +504,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
 #pragma unroll
                         for (int k = 0; k < 5; k++) {
                             const int sc = ((INT ? gx + k - 2 : reflect101(gx + k - 2, cols)) >> 1) - cx0;
-                            au = fmaf(Cu[cy * CW + sc], g5[k], au);
-                            av = fmaf(Cv[cy * CW + sc], g5[k], av);
+                            const v2f cuv = Cuv[cy * CW + sc];
+                            au = fmaf(cuv.x, g5[k], au);
+                            av = fmaf(cuv.y, g5[k], av);
                         }
                         Ru[i] = au;
                         Rv[i] = av;
