@@ -259,7 +259,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     if (CARRY) asm volatile("" : "+v"(tid_));
     const int tid = tid_;
     const int rows = a.rows, cols = a.cols;
-    const int x0 = tile_x * TW, y0 = tile_y * TH;
+    const int x0 = tile_x * TW, y0 = tile_y * TH + a.y_shift;  // y_shift: band launches tile from row_begin
     const int rx0 = x0 - H, ry0 = y0 - H;
     const float *__restrict__ prev = a.prev + pair * a.img_pair;
     const float *__restrict__ next = a.next + pair * a.img_pair;
@@ -790,7 +790,10 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
     {
         constexpr int FX = C::TW + C::H + E, FY = C::TH + C::H + E;
         int ix0 = (C::H + E + C::TW - 1) / C::TW, ix1 = a.cols >= FX ? (a.cols - FX) / C::TW + 1 : 0;
-        int iy0 = (C::H + E + C::TH - 1) / C::TH - ty_base, iy1 = (a.rows >= FY ? (a.rows - FY) / C::TH + 1 : 0) - ty_base;
+        // tile rows start at ty * TH + y_shift (band launches): interior <=> y_shift + ty*TH - H - E >= 0 and
+        // y_shift + ty*TH + FY <= rows
+        int iy0 = (C::H + E - a.y_shift + C::TH - 1) / C::TH - ty_base;
+        int iy1 = (a.rows >= FY + a.y_shift ? (a.rows - FY - a.y_shift) / C::TH + 1 : 0) - ty_base;
         ix1 = ix1 < tiles_x ? ix1 : tiles_x;
         iy0 = iy0 > 0 ? iy0 : 0;
         iy1 = iy1 < tiles_y ? iy1 : tiles_y;
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(NTV, THV == 16 ? 2 : NTV / 128) void lk_level_kerne
     constexpr int E = C::M > 2 ? C::M : 2;
     int tile_x, tile_y;
     lk_tile_of<C>(a, blockIdx.x, tile_x, tile_y);
-    const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
+    const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH + a.y_shift - C::H;
     // interior: tile + halo + the staged `next` margin (>= the pyrUp support) inside the image
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
@@ -1024,11 +1027,16 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             }
         }
     }
-    const int tile_rows = cdiv(a.row_end, C::TH) - a.row_begin / C::TH;
+    // Band launches (row-sharded execution) tile from row_begin, not from the multiple of TH below it: a
+    // 135-row band is 5 tile rows instead of 6.  pyrUp pairs fine rows (2m, 2m+1) per coarse row, so the
+    // modes with a base flow need an even origin (the row-shard plan's cuts are even on those levels).
+    LkLevelArgs b = a;
+    b.y_shift = (a.row_begin > 0 && (a.mode == LK_FLOW_NONE || (a.row_begin & 1) == 0)) ? a.row_begin % C::TH : 0;
+    const int tile_rows = b.y_shift ? cdiv(a.row_end - a.row_begin, C::TH) : cdiv(a.row_end, C::TH) - a.row_begin / C::TH;
     const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
     switch (a.mode) {
         case LK_FLOW_NONE:
-            lk_level_kernel<R, 0, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 0, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         case LK_FLOW_COARSE:
             if (a.rows != 2 * a.flow_rows || a.cols != 2 * a.flow_cols) {
@@ -1036,10 +1044,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
                           a.flow_cols, a.rows, a.cols);
                 return MICV_EINVAL;
             }
-            lk_level_kernel<R, 1, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 1, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         case LK_FLOW_FULL:
-            lk_level_kernel<R, 2, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps);
+            lk_level_kernel<R, 2, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         default:
             set_error("lk fused: bad mode %d", a.mode);

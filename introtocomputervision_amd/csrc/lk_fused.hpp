@@ -25,6 +25,7 @@ struct LkLevelArgs {
     int add_base;  // 1: out = base + flow (OpticalFlow.cpp:161-162); 0: out = flow (:100-101)
     // Output rows [row_begin, row_end) only (row-sharded execution); 0 / rows = everything.
     int row_begin = 0, row_end = 0;
+    int y_shift = 0;  // set by the launcher: tile rows start at tile_y * TH + y_shift (band launches)
     int narrow = 0;  // MICV_OPT_LK_NARROW_TILES: 256-thread form of the win-15 kernel
     // Tile chains (lk_fused.hip): ctx owns the cached schedules; max_chain = MICV_OPT_LK_CHAIN
     // (0 = automatic, 1 = off, n = longest chain).  Host side only.
