@@ -1,17 +1,19 @@
 // lk_fused.hip -- one pyramid level of Lucas-Kanade as ONE LDS-tiled kernel (gfx950).
 //
-// Per 64x32 output tile (256 threads = 4 wave64, 2 workgroups per CU by LDS):
-//   phase 0  stage in LDS: the prev tile (+R+1 halo), a window of `next` (tile + halo + 8 px
-//            margin) and the coarse flow block                     -- 16-byte coalesced loads
-//   phase 2  "marching" jobs (one column x 8 rows each): pyrUp of the coarse flow (row taps,
-//            column taps, x2 -- Pyramids.cu:126-127, OpticalFlow.cpp:142), then lk::warp of
-//            `next` with the 4 bilinear taps served from the LDS window (global fallback for
-//            flows that leave it)                                      -> warped tile in LDS
-//   phase 3  Sobel pairs of prev / warped with a 3-row register window, Ix Iy It -> LDS
+// Per 64x32 output tile (512 threads = 8 wave64 at window 15, 256 at the other windows; 79.5 KB of
+// LDS = 2 workgroups per CU; 64x16 tiles for launches of at most one tile per CU):
+//   phase 0  stage in LDS by LDS-DMA: the prev tile (+R+1 halo), a window of `next` (tile + halo +
+//            8 px margin); the coarse flow block goes in as (u, v) pairs
+//   phase 2  "marching" jobs (one column x 4 rows each): pyrUp of the coarse flow, both fields as
+//            the lanes of packed f32 ops (row taps, column taps, x2 -- Pyramids.cu:126-127,
+//            OpticalFlow.cpp:142), then lk::warp of `next` with the 4 bilinear taps served from the
+//            LDS window (global fallback for flows that leave it)        -> warped tile in LDS
+//   phase 3  Sobel pairs of prev / warped with a 3-row register window, two adjacent columns per
+//            job (packed f32), Ix Iy It -> LDS, the three planes interleaved by row
 //   phase 4  five Gaussian-weighted window sums in two sweeps (xx,xy,yy then xt,yt): products
 //            formed on the fly, separable (2R+1)-tap row pass (4 outputs per thread from
-//            ds_read_b128 windows) into XOR-swizzled LDS row buffers, column pass (8 outputs
-//            per thread) in registers
+//            ds_read_b128 windows, every FMA packed with skewed output pairs: row_taps_skew) into
+//            XOR-swizzled LDS row buffers, column pass (4 outputs per thread) in registers
 //   phase 5  2x2 solve in double, add the base flow, store du / dv
 // HBM traffic per level pixel: read prev (4 B) + next (4 B) + coarse flow (2 B), write du, dv
 // (8 B).  Nothing else leaves the CU.
@@ -20,6 +22,8 @@
 // phases 0-3 (reflect101 / bounds checks on every neighbour, separate pyrUp row-pass phase,
 // global gathers), then fill the out-of-image cells of the gradient planes by reflection so
 // that phase 4 is the same straight-line code for every tile.
+// Optional: lk_level_chain_kernel walks vertically adjacent tiles in one workgroup and carries the
+// last 2R gradient rows over in LDS (MICV_OPT_LK_CHAIN; measured in DESIGN.md section 5).
 // All arithmetic goes through lk_device.hpp / the fmaf chains below, identical to the
 // generic kernels in lk.hip and to the CPU oracle: every body produces the same bits.
 #include "lk_fused.hpp"
