@@ -253,6 +253,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= 0 && value <= 4, "micv_ctx_set_option: stream groups must be 0..4");
     if (option == MICV_OPT_STEREO_ROWS)
         MICV_REQUIRE(value == 0 || value == 8 || value == 10, "micv_ctx_set_option: stereo rows must be 0, 8 or 10");
+    if (option == MICV_OPT_LK_SHORT_TILES)
+        MICV_REQUIRE(value >= -1 && value <= (1 << 20), "micv_ctx_set_option: short-tile limit must be -1..2^20");
     if (option == MICV_OPT_LK_CHAIN)
         MICV_REQUIRE(value >= -1 && value <= 32, "micv_ctx_set_option: chain length must be -1..32");
     ctx->opt[option] = value;

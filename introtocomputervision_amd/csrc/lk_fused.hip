@@ -689,12 +689,17 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     float Sxx[RPT], Sxy[RPT], Syy[RPT], Sxt[RPT], Syt[RPT];
     constexpr int RPI = 4 * (NT / 64);  // gradient rows one row-pass iteration covers
     constexpr int SWEEP_UNROLL = NT >= 512 ? 1 : 4;  // 512 threads: rolled sweeps keep the 128-VGPR budget
+    // 64x16 tiles: one trip per sweep.  As straight-line code the scheduler overlaps the sweeps with the
+    // column passes around them and spills; a trip count the compiler cannot see (a.batch is never
+    // negative) keeps each sweep a rolled loop = its own scheduling region, as at 64x32.
+    constexpr int SWEEP_TRIPS = (GH + RPI - 1) / RPI;
+    const int sweep_trips = SWEEP_TRIPS == 1 ? 1 + (a.batch < 0 ? 1 : 0) : SWEEP_TRIPS;
     {
         const int lane = tid & 63, wave = tid >> 6;
         const int grp = lane >> 2, c0 = 4 * grp;
         // sweep A: Ix^2, Ix*Iy, Iy^2  (windows of Ix, Iy read once)
 #pragma unroll SWEEP_UNROLL
-        for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
+        for (int it = 0; it < sweep_trips; it++) {
             const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
                 v2f wx[2 * C::WV], wy[2 * C::WV];
@@ -722,7 +727,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         MICV_STOP(42)
         // sweep B: Ix*It, Iy*It
 #pragma unroll SWEEP_UNROLL
-        for (int it = 0; it < (GH + RPI - 1) / RPI; it++) {
+        for (int it = 0; it < sweep_trips; it++) {
             const int qy = it * RPI + wave * 4 + (lane & 3);
             if (qy < GH) {
                 v2f wx[2 * C::WV], wt[2 * C::WV];
@@ -838,10 +843,8 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
     }
 }
 
-// The 64x16 form serves launches of at most one workgroup per CU: it may use the whole register
-// file of its two waves per SIMD (no spills at 128+ VGPRs), occupancy is not what limits it.
 template <int R, int MODE, int NTV, int THV = 32>
-__global__ __launch_bounds__(NTV, THV == 16 ? 2 : NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
     using C = LkCfg<R, NTV, THV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int E = C::M > 2 ? C::M : 2;
@@ -1075,10 +1078,11 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             // Measured on MI355X (8 pairs of 1080p): 512 threads 0.377 ms per level-0 launch vs 0.406 ms,
             // and the latency-bound coarse levels gain more.  MICV_OPT_LK_NARROW_TILES selects the narrow form.
             if (a.narrow) return launch_r<7, 256>(s, a);
-            // a launch of at most one 64x16 tile per CU costs one tile's latency: half-height tiles shorten it
-            // (batch 1, 1080p: levels 2-4)
+            // a launch of at most one round of 64x16 tiles costs one tile's latency: half-height tiles shorten
+            // it (batch 1, 1080p: levels 1-4, 0.111 -> 0.096 ms per call)
             const long short_tiles = (long)cdiv(a.cols, 64) * (cdiv(a.row_end > 0 ? a.row_end : a.rows, 16)) * a.batch;
-            if (short_tiles <= 256 && a.short_tiles >= 0) return launch_r<7, 512, 16>(s, a);
+            const long short_limit = a.short_tiles > 0 ? a.short_tiles : 512;  // one round at two workgroups per CU
+            if (short_tiles <= short_limit && a.short_tiles >= 0) return launch_r<7, 512, 16>(s, a);
             return launch_r<7, 512>(s, a);
         }
         case 7: return launch_r<3, 256>(s, a);
