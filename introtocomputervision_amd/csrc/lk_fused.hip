@@ -313,9 +313,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     }
     const bool vec_ok = INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
-    // whole waves for the first tile of a chain / single tiles; carry tiles start mid-wave (the
-    // transfers of lanes beyond the range are masked off, the wave's LDS base stays uniform)
-    constexpr bool DMA_OK = CARRY || (((RH * (RW / 4)) % 64 == 0) && ((NH * (NW / 4)) % 64 == 0));
+    // 16-byte rows; the last wave of a transfer may be partial and carry tiles start mid-wave (lanes
+    // beyond the range are masked off, the wave's LDS base stays uniform)
+    constexpr bool DMA_OK = (RW % 4 == 0) && (NW % 4 == 0);
     if (INT && DMA_OK && vec_ok) {
         // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip
         // and no ds_write; every transfer of the tile is in flight at once.  The LDS images are
@@ -1085,9 +1085,9 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             if (short_tiles <= short_limit && a.short_tiles >= 0) return launch_r<7, 512, 16>(s, a);
             return launch_r<7, 512>(s, a);
         }
-        case 7: return launch_r<3, 256>(s, a);
+        case 7: return a.narrow ? launch_r<3, 256>(s, a) : launch_r<3, 512>(s, a);  // 512 threads: the staged / marching body
         case 21: return launch_r<10, 256>(s, a);  // the reference's default winSize (OpticalFlow.h:9,18)
-        case 11: return launch_r<5, 256>(s, a);
+        case 11: return a.narrow ? launch_r<5, 256>(s, a) : launch_r<5, 512, 16>(s, a);  // H = 6: marching needs 2-row jobs
         default:
             set_error("lk fused: window %d has no tiled instantiation", a.win);
             return MICV_EUNSUPPORTED;
