@@ -54,7 +54,9 @@ struct LkCfg {
     static constexpr int R = R_;
     static constexpr int W = 2 * R + 1;
     static constexpr int TW = 64, TH = TH_, NT = NT_;
-    static constexpr int H = R + 1;                         // image halo (Sobel + window)
+    // image halo: Sobel + window = R + 1, rounded up to a multiple of 4 so that region rows are whole
+    // 16-byte chunks (LDS-DMA) and the halo bands split into whole marching jobs at every window
+    static constexpr int H = (R + 1 + 3) & ~3;
     static constexpr int RW = TW + 2 * H, RH = TH + 2 * H;  // image region
     static constexpr int PS = RW;                           // LDS row stride of P / Wp
     static constexpr int GW = TW + 2 * R, GH = TH + 2 * R;  // gradient region
@@ -1086,8 +1088,10 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             return launch_r<7, 512>(s, a);
         }
         case 7: return a.narrow ? launch_r<3, 256>(s, a) : launch_r<3, 512>(s, a);  // 512 threads: the staged / marching body
-        case 21: return launch_r<10, 256>(s, a);  // the reference's default winSize (OpticalFlow.h:9,18)
-        case 11: return a.narrow ? launch_r<5, 256>(s, a) : launch_r<5, 512, 16>(s, a);  // H = 6: marching needs 2-row jobs
+        case 21:  // the reference's default winSize (OpticalFlow.h:9,18): halo 12, 64x16 tiles fit two workgroups per CU
+            // (64x32 tiles need 92 KB of LDS = one workgroup per CU: measured 17.6 Gpix/s against 18.6)
+            return a.narrow ? launch_r<10, 256>(s, a) : launch_r<10, 512, 16>(s, a);
+        case 11: return a.narrow ? launch_r<5, 256>(s, a) : launch_r<5, 512>(s, a);
         default:
             set_error("lk fused: window %d has no tiled instantiation", a.win);
             return MICV_EUNSUPPORTED;
