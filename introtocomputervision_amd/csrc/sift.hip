@@ -8,12 +8,13 @@
 // calcSIFTDescriptor algorithm (window rotated by the keypoint angle, bin width 3 * size / 2 px,
 // Gaussian weight, trilinear distribution, normalise -> clamp 0.2 -> renormalise to 512 -> 8 bits)
 // with fixed polynomial cos / sin / exp, cv::fastAtan2's polynomial, and a histogram accumulated in
-// 64-bit fixed point (2^-40 of the window's largest gradient magnitude) so that the result does
+// 64-bit fixed point (2^-40 of a bound on the window's gradient magnitudes) so that the result does
 // not depend on the order in which the samples arrive.
 //
 // One wave64 per keypoint, four keypoints per workgroup.  The window (107 x 107 samples for the
 // reference's size-10 keypoints) is swept twice by the wave's lanes with coalesced row reads
-// (second sweep served by L1/L2): sweep 1 finds the magnitude bound by a wave max-reduction, sweep
+// (second sweep served by L1/L2): sweep 1 finds the magnitude bound (a plain max of |gx|, |gy| over
+// the bounding square) by a wave max-reduction, sweep
 // 2 scatters the eight trilinear shares of every sample into the wave's LDS histogram with native
 // 64-bit LDS atomics.  The 128-term norms are summed left to right by one lane (the contract).
 #include <cfloat>
@@ -24,6 +25,15 @@ namespace micv {
 
 constexpr int SD = 4, SN = 8;
 constexpr int SHIST = (SD + 2) * (SD + 2) * (SN + 2);
+// Private copies of the histogram per wave, picked by the lane's column within its 8x8 block: lanes
+// that hit the same bin in the same instruction serialise in the LDS atomic unit (flat regions and
+// straight edges send a whole block to one bin), and COPIES copies divide that by COPIES.  Measured on
+// 5 035 keypoints of a 4K checkerboard: 1 copy 0.342 ms, 2 copies 0.294 ms, 4 copies 0.374 ms (LDS
+// then limits the waves per CU below what the keypoint list offers).
+#ifndef MICV_SIFT_COPIES
+#define MICV_SIFT_COPIES 2
+#endif
+constexpr int COPIES = MICV_SIFT_COPIES;
 
 // sin / cos of `deg` degrees: quadrant by float arithmetic, Taylor polynomials as fmaf chains.
 __device__ __forceinline__ void sincos_deg(float deg, float &s, float &c) {
@@ -122,56 +132,77 @@ __device__ __forceinline__ SiftGeom sift_geometry(const float *__restrict__ kp, 
     return g;
 }
 
-__device__ __forceinline__ bool sift_sample(const float *__restrict__ gx, const float *__restrict__ gy,
-                                            int gstride, int rows, int cols, const SiftGeom &g, int i, int j,
-                                            float &rbin, float &cbin, float &dx, float &dy, float &wexp) {
+// Window geometry of sample (i, j): rotated bin coordinates, the Gaussian exponent, and whether the
+// sample contributes at all (inside the 4x4 grid's reach and the image interior).
+__device__ __forceinline__ bool sift_test(int rows, int cols, const SiftGeom &g, int i, int j, float &rbin,
+                                          float &cbin, float &wexp) {
     const float c_rot = (float)j * g.cos_t - (float)i * g.sin_t;
     const float r_rot = (float)j * g.sin_t + (float)i * g.cos_t;
     rbin = r_rot + (float)(SD / 2) - 0.5f;
     cbin = c_rot + (float)(SD / 2) - 0.5f;
     const int r = g.py + i, c = g.px + j;
-    if (!(rbin > -1.f && rbin < (float)SD && cbin > -1.f && cbin < (float)SD && r > 0 && r < rows - 1 &&
-          c > 0 && c < cols - 1))
-        return false;
-    dx = gx[(size_t)r * gstride + c];
-    dy = -gy[(size_t)r * gstride + c];  // SIFT's dy is "up minus down"
     wexp = (c_rot * c_rot + r_rot * r_rot) * (-1.f / ((float)(SD * SD) * 0.5f));
-    return true;
+    return rbin > -1.f && rbin < (float)SD && cbin > -1.f && cbin < (float)SD && r > 0 && r < rows - 1 && c > 0 &&
+           c < cols - 1;
 }
 
+// Waves of one keypoint meet at a workgroup barrier; a keypoint that owns a single wave only needs
+// its own LDS traffic ordered.
+template <int WPK>
+__device__ __forceinline__ void keypoint_sync() {
+    if constexpr (WPK > 1) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// WPK waves per keypoint: 1 when there are enough keypoints to fill the chip (4 keypoints per
+// workgroup), 4 when there are few (one keypoint per workgroup, the window's blocks dealt round-robin
+// to the waves, each wave adding into its own histogram copies) -- a lone wave takes ~0.13 ms for a
+// 107x107 window, which is all the latency a small keypoint list would ever see.
+template <int WPK>
 __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__restrict__ gx,
                                                                const float *__restrict__ gy, int gstride,
                                                                int rows, int cols,
                                                                const float *__restrict__ kps, long long n,
                                                                float *__restrict__ desc, int dstride) {
-    __shared__ unsigned long long hist_all[4][SHIST];
-    __shared__ float dst_all[4][SD * SD * SN];
+    constexpr int G = 4 / WPK;  // keypoints per workgroup
+    constexpr int LEN = SD * SD * SN;
+    __shared__ unsigned long long hist_all[4][COPIES * SHIST];
+    __shared__ float dst_all[G][LEN];
+    __shared__ float bound_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long k = (long long)blockIdx.x * 4 + wave;
-    if (k >= n) return;  // whole waves leave; no workgroup barrier below
+    const int grp = wave / WPK, sub = wave - grp * WPK;
+    const long long k = (long long)blockIdx.x * G + grp;
+    if (k >= n) return;  // WPK 1: whole waves leave, no workgroup barrier below; WPK 4: never taken
     unsigned long long *hist = hist_all[wave];
-    float *dst = dst_all[wave];
+    float *dst = dst_all[grp];
     float *out = desc + (size_t)k * dstride;
     const SiftGeom g = sift_geometry(kps + 4 * k, rows, cols);
-    for (int t = lane; t < SHIST; t += 64) hist[t] = 0ull;
+    for (int t = lane; t < COPIES * SHIST; t += 64) hist[t] = 0ull;
     const int side = 2 * g.radius + 1;
     const long long total = g.valid ? (long long)side * side : 0;
 
-    // sweep 1: largest gradient magnitude among the contributing samples
+    // sweep 1: a bound on every contribution, 2 * max(|gx|, |gy|) over the window's bounding square
+    // inside the image interior (no rotation, no square root: ~8 instructions per sample)
     float bound = 0.f;
     {
-        int i = -g.radius, j = -g.radius + lane;
-        for (long long s = lane; s < total; s += 64) {
+        const int first = 64 * sub + lane;
+        int i = -g.radius + first / side, j = -g.radius + first % side;
+        for (long long s = first; s < total; s += 64 * WPK) {
             while (j > g.radius) {
                 j -= side;
                 i++;
             }
-            float rbin, cbin, dx, dy, w;
-            if (sift_sample(gx, gy, gstride, rows, cols, g, i, j, rbin, cbin, dx, dy, w)) {
-                const float mag = sqrtf(dx * dx + dy * dy);
-                bound = mag > bound ? mag : bound;  // NaN magnitudes never raise the bound
+            const int r = g.py + i, c = g.px + j;
+            if (r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
+                const float ax = fabsf(gx[(size_t)r * gstride + c]), ay = fabsf(gy[(size_t)r * gstride + c]);
+                const float m = ax > ay ? ax : ay;
+                bound = m > bound ? m : bound;  // NaN gradients never raise the bound
             }
-            j += 64;
+            j += 64 * WPK;
         }
     }
 #pragma unroll
@@ -179,40 +210,71 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
         const float other = __shfl_xor(bound, o, 64);
         bound = other > bound ? other : bound;
     }
+    if constexpr (WPK > 1) {
+        bound_all[wave] = bound;
+        __syncthreads();
+#pragma unroll
+        for (int w2 = 0; w2 < WPK; w2++) bound = bound_all[w2] > bound ? bound_all[w2] : bound;
+    }
+    bound = bound * 2.f;
     __builtin_amdgcn_wave_barrier();
     if (!(bound > 0.f) || !isfinite(bound)) {  // flat (or empty, or invalid) window: all-zero descriptor
-        for (int t = lane; t < SD * SD * SN; t += 64) out[t] = 0.f;
-        return;
+        for (int t = 64 * sub + lane; t < LEN; t += 64 * WPK) out[t] = 0.f;
+        return;  // the same decision in every wave of the keypoint
     }
     int e;
     (void)frexpf(bound, &e);  // bound < 2^e
     const int sh = 40 - e;
+    const double fx_scale = ldexp(1.0, sh);
 
     // sweep 2: eight trilinear shares per sample, fixed-point adds into the wave's histogram
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the zero fill above is ordered first
-    __builtin_amdgcn_wave_barrier();
+    // (the wave's zero fill of its own copies is ordered before its own atomics: same wave, in order)
+    // A lone wave is bound by the latency of its gradient loads (one dependent L2 / HBM round trip per
+    // sample would cost ~1 us each), so the samples go four at a time: the geometry tests and the
+    // eight unconditional loads of a batch first (rejected samples read element 0), the arithmetic
+    // and the LDS atomics after them.
+    // The wave visits the bounding square in 8x8-pixel blocks (the sums are order-independent): about
+    // half of the square lies outside the rotated window, and a block that is outside altogether is
+    // skipped by the whole wave (row-major runs of 64 almost always keep a few live lanes).
     {
-        int i = -g.radius, j = -g.radius + lane;
-        for (long long s = lane; s < total; s += 64) {
-            while (j > g.radius) {
-                j -= side;
-                i++;
+        constexpr int U = 4;
+        const int nb = (side + 7) >> 3;
+        const int nblk = g.valid ? nb * nb : 0;
+        const int ly = lane >> 3, lx = lane & 7;
+        for (int blk = sub * U; blk < nblk; blk += U * WPK) {
+            float rbin[U], cbin[U], dx[U], dy[U], w[U];
+            bool ok[U];
+            int bi = blk / nb, bj = blk - bi * nb;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = -g.radius + 8 * bi + ly, j = -g.radius + 8 * bj + lx;
+                ok[u] = blk + u < nblk && i <= g.radius && j <= g.radius &&
+                        sift_test(rows, cols, g, i, j, rbin[u], cbin[u], w[u]);
+                const size_t off = ok[u] ? (size_t)(g.py + i) * gstride + (g.px + j) : 0;
+                dx[u] = gx[off];
+                dy[u] = -gy[off];  // SIFT's dy is "up minus down"
+                if (++bj == nb) {
+                    bj = 0;
+                    bi++;
+                }
             }
-            float rbin, cbin, dx, dy, w;
-            if (sift_sample(gx, gy, gstride, rows, cols, g, i, j, rbin, cbin, dx, dy, w)) {
-                const float mag = sqrtf(dx * dx + dy * dy) * exp_neg(w);
-                float obin = (fast_atan2_deg(dy, dx) - g.ori) * ((float)SN / 360.f);
-                const float r0f = floorf(rbin), c0f = floorf(cbin), o0f = floorf(obin);
-                rbin -= r0f;
-                cbin -= c0f;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (!ok[u]) continue;
+                const float mag = sqrtf(dx[u] * dx[u] + dy[u] * dy[u]) * exp_neg(w[u]);
+                float obin = (fast_atan2_deg(dy[u], dx[u]) - g.ori) * ((float)SN / 360.f);
+                float rb = rbin[u], cb = cbin[u];
+                const float r0f = floorf(rb), c0f = floorf(cb), o0f = floorf(obin);
+                rb -= r0f;
+                cb -= c0f;
                 obin -= o0f;
                 const int r0 = (int)r0f, c0 = (int)c0f;
                 int o0 = (int)o0f;
                 if (o0 < 0) o0 += SN;
                 if (o0 >= SN) o0 -= SN;
-                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
-                const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                const float v_r1 = mag * rb, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cb, v_rc10 = v_r1 - v_rc11;
+                const float v_rc01 = v_r0 * cb, v_rc00 = v_r0 - v_rc01;
                 const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
                 const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
                 const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
@@ -220,8 +282,10 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
                 // NaN samples (a NaN gradient) have no defined bin: o0 is clamped so the adds stay inside
                 // the histogram; what they add is llrint(NaN), as on the host
                 o0 = o0 < 0 ? 0 : (o0 > SN - 1 ? SN - 1 : o0);
-                const int idx = ((r0 + 1) * (SD + 2) + c0 + 1) * (SN + 2) + o0;
-#define MICV_FX(v) ((unsigned long long)llrintf(ldexpf((v), sh)))
+                const int idx = ((r0 + 1) * (SD + 2) + c0 + 1) * (SN + 2) + o0 + (lane & (COPIES - 1)) * SHIST;
+                // llrintf(ldexpf(v, sh)) for 0 <= v * 2^sh < 2^41: one double fma onto 2^52 rounds to the
+                // nearest-even integer and leaves it in the low mantissa bits
+#define MICV_FX(v) ((unsigned long long)__double_as_longlong(fma((double)(v), fx_scale, 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull)
                 atomicAdd(&hist[idx], MICV_FX(v000));
                 atomicAdd(&hist[idx + 1], MICV_FX(v001));
                 atomicAdd(&hist[idx + (SN + 2)], MICV_FX(v010));
@@ -232,25 +296,26 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
                 atomicAdd(&hist[idx + (SD + 3) * (SN + 2) + 1], MICV_FX(v111));
 #undef MICV_FX
             }
-            j += 64;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    keypoint_sync<WPK>();
 
     // finalize: circular orientation axis, spatial border bins dropped, back to float
-    for (int t = lane; t < SD * SD * SN; t += 64) {
+    const unsigned long long *hist0 = hist_all[grp * WPK];  // the keypoint's WPK x COPIES copies are contiguous
+    for (int t = 64 * sub + lane; t < LEN; t += 64 * WPK) {
         const int cell = t / SN, o = t - cell * SN;
         const int ci = cell / SD, cj = cell - ci * SD;
         const int idx = ((ci + 1) * (SD + 2) + (cj + 1)) * (SN + 2);
-        long long h = (long long)hist[idx + o];
-        if (o < 2) h += (long long)hist[idx + SN + o];
+        long long h = 0;
+#pragma unroll
+        for (int cp = 0; cp < COPIES * WPK; cp++) {
+            h += (long long)hist0[cp * SHIST + idx + o];
+            if (o < 2) h += (long long)hist0[cp * SHIST + idx + SN + o];
+        }
         dst[t] = ldexpf((float)h, e - 40);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    keypoint_sync<WPK>();
     // the two 128-term norms, left to right in float (every lane computes them: uniform, no broadcast)
-    constexpr int LEN = SD * SD * SN;
     float nrm2 = 0.f;
     for (int t = 0; t < LEN; t++) nrm2 += dst[t] * dst[t];
     const float thr = sqrtf(nrm2) * 0.2f;  // SIFT_DESCR_MAG_THR
@@ -262,7 +327,7 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
     }
     const float nrm = sqrtf(nrm2);
     const float scale = 512.f / (nrm > FLT_EPSILON ? nrm : FLT_EPSILON);  // SIFT_INT_DESCR_FCTR
-    for (int t = lane; t < LEN; t += 64) {
+    for (int t = 64 * sub + lane; t < LEN; t += 64 * WPK) {
         const float d0 = dst[t];
         const float val = d0 < thr ? d0 : thr;
         const float v = rintf(val * scale);  // saturate_cast<uchar>
@@ -285,8 +350,13 @@ extern "C" int micv_sift_descriptors_dev(micv_ctx *ctx, const float *gx, const f
     MICV_REQUIRE(n < ((int64_t)1 << 31) * 4, "micv_sift_descriptors: too many keypoints");
     MICV_HIP(hipSetDevice(ctx->device));
     if (n == 0) return MICV_OK;
-    sift_descriptor_kernel<<<(unsigned)((n + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        gx, gy, (int)(gstride / 4), rows, cols, kp_xysa, (long long)n, desc, (int)(dstride / 4));
+    // fewer keypoints than two waves per SIMD: spend four waves on each
+    if (n < 2048)
+        sift_descriptor_kernel<4><<<(unsigned)n, 256, 0, static_cast<hipStream_t>(stream)>>>(
+            gx, gy, (int)(gstride / 4), rows, cols, kp_xysa, (long long)n, desc, (int)(dstride / 4));
+    else
+        sift_descriptor_kernel<1><<<(unsigned)((n + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(
+            gx, gy, (int)(gstride / 4), rows, cols, kp_xysa, (long long)n, desc, (int)(dstride / 4));
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }

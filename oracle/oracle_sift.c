@@ -18,8 +18,9 @@
  *   - cos / sin of the keypoint angle and exp() of the Gaussian weight are fixed polynomial
  *     evaluations written out below (fmaf chains), not libm calls;
  *   - orientation = cv::fastAtan2's published polynomial (degrees), unfused;
- *   - the histogram is accumulated in 64-bit fixed point relative to the largest gradient
- *     magnitude in the window (2^-40 of it), so the sum does not depend on the order of the samples;
+ *   - the histogram is accumulated in 64-bit fixed point at 2^-40 of a bound on the window's gradient
+ *     magnitudes (2 x the largest |gx| or |gy| in the window's bounding square), so the sum does
+ *     not depend on the order of the samples;
  *   - the two 128-term norms are summed left to right in float.
  */
 #include <float.h>
@@ -161,16 +162,19 @@ int orc_sift_descriptors(const float *gx, const float *gy, int rows, int cols, s
             continue;
         sift_geom g;
         sift_geometry(kp, rows, cols, &g);
-        /* pass 1: the largest gradient magnitude among the contributing samples fixes the scale of
-         * the fixed-point accumulators */
+        /* pass 1: a bound on every contribution fixes the scale of the fixed-point accumulators:
+         * mag = sqrt(dx^2 + dy^2) <= 2 max(|dx|, |dy|), maximised over the window's bounding square
+         * inside the image interior (a max: no order, no rotation, no square root) */
         float bound = 0.f;
         for (int i = -g.radius; i <= g.radius; i++)
             for (int j = -g.radius; j <= g.radius; j++) {
-                float rbin, cbin, dx, dy, w;
-                if (!sift_sample(gx, gy, rows, cols, stride, &g, i, j, &rbin, &cbin, &dx, &dy, &w)) continue;
-                const float mag = sqrtf(dx * dx + dy * dy);
-                if (mag > bound) bound = mag;
+                const int r = g.py + i, c = g.px + j;
+                if (!(r > 0 && r < rows - 1 && c > 0 && c < cols - 1)) continue;
+                const float ax = fabsf(AT(gx, stride, r, c)), ay = fabsf(AT(gy, stride, r, c));
+                const float m = ax > ay ? ax : ay;
+                if (m > bound) bound = m;
             }
+        bound = bound * 2.f;
         for (int t = 0; t < SIFT_D * SIFT_D * SIFT_N; t++) dst[t] = 0.f;
         if (!(bound > 0.f) || !isfinite(bound)) continue;  /* flat window: all-zero descriptor */
         int e;
