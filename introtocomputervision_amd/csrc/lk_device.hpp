@@ -47,33 +47,39 @@ __device__ __forceinline__ void lk_solve(float sxx, float sxy, float syy, float 
 template <int NW, int NH>
 __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N, int nx0, int ny0,
                                                     const float *__restrict__ src, int rows,
-                                                    int cols, int stride, int x, int y, float du,
+                                                    int cols, int stride, float xf, float yf, float du,
                                                     float dv) {
-    const float mx = (float)x + du, my = (float)y + dv;
+    // (xf, yf) = the pixel's coordinates already as floats (exact: the caller counts rows in float)
+    const float mx = xf + du, my = yf + dv;
     const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
     const int fx = sx & 31, fy = sy & 31;
-    const int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
-    const float ax1 = (float)fx * 0.03125f, ax0 = 1.f - ax1;
-    const float ay1 = (float)fy * 0.03125f, ay0 = 1.f - ay1;
+    const float ax1 = (float)fx * 0.03125f, ay1 = (float)fy * 0.03125f;
+    // weights as aligned pairs, so the four weight products and the four tap products are two packed
+    // multiplies each with a broadcast operand (the scalar form made the compiler shuffle halves)
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    const v2f_ X = {1.f - ax1, ax1}, Y = {1.f - ay1, ay1};
     float v0, v1, v2, v3;
-    const int lx = ix - nx0, ly = iy - ny0;
+    // the 16-bit clamp of cv::remap's integer map only matters outside the window: the window test
+    // runs on the unclamped cell (no wrap: |sx >> 5| < 2^26), the clamp moves into the fallback
+    const int lx = (sx >> 5) - nx0, ly = (sy >> 5) - ny0;
     if ((unsigned)lx < (unsigned)(NW - 1) && (unsigned)ly < (unsigned)(NH - 1)) {
-        // row offset by shifts where the window width allows (96 = 64 + 32: two full-rate ops instead
-        // of the quarter-rate v_mul_lo_u32 a plain `ly * NW` turns into)
-        int row_off;
-        if (NW == 96) {
-            int hi = ly << 6;
-            asm("" : "+v"(hi));  // keeps LLVM from folding the two shifts back into one multiply
-            row_off = hi + (ly << 5);
-        } else {
-            row_off = ly * NW;
-        }
-        const float *p = N + row_off + lx;
+        // cell index by one full-rate 24-bit multiply-add (a plain `ly * NW + lx` turns into the
+        // quarter-rate v_mul_lo_u32, and LLVM folds __mul24 and shift pairs back into it), and the
+        // address as ONE register the four taps hang off by immediate offsets (two ds_read2_b32;
+        // left alone, the compiler materialises a base per tap row)
+        typedef const __attribute__((address_space(3))) float lds_cfloat;
+        int cell;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cell) : "v"(ly), "s"(NW), "v"(lx));
+        int nbase = (int)(size_t)(lds_cfloat *)N;  // the window's LDS address, kept in a scalar register
+        asm("" : "+s"(nbase));
+        lds_cfloat *p = (lds_cfloat *)(size_t)(nbase + 4 * cell);
+        asm("" : "+v"(p));
         v0 = p[0];
         v1 = p[1];
         v2 = p[NW];
         v3 = p[NW + 1];
     } else {
+        const int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
         const bool x0 = (unsigned)ix < (unsigned)cols, x1 = (unsigned)(ix + 1) < (unsigned)cols;
         const bool y0 = (unsigned)iy < (unsigned)rows, y1 = (unsigned)(iy + 1) < (unsigned)rows;
         const float *p = src + (ptrdiff_t)iy * stride + ix;
@@ -82,10 +88,12 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
         v2 = (x0 && y1) ? p[stride] : 0.f;
         v3 = (x1 && y1) ? p[stride + 1] : 0.f;
     }
-    float r = v0 * (ay0 * ax0);
-    r = r + v1 * (ay0 * ax1);
-    r = r + v2 * (ay1 * ax0);
-    r = r + v3 * (ay1 * ax1);
+    // r = v0*(ay0*ax0) + v1*(ay0*ax1) + v2*(ay1*ax0) + v3*(ay1*ax1), summed left to right
+    const v2f_ w0 = (v2f_){Y.x, Y.x} * X, w1 = (v2f_){Y.y, Y.y} * X;
+    const v2f_ p0 = (v2f_){v0, v1} * w0, p1 = (v2f_){v2, v3} * w1;
+    float r = p0.x + p0.y;
+    r = r + p1.x;
+    r = r + p1.y;
     return r;
 }
 

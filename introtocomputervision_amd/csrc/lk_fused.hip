@@ -414,18 +414,28 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             // coarse columns {m-1,m-1,m,m,m+1} (gx = 2m) or {m-1,m,m,m+1,m+1} (gx = 2m+1); column
             // taps of rows 2m / 2m+1 read the same pattern of coarse rows: six row-pass values per
             // field, built from 3 coarse columns each, serve all 8 rows.
+            // origin of the staged window, as scalars (the compiler otherwise re-derives rx0 - M per pixel)
+            int nx0s = rx0 - M, ny0s = ry0 - M + LY0;
+            asm("" : "+s"(nx0s), "+s"(ny0s));
             auto march = [&](int lx, int ly0, float *bu8, float *bv8) {
                 const int gx = rx0 + lx, gy0 = ry0 + ly0;
+                const float xf = (float)gx, yf0 = (float)gy0;
+                // one address register for the job's four stores (rows at immediate offsets)
+                typedef __attribute__((address_space(3))) float lds_float;
+                lds_float *wrow = (lds_float *)(Wp + ly0 * PS + lx);
+                asm("" : "+v"(wrow));
                 v2f ruv[RPT / 2 + 2];  // row-pass values of both fields, (u, v) per coarse row
                 if (MODE == LK_FLOW_COARSE) {
                     const int cyb = ((gy0 >> 1) - 1) - cy0;
                     const int ccb = ((gx >> 1) - 1) - cx0;
-                    const bool odd = gx & 1;
+                    // taps 1 and 3 read coarse column (0 or 1) + parity: two more LDS reads off a
+                    // second base register instead of four v_cndmask per coarse row
+                    const int odd = gx & 1;
 #pragma unroll
                     for (int i = 0; i < RPT / 2 + 2; i++) {
                         const v2f *c = Cuv + (cyb + i) * CW + ccb;
                         const v2f c0 = c[0], c1 = c[1], c2 = c[2];
-                        const v2f ca = odd ? c1 : c0, cb = odd ? c2 : c1;
+                        const v2f ca = c[odd], cb = c[1 + odd];
                         v2f t = c0 * (v2f){g5[0], g5[0]};
                         t = __builtin_elementwise_fma(ca, (v2f){g5[1], g5[1]}, t);
                         t = __builtin_elementwise_fma(c1, (v2f){g5[2], g5[2]}, t);
@@ -469,8 +479,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         // warp right away: the flow pair's live range ends here.  Carry tiles need
                         // the warped image from region row LYC on (the base flow of every own row)
                         if (!CARRY || ly0 + j >= LY0)
-                            Wp[(ly0 + j) * PS + lx] = warp_sample_staged<NW, NH>(
-                                Nx, rx0 - M, ry0 - M + LY0, next, rows, cols, istride, gx, gy0 + j, bu, bv);
+                            wrow[j * PS] = warp_sample_staged<NW, NH>(
+                                Nx, nx0s, ny0s, next, rows, cols, istride, xf, yf0 + (float)j, bu, bv);
                         // 512-thread tiles run at a 128-VGPR budget: keep the rows from interleaving
                         if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
                     }
