@@ -322,32 +322,54 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip
         // and no ds_write; every transfer of the tile is in flight at once.  The LDS images are
         // dense (P: 80-float rows, window: 96-float rows), so element i of the tile lives at
-        // float4 slot i and one wave-instruction covers slots [i0, i0 + 64).
+        // float4 slot i and one wave-instruction covers slots [i0, i0 + 64), every lane busy.
+        // A thread's slots are NT apart: (row, float4) of the next one follows from the previous by
+        // constant steps and one carry, so only the first costs a divide and a 64-bit multiply
+        // (a flat index per transfer ran 139 VALU instructions per wave on addresses; whole rows
+        // per instruction need fewer still but 23 % more, partly empty, transfers: measured slower).
         constexpr int V = RW / 4, NP = ((RH - LY0) * V + NT - 1) / NT;
         constexpr int VN = NW / 4, NN = (NH * VN + NT - 1) / NT;
         const int lane = tid & 63;
+        const int slot0 = __builtin_amdgcn_readfirstlane(tid - lane);  // the wave's first slot of a pass
+        {
+            constexpr int A = NT / V, B = NT % V;  // slot + NT = (row + A, float4 + B), carry at V
+            int ly = tid / V, lv = tid - ly * V;   // carry tiles: region rows [LYC, RH) only
+            size_t goff = (size_t)(ry0 + LY0 + ly) * istride + rx0 + 4 * lv;
+            const size_t step = (size_t)A * istride + 4 * B, carry = (size_t)istride - 4 * V;
 #pragma unroll
-        for (int k = 0; k < NP; k++) {
-            const int i = LY0 * V + tid + k * NT;  // carry tiles: region rows [LYC, RH) only
-            if (i < RH * V) {
-                const int ly = i / V, lv = i - ly * V;
-                const size_t goff = (size_t)(ry0 + ly) * istride + rx0 + 4 * lv;
-                __builtin_amdgcn_global_load_lds((glb_cvoid *)(prev + goff), (lds_void *)(P + 4 * (i - lane)),
-                                                 16, 0, 0);
-                if (MODE == LK_FLOW_NONE)
-                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(next + goff),
-                                                     (lds_void *)(Wp + 4 * (i - lane)), 16, 0, 0);
+            for (int k = 0; k < NP; k++) {
+                if (k == NP - 1 ? (ly < RH - LY0) : true) {
+                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(prev + goff),
+                                                     (lds_void *)(P + 4 * (LY0 * V + slot0 + k * NT)), 16, 0, 0);
+                    if (MODE == LK_FLOW_NONE)
+                        __builtin_amdgcn_global_load_lds((glb_cvoid *)(next + goff),
+                                                         (lds_void *)(Wp + 4 * (LY0 * V + slot0 + k * NT)), 16, 0, 0);
+                }
+                if (k + 1 < NP) {
+                    lv += B;
+                    const bool c = lv >= V;
+                    lv -= c ? V : 0;
+                    ly += A + (c ? 1 : 0);
+                    goff += step + (c ? carry : 0);
+                }
             }
         }
         if (STAGED) {
+            constexpr int A = NT / VN, B = NT % VN;
+            int ly = tid / VN, lv = tid - ly * VN;
+            size_t goff = (size_t)(ry0 - M + LY0 + ly) * istride + rx0 - M + 4 * lv;
+            const size_t step = (size_t)A * istride + 4 * B, carry = (size_t)istride - 4 * VN;
 #pragma unroll
             for (int k = 0; k < NN; k++) {
-                const int i = tid + k * NT;
-                if (i < NH * VN) {
-                    const int ly = i / VN, lv = i - ly * VN;
-                    __builtin_amdgcn_global_load_lds(
-                        (glb_cvoid *)(next + (size_t)(ry0 - M + LY0 + ly) * istride + rx0 - M + 4 * lv),
-                        (lds_void *)(Nx + 4 * (i - lane)), 16, 0, 0);
+                if (k == NN - 1 ? (ly < NH) : true)
+                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(next + goff),
+                                                     (lds_void *)(Nx + 4 * (slot0 + k * NT)), 16, 0, 0);
+                if (k + 1 < NN) {
+                    lv += B;
+                    const bool c = lv >= VN;
+                    lv -= c ? VN : 0;
+                    ly += A + (c ? 1 : 0);
+                    goff += step + (c ? carry : 0);
                 }
             }
         }
