@@ -119,6 +119,8 @@ def parse_args(argv=None):
                          "passes of tools/profile.sh use 1 so a level-0 dispatch covers the whole batch")
     ap.add_argument("--lk-chain", type=int, default=0,
                     help="MICV_OPT_LK_CHAIN of every context: 0 = the library's rule, 1 = no tile chains, n = longest chain")
+    ap.add_argument("--preroll-s", type=float, default=0.25,
+                    help="seconds of untimed steps before the warm-up steps (clock pre-roll; 0 = none)")
     ap.add_argument("--sustained-s", type=float, default=2.0,
                     help="seconds of back-to-back steps for the `sustained` field (0 = skip)")
     ap.add_argument("--mode", choices=["pairs", "rowshard"], default="pairs",
@@ -320,6 +322,16 @@ def main(argv=None):
         return max_and_all(time.perf_counter() - t0, dev)
 
     ctx.warmup(stream)
+    # Pre-roll (untimed, before the W warm-up steps): the first ~30 ms of work after the device has
+    # idled run ~15 % slower (power state ramp; measured 43 vs 50 Gpix/s at W=5, K=20), and W steps are
+    # only W x 0.35 ms.  A quarter second of the same steps puts the timed window at sustained clocks,
+    # which is what `sustained` (two seconds of steps) reports independently.
+    if args.preroll_s > 0:
+        t_end = time.perf_counter() + args.preroll_s
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     dt, per_rank = timed(args.steps)
@@ -455,6 +467,7 @@ def main(argv=None):
                 "parity_1080p": None if parity is None else parity["bit_exact"],
                 "parity_1080p_detail": parity,
                 "passes_in_flight": max(1, args.inflight) if args.mode == "pairs" else 1,
+                "preroll_s": args.preroll_s,
                 "one_pass_at_a_time_ms_per_step": serial_ms,
                 "single_pair_ms": single_pair_ms,
                 "single_pair_Mpix_s": None if not single_pair_ms else ROWS * COLS / single_pair_ms / 1e3,
