@@ -28,16 +28,37 @@ __device__ __forceinline__ float avg2(float a, float b) { return a * 0.5f + b * 
 
 // OpticalFlow.cpp:85-103 with cv::determinant / cv::solve(DECOMP_LU) 2x2 CV_32F: double
 // det2, threshold tau = 0.1, Cramer with d = 1/det in double, results cast to float.
+//
+// Instruction count matters here (f64 issues at 1.85 ns per wave-instruction, ~14 % of the level
+// kernel's VALU time went to this function), so two identities are used, both exact:
+//  * a product of two floats is exact in double (48-bit significand), hence a*b - c*d rounds once
+//    whether it is written mul, mul, sub or mul, fma;
+//  * the correctly rounded 1/det is computed by the same rcp + Newton + residual-correction chain
+//    the compiler emits for a division, minus its v_div_scale / v_div_fmas / v_div_fixup wrapping:
+//    that wrapping only acts on operands near the ends of the exponent range, and det here lies in
+//    [0.1, 2^256) (or is NaN, which the chain propagates like the division does).
+__device__ __forceinline__ double lk_exact_diff(float a, float b, float c, float d) {
+    return fma((double)a, (double)b, -((double)c * (double)d));  // == a*b - c*d in double
+}
+__device__ __forceinline__ double lk_rcp_normal(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);  // residual of the quotient 1 * r
+    return fma(e, r, r);
+}
 __device__ __forceinline__ void lk_solve(float sxx, float sxy, float syy, float sxt, float syt,
                                          float &u, float &v) {
-    const double det = (double)sxx * (double)syy - (double)sxy * (double)sxy;
+    const double det = lk_exact_diff(sxx, syy, sxy, sxy);
     u = 0.f;
     v = 0.f;
     if (!(det < 0.1) && det != 0.) {
-        const double d = 1. / det;
+        const double d = lk_rcp_normal(det);
         const float b0 = -sxt, b1 = -syt;
-        u = (float)(((double)b0 * (double)syy - (double)b1 * (double)sxy) * d);
-        v = (float)(((double)b1 * (double)sxx - (double)b0 * (double)sxy) * d);
+        u = (float)(lk_exact_diff(b0, syy, b1, sxy) * d);
+        v = (float)(lk_exact_diff(b1, sxx, b0, sxy) * d);
     }
 }
 
