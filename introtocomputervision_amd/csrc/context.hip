@@ -209,11 +209,28 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (auto &b : ctx->io_cache) (void)hipFree(b.p);
     for (auto &e : ctx->lk_sched) (void)hipFree(e.dev);
+    if (ctx->lk_tickets) (void)hipFree(ctx->lk_tickets);
     for (void *t : ctx->trig_tables)
         if (t) (void)hipFree(t);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
+}
+
+int micv_ctx::lk_ticket_slot(unsigned **out) {
+    constexpr int kSlots = 16, kWords = 16;
+    if (!lk_tickets) {
+        void *p = nullptr;
+        MICV_HIP(hipMalloc(&p, kSlots * kWords * sizeof(unsigned)));
+        hipError_t e = hipMemset(p, 0, kSlots * kWords * sizeof(unsigned));
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            MICV_HIP(e);
+        }
+        lk_tickets = static_cast<unsigned *>(p);
+    }
+    *out = lk_tickets + (size_t)(lk_ticket_rr++ % kSlots) * kWords;
+    return MICV_OK;
 }
 
 size_t micv_ctx_scratch_bytes(const micv_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
@@ -257,6 +274,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= -1 && value <= (1 << 20), "micv_ctx_set_option: short-tile limit must be -1..2^20");
     if (option == MICV_OPT_LK_CHAIN)
         MICV_REQUIRE(value >= -1 && value <= 32, "micv_ctx_set_option: chain length must be -1..32");
+    if (option == MICV_OPT_LK_STREAM)
+        MICV_REQUIRE(value >= 0 && value <= 1, "micv_ctx_set_option: streamed launch must be 0 or 1");
     ctx->opt[option] = value;
     return MICV_OK;
 }

@@ -174,6 +174,7 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.ctx = ctx;
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
+        a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
         bool out_in_cur = false;
         if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
         if (level == 0) {
@@ -412,6 +413,7 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
         a.ctx = ctx;
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
+        a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
         return launch_lk_level_fused(s, a);
     }
     void *scratch;
@@ -462,6 +464,7 @@ int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next,
         a.ctx = ctx;
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
+        a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
         a.flow_pair = 0;
         if (!flow_u) {
             a.mode = LK_FLOW_NONE;

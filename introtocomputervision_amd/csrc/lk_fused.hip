@@ -77,6 +77,8 @@ struct LkCfg {
     static constexpr int ROWBUF_F = 3 * GH * RBS;
     static constexpr int IMG_F = (2 * RH * PS > ROWBUF_F ? 2 * RH * PS : ROWBUF_F);
     static constexpr int C_F = (2 * CH * CW + 3) & ~3;         // coarse block, both fields, 16-B padded
+    // streamed tiles: rows of u and v interleaved, each padded to whole float4s (dma_coarse)
+    static constexpr int CWP = (CW + 3) & ~3, CS_F = 2 * CH * CWP;
     static constexpr int FLOW_F = C_F + 2 * CH * RW;           // border tiles: C + R
     static constexpr int STAGE_F = C_F + NW * NH;              // interior tiles: C + next window
     static constexpr int GRAD_F = GH * GS;
@@ -233,20 +235,117 @@ __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S
 // tile above left them there), phases 0-3 cover region rows [LYC, RH) only.  MORE: another tile of
 // the chain follows -- the last QC gradient rows are moved to the front of the gradient area once
 // the row passes are done with them.
-template <int R, int MODE, bool INT, int NTV, bool CARRY = false, int THV = 32>
+// LDS-DMA of a dense block: `nrows` rows of 4 * V4 floats, global row pitch `istride`, into a dense
+// LDS image at `dst` (global_load_lds_dwordx4: 16 B per lane straight into LDS, no VGPR round trip,
+// no ds_write; every transfer in flight at once).  Element i of the block lives at float4 slot i and
+// one wave-instruction covers slots [i0, i0 + 64), every lane busy.  A thread's slots are NT apart:
+// (row, float4) of the next one follows from the previous by constant steps and one carry, so only
+// the first costs a divide and a 64-bit multiply (a flat index per transfer ran 139 VALU instructions
+// per wave on addresses; whole rows per instruction need fewer still but 23 % more, partly empty,
+// transfers: measured slower).  `src` points at the block's first element; rows must be 16-B aligned.
+template <int NT, int V4, int NROWS>
+__device__ __forceinline__ void dma_rows(const float *__restrict__ src, int istride, float *dst, int tid) {
+    constexpr int NP = (NROWS * V4 + NT - 1) / NT, A = NT / V4, B = NT % V4;  // slot + NT = (row + A, float4 + B)
+    const int lane = tid & 63;
+    const int slot0 = __builtin_amdgcn_readfirstlane(tid - lane);  // the wave's first slot of a pass
+    int ly = tid / V4, lv = tid - ly * V4;
+    size_t goff = (size_t)ly * istride + 4 * lv;
+    const size_t step = (size_t)A * istride + 4 * B, carry = (size_t)istride - 4 * V4;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        if (k == NP - 1 ? (ly < NROWS) : true)
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(src + goff), (lds_void *)(dst + 4 * (slot0 + k * NT)), 16,
+                                             0, 0);
+        if (k + 1 < NP) {
+            lv += B;
+            const bool c = lv >= V4;
+            lv -= c ? V4 : 0;
+            ly += A + (c ? 1 : 0);
+            goff += step + (c ? carry : 0);
+        }
+    }
+}
+
+// Streamed tiles (lk_level_stream_kernel): the coarse flow block goes in by LDS-DMA too.  LDS layout:
+// [u row | v row] per coarse row, CWP = CW rounded up to whole float4s each, so that pyrUp reads a
+// (u, v) pair with one ds_read2_b32; a wave-instruction moves as many consecutive half-rows as fit
+// in 64 lanes (16 B per lane, 11 transfers per tile; one dword transfer per half-row, 54 per tile,
+// measured the same).  Interior tiles only: every row and column of the block lies inside the coarse
+// image (no clamping); rows start at any 4-byte address, which the 16-byte DMA accepts.
+template <typename C>
+__device__ __forceinline__ void dma_coarse(const LkLevelArgs &a, int pair, int cx0, int cy0, float *Cf, int tid) {
+    constexpr int Q = C::CWP / 4, HPI = 64 / Q, HALF_ROWS = 2 * C::CH, NI = (HALF_ROWS + HPI - 1) / HPI;
+    constexpr int NWV = C::NT / 64;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hl = lane / Q, q = lane - hl * Q;  // half-row within the instruction, float4 within the half-row
+    const int fc = a.flow_cols;
+    const float *__restrict__ fu = a.flow_u + pair * a.flow_pair + (size_t)cy0 * fc + cx0 + 4 * q;
+    const float *__restrict__ fv = a.flow_v + pair * a.flow_pair + (size_t)cy0 * fc + cx0 + 4 * q;
+#pragma unroll
+    for (int k = 0; k < (NI + NWV - 1) / NWV; k++) {
+        const int it = wave + NWV * k;
+        const int hr = it * HPI + hl;  // half-row: coarse row hr / 2, field hr % 2
+        if (it < NI && hl < HPI && hr < HALF_ROWS)
+            __builtin_amdgcn_global_load_lds((glb_cvoid *)(((hr & 1) ? fv : fu) + (size_t)(hr >> 1) * fc),
+                                             (lds_void *)(Cf + it * HPI * C::CWP), 16, 0, 0);
+    }
+}
+
+// What a streamed tile hands back to the loop that runs it: the entry it took the next ticket for,
+// and whether that tile's `next` window and coarse block are already on their way into LDS.
+struct LkStreamLink {
+    const int4 *sched;  // per-XCD lists, entry t of XCD x at sched[8 * t + x]
+    int per_xcd, xcd;
+    unsigned *counter;  // this XCD's ticket counter
+    int *slot;          // LDS word the ticket travels through
+    int4 next;          // .z == 0: none
+    bool next_staged;
+    // The tile's results stay in registers until the barrier that ends it has passed: a store issued
+    // before that barrier would have to be acknowledged by memory before the workgroup may go on (the
+    // barrier waits for every outstanding vector-memory operation, stores included).
+    float ou[8], ov[8];
+};
+
+template <typename C>
+__device__ __forceinline__ bool lk_tile_interior(const LkLevelArgs &a, int tile_x, int tile_y) {
+    constexpr int E = C::M > 2 ? C::M : 2;
+    const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
+    return rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 && ry0 + C::RH + E <= a.rows;
+}
+
+// The `next` window and the coarse block of an interior tile, by LDS-DMA into the staging area
+// (what phase 0 stages besides the prev tile); no wait, no barrier.
+template <typename C>
+__device__ __forceinline__ void lk_stage_ahead(const LkLevelArgs &a, float *lds, int tile_x, int tile_y, int pair,
+                                               int tid) {
+    float *Xs = lds + C::IMG_F;
+    const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH - C::H;
+    const int cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1, cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
+    dma_coarse<C>(a, pair, cx0, cy0, Xs, tid);
+    const float *next = a.next + pair * a.img_pair;
+    dma_rows<C::NT, C::NW / 4, C::NH>(next + (size_t)(ry0 - C::M) * a.img_stride + rx0 - C::M, a.img_stride,
+                                      Xs + C::CS_F, tid);
+}
+
+template <int R, int MODE, bool INT, int NTV, bool CARRY = false, int THV = 32, bool STREAM = false,
+          bool IN_LOOP = CARRY || STREAM>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
-                                        float *lds, int tile_x, int tile_y, int pair, bool more = false) {
+                                        float *lds, int tile_x, int tile_y, int pair, bool more = false,
+                                        LkStreamLink *link = nullptr) {
     using C = LkCfg<R, NTV, THV>;
     constexpr int RPT = C::RPT;
     constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
     constexpr int GW = C::GW, GH = C::GH, GS = C::GS, GP = C::GP, CW = C::CW, NT = C::NT;
     constexpr int M = C::M, NW = C::NW;
     static_assert(!CARRY || (INT && C::FAST && MODE == LK_FLOW_COARSE && C::CHAIN_OK), "carry tiles: interior, coarse flow");
+    static_assert(!STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY && C::RW % 4 == 0 && C::NW % 4 == 0),
+                  "streamed tiles: interior, coarse flow, LDS-DMA staging");
+    static_assert(!STREAM || C::CS_F + C::NW * C::NH <= C::X_F, "streamed tiles: staging fits the gradient area");
     constexpr int LY0 = CARRY ? C::LYC : 0;            // first region row this tile stages / warps
     constexpr int Q0 = CARRY ? C::QC : 0;              // first gradient row this tile computes
     constexpr int CH = CARRY ? C::CHC : C::CH;         // coarse block rows
     constexpr int NH = CARRY ? C::NHC : C::NH;         // `next` window rows
-    constexpr int CBF = CARRY ? C::CC_F : C::C_F;      // floats of the coarse block (both fields)
+    constexpr int CBF = STREAM ? C::CS_F : (CARRY ? C::CC_F : C::C_F);  // floats of the coarse block (both fields)
     constexpr bool STAGED = INT && C::FAST && MODE != LK_FLOW_NONE;  // next window in LDS
     float *P = lds;
     float *Wp = lds + RH * PS;
@@ -259,10 +358,11 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     float *Gx = X, *Gy = X + GP, *Gt = X + 2 * GP;
     float *rb0 = lds, *rb1 = lds + GH * C::RBS, *rb2 = lds + 2 * GH * C::RBS;  // alias P / Wp
 
-    // Carry tiles run inside the chain loop: an opaque copy of the thread index keeps the compiler
-    // from hoisting every lane-derived address out of that loop (which costs ~70 spilled VGPRs).
+    // Tiles that run inside a loop (chains, the streamed launch): an opaque copy of the thread index
+    // keeps the compiler from hoisting every lane-derived address out of that loop (which costs ~70
+    // spilled VGPRs).
     int tid_ = threadIdx.x;
-    if (CARRY) asm volatile("" : "+v"(tid_));
+    if (IN_LOOP) asm volatile("" : "+v"(tid_));
     const int tid = tid_;
     const int rows = a.rows, cols = a.cols;
     const int x0 = tile_x * TW, y0 = tile_y * TH + a.y_shift;  // y_shift: band launches tile from row_begin
@@ -293,9 +393,13 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     // Interior tiles issue ALL their global loads into registers first and write LDS afterwards,
     // so the loads overlap each other (a load -> ds_write loop would serialise on every wait).
     int cx0 = 0, cy0 = 0;
-    constexpr int NC = (CH * CW + NT - 1) / NT;
+    constexpr int NC = STREAM ? 1 : (CH * CW + NT - 1) / NT;
     float rcu[NC], rcv[NC];
-    if (MODE == LK_FLOW_COARSE) {
+    if (STREAM) {
+        // the coarse block and the `next` window were staged ahead (lk_stage_ahead), a barrier ago
+        cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
+        cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
+    } else if (MODE == LK_FLOW_COARSE) {
         const float *__restrict__ fu = a.flow_u + pair * a.flow_pair;
         const float *__restrict__ fv = a.flow_v + pair * a.flow_pair;
         const int fr = a.flow_rows, fc = a.flow_cols;
@@ -313,67 +417,22 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             rcv[k] = fv[(size_t)yy * fc + xx];
         }
     }
-    const bool vec_ok = INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
+    // (the host launches streamed tiles only when this holds)
+    const bool vec_ok = STREAM || (INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
+                                   ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0);
     // 16-byte rows; the last wave of a transfer may be partial and carry tiles start mid-wave (lanes
     // beyond the range are masked off, the wave's LDS base stays uniform)
     constexpr bool DMA_OK = (RW % 4 == 0) && (NW % 4 == 0);
     if (INT && DMA_OK && vec_ok) {
-        // LDS-DMA (global_load_lds_dwordx4): 16 B per lane straight into LDS, no VGPR round trip
-        // and no ds_write; every transfer of the tile is in flight at once.  The LDS images are
-        // dense (P: 80-float rows, window: 96-float rows), so element i of the tile lives at
-        // float4 slot i and one wave-instruction covers slots [i0, i0 + 64), every lane busy.
-        // A thread's slots are NT apart: (row, float4) of the next one follows from the previous by
-        // constant steps and one carry, so only the first costs a divide and a 64-bit multiply
-        // (a flat index per transfer ran 139 VALU instructions per wave on addresses; whole rows
-        // per instruction need fewer still but 23 % more, partly empty, transfers: measured slower).
-        constexpr int V = RW / 4, NP = ((RH - LY0) * V + NT - 1) / NT;
-        constexpr int VN = NW / 4, NN = (NH * VN + NT - 1) / NT;
-        const int lane = tid & 63;
-        const int slot0 = __builtin_amdgcn_readfirstlane(tid - lane);  // the wave's first slot of a pass
-        {
-            constexpr int A = NT / V, B = NT % V;  // slot + NT = (row + A, float4 + B), carry at V
-            int ly = tid / V, lv = tid - ly * V;   // carry tiles: region rows [LYC, RH) only
-            size_t goff = (size_t)(ry0 + LY0 + ly) * istride + rx0 + 4 * lv;
-            const size_t step = (size_t)A * istride + 4 * B, carry = (size_t)istride - 4 * V;
-#pragma unroll
-            for (int k = 0; k < NP; k++) {
-                if (k == NP - 1 ? (ly < RH - LY0) : true) {
-                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(prev + goff),
-                                                     (lds_void *)(P + 4 * (LY0 * V + slot0 + k * NT)), 16, 0, 0);
-                    if (MODE == LK_FLOW_NONE)
-                        __builtin_amdgcn_global_load_lds((glb_cvoid *)(next + goff),
-                                                         (lds_void *)(Wp + 4 * (LY0 * V + slot0 + k * NT)), 16, 0, 0);
-                }
-                if (k + 1 < NP) {
-                    lv += B;
-                    const bool c = lv >= V;
-                    lv -= c ? V : 0;
-                    ly += A + (c ? 1 : 0);
-                    goff += step + (c ? carry : 0);
-                }
-            }
-        }
-        if (STAGED) {
-            constexpr int A = NT / VN, B = NT % VN;
-            int ly = tid / VN, lv = tid - ly * VN;
-            size_t goff = (size_t)(ry0 - M + LY0 + ly) * istride + rx0 - M + 4 * lv;
-            const size_t step = (size_t)A * istride + 4 * B, carry = (size_t)istride - 4 * VN;
-#pragma unroll
-            for (int k = 0; k < NN; k++) {
-                if (k == NN - 1 ? (ly < NH) : true)
-                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(next + goff),
-                                                     (lds_void *)(Nx + 4 * (slot0 + k * NT)), 16, 0, 0);
-                if (k + 1 < NN) {
-                    lv += B;
-                    const bool c = lv >= VN;
-                    lv -= c ? VN : 0;
-                    ly += A + (c ? 1 : 0);
-                    goff += step + (c ? carry : 0);
-                }
-            }
-        }
-        if (MODE == LK_FLOW_COARSE) {
+        // LDS-DMA (dma_rows): the LDS images are dense (P: 80-float rows, window: 96-float rows); carry
+        // tiles stage region rows [LYC, RH) only
+        constexpr int V = RW / 4;
+        dma_rows<NT, V, RH - LY0>(prev + (size_t)(ry0 + LY0) * istride + rx0, istride, P + LY0 * RW, tid);
+        if (MODE == LK_FLOW_NONE)
+            dma_rows<NT, V, RH - LY0>(next + (size_t)(ry0 + LY0) * istride + rx0, istride, Wp + LY0 * RW, tid);
+        if (STAGED && !STREAM)
+            dma_rows<NT, NW / 4, NH>(next + (size_t)(ry0 - M + LY0) * istride + rx0 - M, istride, Nx, tid);
+        if (MODE == LK_FLOW_COARSE && !STREAM) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 const int i = tid + k * NT;
@@ -425,7 +484,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     float base_u[RPT], base_v[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; j++) base_u[j] = base_v[j] = 0.f;
-    if (MODE != LK_FLOW_NONE) __syncthreads();
+    // streamed tiles: what phase 2 reads was staged before the previous barrier, and the prev tile's
+    // DMA (issued just now) is only needed by phase 3, a barrier further on
+    if (MODE != LK_FLOW_NONE && !STREAM) __syncthreads();
     MICV_STAMP(0)
 
     if (MODE != LK_FLOW_NONE) {
@@ -455,9 +516,24 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     const int odd = gx & 1;
 #pragma unroll
                     for (int i = 0; i < RPT / 2 + 2; i++) {
-                        const v2f *c = Cuv + (cyb + i) * CW + ccb;
-                        const v2f c0 = c[0], c1 = c[1], c2 = c[2];
-                        const v2f ca = c[odd], cb = c[1 + odd];
+                        v2f c0, c1, c2, ca, cb;
+                        if (STREAM) {
+                            // rows of u and v interleaved (dma_coarse): a pair = one ds_read2_b32
+                            constexpr int CWP = C::CWP;
+                            const float *c = Xs + (cyb + i) * (2 * CWP) + ccb;
+                            c0 = (v2f){c[0], c[CWP]};
+                            c1 = (v2f){c[1], c[CWP + 1]};
+                            c2 = (v2f){c[2], c[CWP + 2]};
+                            ca = (v2f){c[odd], c[CWP + odd]};
+                            cb = (v2f){c[1 + odd], c[CWP + 1 + odd]};
+                        } else {
+                            const v2f *c = Cuv + (cyb + i) * CW + ccb;
+                            c0 = c[0];
+                            c1 = c[1];
+                            c2 = c[2];
+                            ca = c[odd];
+                            cb = c[1 + odd];
+                        }
                         v2f t = c0 * (v2f){g5[0], g5[0]};
                         t = __builtin_elementwise_fma(ca, (v2f){g5[1], g5[1]}, t);
                         t = __builtin_elementwise_fma(c1, (v2f){g5[2], g5[2]}, t);
@@ -597,6 +673,10 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     }
     __syncthreads();
     MICV_STAMP(2)
+    // streamed tiles: one thread takes the ticket of the tile that follows; the answer is needed after
+    // sweep B's row pass and travels through LDS two barriers before that
+    int ticket = 0;
+    if (STREAM && tid == 0) ticket = (int)atomicAdd(link->counter, 1u);
 
     // ---- phase 3: gradients --------------------------------------------------------------
     {
@@ -754,6 +834,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 row_taps_skew<C>(wy, wy, g, rb2 + o);
             }
         }
+        if (STREAM && tid == 0) *link->slot = ticket;
         __syncthreads();
         MICV_STOP(41)
         col_pass<C>(rb0, Sxx, g, c, r0);
@@ -782,6 +863,21 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         }
         __syncthreads();
         MICV_STOP(43)
+        if constexpr (STREAM) {
+            // the gradient planes are dead: the next tile's `next` window and coarse block go in over
+            // them while this tile runs its last column passes and the solve
+            const int t = __builtin_amdgcn_readfirstlane(*link->slot);
+            link->next = make_int4(0, 0, 0, 0);
+            link->next_staged = false;
+            if (t < link->per_xcd) {
+                const int4 e2 = link->sched[8 * t + link->xcd];
+                link->next = e2;
+                if (e2.z > 0 && lk_tile_interior<C>(a, e2.x, e2.y)) {
+                    lk_stage_ahead<C>(a, lds, e2.x, e2.y, e2.w, tid);
+                    link->next_staged = true;
+                }
+            }
+        }
         if (INT && C::CHAIN_OK && MODE == LK_FLOW_COARSE && more) {
             // the row passes are done with the gradient planes: hand the last QC rows (all three
             // planes, one contiguous block) to the next tile of the chain as its first QC rows
@@ -809,8 +905,13 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     uu = base_u[j] + uu;
                     vv = base_v[j] + vv;
                 }
-                ou[(size_t)gy * a.out_stride + gx] = uu;
-                ov[(size_t)gy * a.out_stride + gx] = vv;
+                if constexpr (STREAM) {
+                    link->ou[j] = uu;
+                    link->ov[j] = vv;
+                } else {
+                    ou[(size_t)gy * a.out_stride + gx] = uu;
+                    ov[(size_t)gy * a.out_stride + gx] = vv;
+                }
             }
         }
     }
@@ -924,6 +1025,85 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_chain_kernel(LkLevelA
     }
 }
 
+// Streamed launch: a persistent grid (two workgroups per CU) whose workgroups take tiles off their
+// XCD's list by ticket (the schedule of the chain launch with single tiles: every pair's border
+// tiles first, then contiguous runs of interior tiles per XCD).  An interior tile's staging is
+// taken off its critical path: its `next` window and coarse block are DMA'd into the gradient area
+// of the tile BEFORE it while that one runs its last column passes and the solve, and its prev tile
+// is DMA'd at its own start but not awaited until the warp phase is over (in-kernel stamps of the
+// plain launch: a tile spends 32 % of its life waiting for phase 0).  tickets[0..7] = per-XCD
+// counters, tickets[8] = workgroups that have left; the last one out zeroes them for the next launch.
+template <int R, int NTV>
+__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_stream_kernel(LkLevelArgs a, TapsN<2 * R + 1> g,
+                                                                         const int4 *__restrict__ sched, int per_xcd,
+                                                                         unsigned *__restrict__ tickets) {
+    using C = LkCfg<R, NTV>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int slot;
+    const int tid = threadIdx.x;
+    LkStreamLink link;
+    link.sched = sched;
+    link.per_xcd = per_xcd;
+    link.xcd = blockIdx.x & 7;
+    link.counter = tickets + link.xcd;
+    link.slot = &slot;
+    link.next = make_int4(0, 0, 0, 0);
+    link.next_staged = false;
+    if (tid == 0) slot = (int)atomicAdd(link.counter, 1u);
+    __syncthreads();
+    int t = __builtin_amdgcn_readfirstlane(slot);
+    int4 e = t < per_xcd ? sched[8 * t + link.xcd] : make_int4(0, 0, 0, 0);
+    bool staged = false;
+    int4 pending = make_int4(0, 0, 0, 0);  // the streamed tile whose results are still in registers
+    auto flush = [&]() {
+        if (pending.z > 0) {
+            float *__restrict__ ou = a.out_u + pending.w * a.out_pair;
+            float *__restrict__ ov = a.out_v + pending.w * a.out_pair;
+            const int gx = pending.x * C::TW + (tid & (C::TW - 1));
+            const int gy0 = pending.y * C::TH + C::RPT * (tid / C::TW);
+#pragma unroll
+            for (int j = 0; j < C::RPT; j++) {
+                ou[(size_t)(gy0 + j) * a.out_stride + gx] = link.ou[j];
+                ov[(size_t)(gy0 + j) * a.out_stride + gx] = link.ov[j];
+            }
+            pending.z = 0;
+        }
+    };
+    while (e.z > 0) {  // a padding entry ends the list
+        if (lk_tile_interior<C>(a, e.x, e.y)) {
+            if (!staged) {  // the first tile, or the one after a border tile
+                lk_stage_ahead<C>(a, lds, e.x, e.y, e.w, tid);
+                __syncthreads();
+            }
+            flush();  // the previous tile's stores ride behind this tile's first phases
+            lk_tile<R, LK_FLOW_COARSE, true, NTV, false, 32, true>(a, g, lds, e.x, e.y, e.w, false, &link);
+            pending = e;
+            e = link.next;
+            staged = link.next_staged;
+        } else {
+            flush();
+            int tk = 0;
+            if (tid == 0) tk = (int)atomicAdd(link.counter, 1u);
+            lk_tile<R, LK_FLOW_COARSE, false, NTV, false, 32, false, true>(a, g, lds, e.x, e.y, e.w);
+            if (tid == 0) slot = tk;
+            __syncthreads();
+            t = __builtin_amdgcn_readfirstlane(slot);
+            e = t < per_xcd ? sched[8 * t + link.xcd] : make_int4(0, 0, 0, 0);
+            staged = false;
+        }
+        __syncthreads();  // the tile is done with the row buffers; what was staged ahead has landed
+    }
+    flush();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(tickets + 8, 1u) == gridDim.x - 1) {
+            for (int x = 0; x < 8; x++) tickets[x] = 0;
+            tickets[8] = 0;
+            __threadfence();
+        }
+    }
+}
+
 // Host: the chain schedule of one level launch.  Interior tiles of every column are cut into chains
 // of decreasing length (max_chain first, halving towards the bottom of the column), border tiles
 // stay single.  Order of issue = expected duration, longest first (list scheduling: the short items
@@ -980,6 +1160,35 @@ static void build_chain_schedule(int rows, int cols, int batch, int max_chain, s
 
 bool lk_fused_supports(int win) { return win == 15 || win == 7 || win == 21 || win == 11; }
 
+// The cached device copy of a launch shape's schedule (built on first use).
+template <typename C>
+static int get_schedule(const LkLevelArgs &a, int max_chain, const int4 **sched, int *nblocks) {
+    for (auto &e : a.ctx->lk_sched)
+        if (e.rows == a.rows && e.cols == a.cols && e.batch == a.batch && e.r == C::R && e.max_chain == max_chain) {
+            *sched = static_cast<const int4 *>(e.dev);
+            *nblocks = e.nblocks;
+            return MICV_OK;
+        }
+    std::vector<int4> host;
+    build_chain_schedule<C>(a.rows, a.cols, a.batch, max_chain, &host);
+    void *dev = nullptr;
+    MICV_HIP(hipMalloc(&dev, host.size() * sizeof(int4)));
+    hipError_t ce = hipMemcpy(dev, host.data(), host.size() * sizeof(int4), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) {
+        (void)hipFree(dev);
+        MICV_HIP(ce);
+    }
+    if (a.ctx->lk_sched.size() >= 32) {  // shapes keep changing: start over
+        MICV_HIP(hipDeviceSynchronize());  // a launch in flight may still read one of them
+        for (auto &e : a.ctx->lk_sched) (void)hipFree(e.dev);
+        a.ctx->lk_sched.clear();
+    }
+    a.ctx->lk_sched.push_back({a.rows, a.cols, a.batch, C::R, max_chain, dev, (int)host.size()});
+    *sched = static_cast<const int4 *>(dev);
+    *nblocks = (int)host.size();
+    return MICV_OK;
+}
+
 template <int R, int NTV, int THV = 32>
 static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     using C = LkCfg<R, NTV, THV>;
@@ -1012,6 +1221,41 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         set_error("lk fused: bad row band [%d, %d) for %d rows", a.row_begin, a.row_end, a.rows);
         return MICV_EINVAL;
     }
+    if constexpr (C::FAST && C::RW % 4 == 0 && C::NW % 4 == 0 && THV == 32 && NTV == 512) {
+        // Streamed launch (MICV_OPT_LK_STREAM = 1; off by default): whole frames with a coarse flow whose
+        // images the LDS-DMA can address (16-byte rows).  Measured on MI355X (8 x 1080p, tools/stream_bench.py,
+        // one box): level-0 launch 0.244 ms against 0.220 ms for the plain grid -- the loop's staging
+        // address arithmetic costs 11 % more VALU instructions (109.5 M against 98.4 M) and hiding the
+        // staging latency buys nothing back: with two workgroups per CU the other workgroup already
+        // covers it.  Kept as an option (bit-exact, tested), not a default.
+        const long tiles = (long)cdiv(a.cols, C::TW) * cdiv(a.rows, C::TH) * a.batch;
+        const bool dma_ok = (a.img_stride & 3) == 0 && (a.img_pair & 3) == 0 &&
+                            ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
+        if (a.mode == LK_FLOW_COARSE && a.ctx && a.stream_tiles > 0 &&
+            a.max_chain <= 1 && a.max_chain >= 0 && dma_ok && a.row_begin == 0 && a.row_end == a.rows &&
+            a.rows == 2 * a.flow_rows && a.cols == 2 * a.flow_cols && a.stamps == nullptr && a.stop_after < 0) {
+            const int4 *sched = nullptr;
+            int nblocks = 0;
+            MICV_TRY(get_schedule<C>(a, 1, &sched, &nblocks));
+            unsigned *tickets = nullptr;
+            MICV_TRY(a.ctx->lk_ticket_slot(&tickets));
+            static thread_local int stream_dev = -1;
+            static thread_local int n_cu = 0;
+            int dev = 0;
+            MICV_HIP(hipGetDevice(&dev));
+            if (stream_dev != dev) {
+                MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_stream_kernel<R, NTV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+                MICV_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+                stream_dev = dev;
+            }
+            long want = 2L * n_cu < tiles ? 2L * n_cu : tiles;
+            const int grid = (int)((want + 7) / 8) * 8;
+            lk_level_stream_kernel<R, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps, sched, nblocks / 8, tickets);
+            MICV_LAUNCH_CHECK();
+            return MICV_OK;
+        }
+    }
     if constexpr (C::CHAIN_OK) {
         if (a.mode == LK_FLOW_COARSE && a.ctx && a.max_chain != 1 && a.row_begin == 0 && a.row_end == a.rows &&
             a.rows == 2 * a.flow_rows && a.cols == 2 * a.flow_cols) {
@@ -1034,29 +1278,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             if (max_chain > 1 || sched_only) {
                 const int4 *sched = nullptr;
                 int nblocks = 0;
-                for (auto &e : a.ctx->lk_sched)
-                    if (e.rows == a.rows && e.cols == a.cols && e.batch == a.batch && e.r == R && e.max_chain == max_chain) {
-                        sched = static_cast<const int4 *>(e.dev);
-                        nblocks = e.nblocks;
-                    }
-                if (!sched) {
-                    std::vector<int4> host;
-                    build_chain_schedule<C>(a.rows, a.cols, a.batch, max_chain, &host);
-                    void *dev = nullptr;
-                    MICV_HIP(hipMalloc(&dev, host.size() * sizeof(int4)));
-                    hipError_t ce = hipMemcpy(dev, host.data(), host.size() * sizeof(int4), hipMemcpyHostToDevice);
-                    if (ce != hipSuccess) {
-                        (void)hipFree(dev);
-                        MICV_HIP(ce);
-                    }
-                    if (a.ctx->lk_sched.size() >= 32) {  // shapes keep changing: start over
-                        for (auto &e : a.ctx->lk_sched) (void)hipFree(e.dev);
-                        a.ctx->lk_sched.clear();
-                    }
-                    a.ctx->lk_sched.push_back({a.rows, a.cols, a.batch, R, max_chain, dev, (int)host.size()});
-                    sched = static_cast<const int4 *>(dev);
-                    nblocks = (int)host.size();
-                }
+                MICV_TRY(get_schedule<C>(a, max_chain, &sched, &nblocks));
                 {
                     static thread_local int chain_dev = -1;
                     int dev = 0;

@@ -373,6 +373,36 @@ def test_tile_chains_are_bit_exact(mods, rows, cols, levels, batch, max_chain):
     assert torch.equal(su, u) and torch.equal(sv, v)
 
 
+@pytest.mark.parametrize("rows,cols,levels,batch,win", [(270, 480, 2, 1, 15), (540, 960, 3, 2, 15), (1080, 1920, 5, 1, 15),
+                                                        (330, 700, 3, 3, 15), (200, 210, 2, 1, 15), (97, 400, 2, 2, 15),
+                                                        (540, 960, 3, 9, 15), (300, 520, 3, 2, 7), (300, 520, 2, 3, 11)])
+def test_streamed_launch_is_bit_exact(mods, rows, cols, levels, batch, win):
+    """The streamed level launch (persistent workgroups take tiles by ticket; an interior tile's `next`
+    window and coarse block are staged during the tile before it): MICV_OPT_LK_STREAM = 1 (off by
+    default: measured slower than the plain grid).  Same bits as the plain launch and as the oracle, call
+    after call (the launch resets its own ticket counters)."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(9000 + i + rows, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_STREAM, 1)
+    u = torch.full((batch, rows, cols), float("nan"), device="cuda")
+    v = torch.full((batch, rows, cols), float("nan"), device="cuda")
+    for rep in range(20):  # more calls than ticket slots: every slot is reused
+        u.fill_(float("nan")); v.fill_(float("nan"))
+        lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), win, levels, ctx=ctx, out=(u, v))
+        if rep in (0, 1, 19):
+            for i in range(batch if rep == 0 else 1):
+                eu, ev = orc.lk_flow_pyr(prev[i], nxt[i], win, levels)
+                assert np.array_equal(host(u[i]), eu) and np.array_equal(host(v[i]), ev), (rep, i)
+    ctx.set_option(_capi.OPT_LK_STREAM, 0)
+    su, sv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), win, levels, ctx=ctx)
+    assert torch.equal(su, u) and torch.equal(sv, v)
+    with pytest.raises(Exception):
+        ctx.set_option(_capi.OPT_LK_STREAM, 2)
+
+
 @pytest.mark.parametrize("rows,cols,levels,batch", [(270, 480, 3, 1), (135, 240, 2, 8), (67, 120, 1, 3), (1080, 1920, 5, 1), (100, 333, 3, 2)])
 def test_short_tiles_are_bit_exact(mods, rows, cols, levels, batch):
     """Launches of at most one 64x16 tile per CU run the half-height form of the win-15 level kernel
