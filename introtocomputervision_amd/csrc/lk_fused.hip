@@ -231,10 +231,6 @@ __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S
 
 // ---- the tile body ---------------------------------------------------------------------------
 
-// CARRY: this tile is not the first of its chain -- gradient rows [0, QC) are already in LDS (the
-// tile above left them there), phases 0-3 cover region rows [LYC, RH) only.  MORE: another tile of
-// the chain follows -- the last QC gradient rows are moved to the front of the gradient area once
-// the row passes are done with them.
 // LDS-DMA of a dense block: `nrows` rows of 4 * V4 floats, global row pitch `istride`, into a dense
 // LDS image at `dst` (global_load_lds_dwordx4: 16 B per lane straight into LDS, no VGPR round trip,
 // no ds_write; every transfer in flight at once).  Element i of the block lives at float4 slot i and
@@ -327,6 +323,11 @@ __device__ __forceinline__ void lk_stage_ahead(const LkLevelArgs &a, float *lds,
                                       Xs + C::CS_F, tid);
 }
 
+// CARRY: this tile is not the first of its chain -- gradient rows [0, QC) are already in LDS (the
+// tile above left them there), phases 0-3 cover region rows [LYC, RH) only.  MORE: another tile of
+// the chain follows -- the last QC gradient rows are moved to the front of the gradient area once
+// the row passes are done with them.
+// STREAM: the tile runs in lk_level_stream_kernel's loop (its window and coarse block were staged ahead).
 template <int R, int MODE, bool INT, int NTV, bool CARRY = false, int THV = 32, bool STREAM = false,
           bool IN_LOOP = CARRY || STREAM>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
@@ -340,12 +341,16 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     static_assert(!CARRY || (INT && C::FAST && MODE == LK_FLOW_COARSE && C::CHAIN_OK), "carry tiles: interior, coarse flow");
     static_assert(!STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY && C::RW % 4 == 0 && C::NW % 4 == 0),
                   "streamed tiles: interior, coarse flow, LDS-DMA staging");
-    static_assert(!STREAM || C::CS_F + C::NW * C::NH <= C::X_F, "streamed tiles: staging fits the gradient area");
+    static_assert(!(STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY)) || C::CS_F + C::NW * C::NH <= C::X_F,
+                  "interior tiles: DMA-staged coarse block + next window fit the gradient area");
     constexpr int LY0 = CARRY ? C::LYC : 0;            // first region row this tile stages / warps
     constexpr int Q0 = CARRY ? C::QC : 0;              // first gradient row this tile computes
     constexpr int CH = CARRY ? C::CHC : C::CH;         // coarse block rows
     constexpr int NH = CARRY ? C::NHC : C::NH;         // `next` window rows
-    constexpr int CBF = STREAM ? C::CS_F : (CARRY ? C::CC_F : C::C_F);  // floats of the coarse block (both fields)
+    // interior tiles take the coarse block by LDS-DMA, rows of u and v interleaved (dma_coarse): no
+    // registers, no ds_write, no per-element index arithmetic (carry tiles keep the (u, v)-pair layout)
+    constexpr bool CDMA = STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY);
+    constexpr int CBF = CDMA ? C::CS_F : (CARRY ? C::CC_F : C::C_F);  // floats of the coarse block (both fields)
     constexpr bool STAGED = INT && C::FAST && MODE != LK_FLOW_NONE;  // next window in LDS
     float *P = lds;
     float *Wp = lds + RH * PS;
@@ -393,12 +398,14 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     // Interior tiles issue ALL their global loads into registers first and write LDS afterwards,
     // so the loads overlap each other (a load -> ds_write loop would serialise on every wait).
     int cx0 = 0, cy0 = 0;
-    constexpr int NC = STREAM ? 1 : (CH * CW + NT - 1) / NT;
+    constexpr int NC = CDMA ? 1 : (CH * CW + NT - 1) / NT;
     float rcu[NC], rcv[NC];
-    if (STREAM) {
-        // the coarse block and the `next` window were staged ahead (lk_stage_ahead), a barrier ago
+    if (CDMA) {
+        // streamed tiles: the coarse block and the `next` window were staged ahead (lk_stage_ahead), a
+        // barrier ago
         cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
         cy0 = (ry0 - 2 > 0 ? ry0 - 2 : 0) >> 1;
+        if (!STREAM) dma_coarse<C>(a, pair, cx0, cy0, Xs, tid);
     } else if (MODE == LK_FLOW_COARSE) {
         const float *__restrict__ fu = a.flow_u + pair * a.flow_pair;
         const float *__restrict__ fv = a.flow_v + pair * a.flow_pair;
@@ -432,7 +439,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             dma_rows<NT, V, RH - LY0>(next + (size_t)(ry0 + LY0) * istride + rx0, istride, Wp + LY0 * RW, tid);
         if (STAGED && !STREAM)
             dma_rows<NT, NW / 4, NH>(next + (size_t)(ry0 - M + LY0) * istride + rx0 - M, istride, Nx, tid);
-        if (MODE == LK_FLOW_COARSE && !STREAM) {
+        if (MODE == LK_FLOW_COARSE && !CDMA) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 const int i = tid + k * NT;
@@ -442,7 +449,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             }
         }
     } else {
-        if (MODE == LK_FLOW_COARSE) {
+        if (MODE == LK_FLOW_COARSE && !CDMA) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
                 const int i = tid + k * NT;
@@ -517,7 +524,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
 #pragma unroll
                     for (int i = 0; i < RPT / 2 + 2; i++) {
                         v2f c0, c1, c2, ca, cb;
-                        if (STREAM) {
+                        if (CDMA) {
                             // rows of u and v interleaved (dma_coarse): a pair = one ds_read2_b32
                             constexpr int CWP = C::CWP;
                             const float *c = Xs + (cyb + i) * (2 * CWP) + ccb;
