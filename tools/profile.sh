@@ -13,6 +13,11 @@ BENCH=(python3 "$repo/bench.py" --cpu-pairs 0)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- \
     "${BENCH[@]}" --steps 20 --warmup 5 --sustained-s 0 > "$out/bench_trace.log" 2>&1
 echo "trace rc=$?"
+# The same steps one pass at a time in one stream group: the level-0 launch alone on the GPU, the
+# duration bench.py's roofline line is about (with two passes in flight the traced launches overlap).
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_alone" -- \
+    "${BENCH[@]}" --steps 20 --warmup 5 --sustained-s 0 --inflight 1 --lk-groups 1 --no-profile-pass > "$out/bench_trace_alone.log" 2>&1
+echo "trace_alone rc=$?"
 
 # PMC passes: one stream group (--lk-groups 1), so each level-0 dispatch covers the whole batch (the
 # launch the roofline line of bench.py is about); counters serialise dispatches anyway.

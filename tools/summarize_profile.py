@@ -34,24 +34,29 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
             float(r["AverageNs"]) / 1e3, r["Percentage"]))
     res["kernel_stats"] = rows[:16]
 
-dur = defaultdict(list)
-for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "Grid_Size_X" in r:  # total work-items = X * Y * Z (batch index is grid.y)
-            g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-        else:
-            g = int(r.get("Grid_Size", 0) or 0)
-        dur[(short(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-if dur:
-    print("== mean duration per (kernel, grid threads)")
-    res["durations_us"] = {}
-    for (k, g), v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-        if "micv" not in k:
-            continue
-        v2 = v[len(v) // 4:]  # drop warm-up quarter
-        m = sum(v2) / len(v2) / 1e3
-        res["durations_us"][f"{k}|{g}"] = {"mean_us": m, "n": len(v2)}
-        print(f"  {k:48s} grid={g:>9d} n={len(v2):4d} mean_us={m:10.2f}")
+# "trace": bench.py as the driver runs it (two passes in flight: traced launches overlap each other);
+# "trace_alone": the same steps one pass at a time, one stream group -- the level-0 launch alone on the
+# GPU, the duration bench.py's roofline line quotes.
+for sub, key, title in (("trace", "durations_us", "two passes in flight"),
+                        ("trace_alone", "durations_alone_us", "one pass at a time: launches alone on the GPU")):
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(out, sub, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "Grid_Size_X" in r:  # total work-items = X * Y * Z (batch index is grid.y)
+                g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            else:
+                g = int(r.get("Grid_Size", 0) or 0)
+            dur[(short(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if dur:
+        print(f"== mean duration per (kernel, grid threads), {title}")
+        res[key] = {}
+        for (k, g), v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            if "micv" not in k:
+                continue
+            v2 = v[len(v) // 4:]  # drop warm-up quarter
+            m = sum(v2) / len(v2) / 1e3
+            res[key][f"{k}|{g}"] = {"mean_us": m, "n": len(v2)}
+            print(f"  {k:48s} grid={g:>9d} n={len(v2):4d} mean_us={m:10.2f}")
 
 pmc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
