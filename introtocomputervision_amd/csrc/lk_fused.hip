@@ -262,6 +262,38 @@ __device__ __forceinline__ void dma_rows(const float *__restrict__ src, int istr
     }
 }
 
+// The same block for a border tile: its top-left element is image pixel (gx0, gy0), possibly outside the
+// rows x cols image `img`.  16-byte chunks inside the image go by LDS-DMA; chunks outside it are
+// zero-filled (ZERO: the `next` window, whose out-of-image cells must read as lk::warp's constant
+// border) or left alone (the prev tile: nothing reads them before the reflected ring fill).  Needs
+// gx0 and cols to be multiples of 4, so that no chunk straddles the image edge.
+template <int NT, int V4, int NROWS, bool ZERO>
+__device__ __forceinline__ void dma_rows_clipped(const float *__restrict__ img, int istride, int rows, int cols,
+                                                 int gx0, int gy0, float *dst, int tid) {
+    constexpr int NP = (NROWS * V4 + NT - 1) / NT, A = NT / V4, B = NT % V4;
+    const int lane = tid & 63;
+    const int slot0 = __builtin_amdgcn_readfirstlane(tid - lane);
+    int ly = tid / V4, lv = tid - ly * V4;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        if (k == NP - 1 ? (ly < NROWS) : true) {
+            const int gy = gy0 + ly, gx = gx0 + 4 * lv;
+            const bool in = (unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols;
+            if (in)
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)(img + (size_t)gy * istride + gx),
+                                                 (lds_void *)(dst + 4 * (slot0 + k * NT)), 16, 0, 0);
+            else if (ZERO)
+                *reinterpret_cast<v4f *>(dst + 4 * (tid + k * NT)) = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        if (k + 1 < NP) {
+            lv += B;
+            const bool c = lv >= V4;
+            lv -= c ? V4 : 0;
+            ly += A + (c ? 1 : 0);
+        }
+    }
+}
+
 // Streamed tiles (lk_level_stream_kernel): the coarse flow block goes in by LDS-DMA too.  LDS layout:
 // [u row | v row] per coarse row, CWP = CW rounded up to whole float4s each, so that pyrUp reads a
 // (u, v) pair with one ds_read2_b32; a wave-instruction moves as many consecutive half-rows as fit
@@ -351,7 +383,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     // registers, no ds_write, no per-element index arithmetic (carry tiles keep the (u, v)-pair layout)
     constexpr bool CDMA = STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY);
     constexpr int CBF = CDMA ? C::CS_F : (CARRY ? C::CC_F : C::C_F);  // floats of the coarse block (both fields)
-    constexpr bool STAGED = INT && C::FAST && MODE != LK_FLOW_NONE;  // next window in LDS
+    constexpr bool STAGED = INT && C::FAST && MODE != LK_FLOW_NONE;  // next window in LDS (interior tiles: by DMA)
+    // Border tiles take the marching body too when the image is at least 4 x 4 (one reflection per tap):
+    // their `next` window is staged with zeros outside the image (= lk::warp's constant border), their
+    // coarse block with replicated edges from a possibly negative origin, and pyrUp's reflected taps differ
+    // from the interior pattern in one place only: the first / last image column and row (see march).
+    const bool fastb = !INT && C::FAST && MODE != LK_FLOW_NONE && a.rows >= 4 && a.cols >= 4;
     float *P = lds;
     float *Wp = lds + RH * PS;
     float *X = lds + C::IMG_F;
@@ -413,13 +450,17 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         cx0 = (rx0 - 2 > 0 ? rx0 - 2 : 0) >> 1;
         // carry tiles: the coarse block starts at the rows the tile's own first output row needs
         cy0 = (ry0 + (CARRY ? H : 0) - 2 > 0 ? ry0 + (CARRY ? H : 0) - 2 : 0) >> 1;
+        if (fastb) {  // the block keeps its place relative to the region: columns / rows before 0 replicate
+            cx0 = (rx0 - 2) >> 1;
+            cy0 = (ry0 - 2) >> 1;
+        }
 #pragma unroll
         for (int k = 0; k < NC; k++) {
             // unconditional loads from clamped (always valid) addresses: no branch, so the
             // compiler keeps every load in flight instead of waiting inside each predicated block
             const int i = tid + k * NT < CH * CW ? tid + k * NT : CH * CW - 1;
             const int cy = i / CW, cx = i - cy * CW;
-            const int yy = cy0 + cy < fr ? cy0 + cy : fr - 1, xx = cx0 + cx < fc ? cx0 + cx : fc - 1;
+            const int yy = clampi(cy0 + cy, 0, fr - 1), xx = clampi(cx0 + cx, 0, fc - 1);
             rcu[k] = fu[(size_t)yy * fc + xx];
             rcv[k] = fv[(size_t)yy * fc + xx];
         }
@@ -458,6 +499,14 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 }
             }
         }
+        // Border tiles whose 16-byte chunks cannot straddle the image edge take the DMA as well
+        // (in-image chunks only; the `next` window's other chunks are zero-filled)
+        const bool clip_dma = fastb && (cols & 3) == 0 && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
+                              ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
+        if (clip_dma) {
+            dma_rows_clipped<NT, RW / 4, RH, false>(prev, istride, rows, cols, rx0, ry0, P, tid);
+            dma_rows_clipped<NT, NW / 4, NH, true>(next, istride, rows, cols, rx0 - M, ry0 - M, Nx, tid);
+        } else
         // Batched, unconditional loads from clamped (always valid) addresses, stored afterwards:
         // every load of the tile is in flight at once.  Cells outside the image receive edge
         // replicas that nothing reads (the gradient phase reflects what it needs).
@@ -487,6 +536,36 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 Nx[i] = next[(size_t)(ry0 - M + LY0 + ly) * istride + rx0 - M + lx];
             }
         }
+        if (fastb && !clip_dma) {
+            // the `next` window of a border tile: zeros outside the image, so that the staged warp's four
+            // taps are exactly cv::remap's BORDER_CONSTANT(0) taps.  Batched like the prev tile above;
+            // a thread's elements are NT apart = (A rows, B columns) with one carry.
+            constexpr int NBN = (NH * NW + NT - 1) / NT, HB = (NBN + 1) / 2, A = NT / NW, B = NT % NW;
+            int ly = tid / NW, lx = tid - ly * NW;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                float rn[HB];
+                int ly2 = ly, lx2 = lx;
+#pragma unroll
+                for (int k = 0; k < HB; k++) {
+                    const int gy = ry0 - M + ly2, gx = rx0 - M + lx2;
+                    const bool ok = (unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols;
+                    const float val = next[(size_t)clampi(gy, 0, rows - 1) * istride + clampi(gx, 0, cols - 1)];
+                    rn[k] = ok ? val : 0.f;
+                    lx2 += B;
+                    const bool c = lx2 >= NW;
+                    lx2 -= c ? NW : 0;
+                    ly2 += A + (c ? 1 : 0);
+                }
+#pragma unroll
+                for (int k = 0; k < HB; k++) {
+                    const int i = tid + (half * HB + k) * NT;
+                    if (i < NH * NW) Nx[i] = rn[k];
+                }
+                ly = ly2;
+                lx = lx2;
+            }
+        }
     }
     float base_u[RPT], base_v[RPT];
 #pragma unroll
@@ -498,7 +577,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
 
     if (MODE != LK_FLOW_NONE) {
         // ---- phase 2: base flow at every region pixel, warp `next` --------------------------
-        if (INT && C::FAST) {
+        if (C::FAST && (INT || fastb)) {
             // Marching job: column lx, 8 region rows from ly0 (global row even).
             // pyrUp = 2x replicate + [1,4,6,4,1]/16 rows then columns.  Row taps of column gx read
             // coarse columns {m-1,m-1,m,m,m+1} (gx = 2m) or {m-1,m,m,m+1,m+1} (gx = 2m+1); column
@@ -521,6 +600,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     // taps 1 and 3 read coarse column (0 or 1) + parity: two more LDS reads off a
                     // second base register instead of four v_cndmask per coarse row
                     const int odd = gx & 1;
+                    // Border tiles: BORDER_REFLECT_101 on the fine grid (Pyramids.cu:126-127) against the
+                    // replicated edges of the coarse block.  Writing out the five taps of fine columns 0, 1,
+                    // cols-2, cols-1 (cols = 2 fc): replication already gives the reflected pattern except
+                    // tap 0 of column 0 (coarse 1, not 0) and tap 4 of column cols-1 (coarse fc-2, not fc-1);
+                    // the same holds for rows.  Those are c2 / c0 of this job's own three columns.
+                    const bool first_col = !INT && gx == 0, last_col = !INT && gx == cols - 1;
 #pragma unroll
                     for (int i = 0; i < RPT / 2 + 2; i++) {
                         v2f c0, c1, c2, ca, cb;
@@ -541,11 +626,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                             ca = c[odd];
                             cb = c[1 + odd];
                         }
-                        v2f t = c0 * (v2f){g5[0], g5[0]};
+                        const v2f t0 = first_col ? c2 : c0, t4 = last_col ? c0 : c2;
+                        v2f t = t0 * (v2f){g5[0], g5[0]};
                         t = __builtin_elementwise_fma(ca, (v2f){g5[1], g5[1]}, t);
                         t = __builtin_elementwise_fma(c1, (v2f){g5[2], g5[2]}, t);
                         t = __builtin_elementwise_fma(cb, (v2f){g5[3], g5[3]}, t);
-                        ruv[i] = __builtin_elementwise_fma(c2, (v2f){g5[4], g5[4]}, t);
+                        ruv[i] = __builtin_elementwise_fma(t4, (v2f){g5[4], g5[4]}, t);
                     }
                 }
                 // FULL mode reads the (already expanded + resized) base flow from global memory:
@@ -555,8 +641,11 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 if (MODE == LK_FLOW_FULL) {
 #pragma unroll
                     for (int j = 0; j < RPT; j++) {
-                        fu_[j] = a.flow_u[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
-                        fv_[j] = a.flow_v[pair * a.flow_pair + (size_t)(gy0 + j) * a.flow_cols + gx];
+                        // border tiles: region pixels outside the image read a valid address (their flow is never used)
+                        const size_t fo = pair * a.flow_pair + (size_t)(INT ? gy0 + j : clampi(gy0 + j, 0, rows - 1)) * a.flow_cols +
+                                          (INT ? gx : clampi(gx, 0, cols - 1));
+                        fu_[j] = a.flow_u[fo];
+                        fv_[j] = a.flow_v[fo];
                     }
                 }
 #pragma unroll
@@ -567,11 +656,14 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         float bu, bv;
                         if (MODE == LK_FLOW_COARSE) {
                             const int i1 = o ? p + 1 : p, i3 = o ? p + 2 : p + 1;
-                            v2f auv = ruv[p] * (v2f){g5[0], g5[0]};
+                            // border tiles: tap 0 of image row 0 and tap 4 of image row rows-1 (see above)
+                            const v2f r0 = (!INT && gy0 + j == 0) ? ruv[p + 2] : ruv[p];
+                            const v2f r4 = (!INT && gy0 + j == rows - 1) ? ruv[p] : ruv[p + 2];
+                            v2f auv = r0 * (v2f){g5[0], g5[0]};
                             auv = __builtin_elementwise_fma(ruv[i1], (v2f){g5[1], g5[1]}, auv);
                             auv = __builtin_elementwise_fma(ruv[p + 1], (v2f){g5[2], g5[2]}, auv);
                             auv = __builtin_elementwise_fma(ruv[i3], (v2f){g5[3], g5[3]}, auv);
-                            auv = __builtin_elementwise_fma(ruv[p + 2], (v2f){g5[4], g5[4]}, auv);
+                            auv = __builtin_elementwise_fma(r4, (v2f){g5[4], g5[4]}, auv);
                             auv = auv * (v2f){2.f, 2.f};  // OpticalFlow.cpp:142,144
                             bu = auv.x;
                             bv = auv.y;
