@@ -221,6 +221,31 @@ def test_lk_pyr_tiny_and_ragged(mods, rows, cols, levels, win):
     assert np.array_equal(host(g1u), e1u) and np.array_equal(host(g1v), e1v)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_lk_pyr_random_even_shapes_border_tiles(mods, seed):
+    """Border tiles run the marching body (zero-padded `next` window, replicated coarse block, pyrUp's
+    reflected taps fixed at the first / last image column and row).  Random shapes whose levels all
+    double exactly (the fused pyrUp), with widths that are and are not multiples of 4 (LDS-DMA or the
+    register path for the window), heights from under one tile to several, a motion with a large and a
+    sub-pixel part so the warp's taps cross the image edge, windows 7 / 11 / 15 / 21."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    rng = np.random.default_rng(0xB0DE + seed)
+    for _ in range(5):
+        levels = int(rng.integers(2, 5))
+        unit = 1 << (levels - 1)
+        rows = unit * int(rng.integers(max(1, 4 // unit + 1), max(3, 260 // unit)))
+        cols = unit * int(rng.integers(max(1, 4 // unit + 1), max(3, 330 // unit)))
+        win = int(rng.choice([7, 11, 15, 21]))
+        dx, dy = int(rng.integers(-9, 10)), int(rng.integers(-9, 10))
+        prev = synth.smooth_noise(int(rng.integers(1 << 30)), rows, cols)
+        nxt = np.ascontiguousarray(np.roll(prev, (dy, dx), (0, 1)))
+        nxt = (0.75 * nxt + 0.25 * np.roll(nxt, 1, 1)).astype(np.float32)  # a quarter pixel more in x
+        eu, ev = orc.lk_flow_pyr(prev, nxt, win, levels)
+        gu, gv = lk.calcOpticalFlowPyr(dev(prev), dev(nxt), win, levels)
+        assert np.array_equal(host(gu), eu) and np.array_equal(host(gv), ev), (rows, cols, levels, win, dx, dy)
+
+
 def test_lk_pitched_views(mods):
     """cv::Mat ROIs: row pitch larger than the width, for inputs and outputs of the host flavour."""
     lk, pyr = mods
