@@ -48,47 +48,89 @@ __global__ __launch_bounds__(256) void filter_cols_kernel(const float *__restric
 }
 
 // LDS-tiled forms of the two passes (the generic LK path runs 5 fields x 43 taps through them): the
-// tile (+ n/2 halo, BORDER_REFLECT_101 resolved while loading, loads batched) is staged once and
-// every tap is an LDS read by consecutive lanes; a thread carries 4 (rows) / 8 (columns) independent
-// chains.  Same fmaf chain per output as the kernels above.
+// tile (+ n/2 halo, BORDER_REFLECT_101 resolved while loading, every load of the tile in flight at
+// once) is staged once; a thread keeps a sliding window of the staged values in registers and runs 4
+// (rows: four adjacent columns) / 8 (columns: eight adjacent rows) independent chains, taps four at a
+// time -- one LDS read per 16 / 8 FMAs.  Same fmaf chain per output as the kernels above.
 __global__ __launch_bounds__(256) void filter_rows_lds_kernel(const float *__restrict__ src,
                                                                int sstride, size_t sfield,
                                                                float *__restrict__ dst, int dstride,
                                                                size_t dfield, int rows, int cols,
                                                                Taps t) {
-    constexpr int TW = 256, TR = 4;
+    constexpr int TW = 256, TR = 8;
     extern __shared__ float fl_lds[];
-    const int a = t.n / 2, pw = TW + t.n - 1;  // staged row width
+    // staged row: TW + n - 1 values, pitch rounded up to whole float4s plus one (the last chunk's second
+    // ds_read_b128 reaches up to 7 floats past the thread's first column)
+    const int a = t.n / 2, pw = ((TW + t.n - 1 + 3) & ~3) + 4;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
     const float *sp = src + blockIdx.z * sfield;
-    for (int base = 0; base < TR * pw; base += 4 * 256) {
-        float v[4];
+    {
+        // every load of the tile in flight at once (the kernel was bound by the latency of its staging,
+        // two dependent batches per small workgroup); (row, column) of a thread's elements by stepping,
+        // not by dividing by the run-time pitch
+        constexpr int NB = (TR * (((TW + 62 + 3) & ~3) + 4) + 255) / 256;  // n <= 63
+        float v[NB];
+        int r = 0, c = threadIdx.x;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = base + k * 256 + threadIdx.x < TR * pw ? base + k * 256 + threadIdx.x : TR * pw - 1;
-            const int r = i / pw, c = i - r * pw;
-            const int yy = y0 + r < rows ? y0 + r : rows - 1;
+        for (int k = 0; k < NB; k++) {
+            while (c >= pw) {
+                c -= pw;
+                r++;
+            }
+            const int rr = r < TR ? r : TR - 1;
+            const int yy = y0 + rr < rows ? y0 + rr : rows - 1;
             v[k] = sp[(size_t)yy * sstride + reflect101(x0 - a + c, cols)];
+            c += 256;
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = base + k * 256 + threadIdx.x;
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * 256;
             if (i < TR * pw) fl_lds[i] = v[k];
         }
     }
     __syncthreads();
-    const int x = x0 + threadIdx.x;
-    if (x >= cols) return;
-    float acc[TR] = {0.f, 0.f, 0.f, 0.f};
-    const float *lp = fl_lds + threadIdx.x;
-    for (int k = 0; k < t.n; k++) {
-        const float w = t.k[k];
+    // A thread finishes FOUR adjacent outputs of one row (thread = (row, group of 4 columns)): the taps
+    // go four at a time, each chunk needs the 7 staged values [4c, 4c + 7) = the float4 it already holds
+    // plus one new ds_read_b128, and does 16 FMAs -- one LDS instruction per 16 FMAs instead of one per
+    // FMA (the kernel was LDS-issue bound).  Every output still runs its own fmaf chain over taps 0, 1, ...
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int q = threadIdx.x & 63;
+#pragma unroll 1
+    for (int r = threadIdx.x >> 6; r < TR; r += 4) {
+    const f4 *lp4 = reinterpret_cast<const f4 *>(fl_lds + r * pw) + q;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    f4 cur = lp4[0];
+    int c = 0;
+    for (; c + 4 <= t.n; c += 4) {
+        const f4 nxt = lp4[(c >> 2) + 1];
+        const float w[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
 #pragma unroll
-        for (int r = 0; r < TR; r++) acc[r] = fmaf(lp[r * pw + k], w, acc[r]);
+        for (int kk = 0; kk < 4; kk++) {
+            const float tap = t.k[c + kk];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] = fmaf(w[kk + j], tap, acc[j]);
+        }
+        cur = nxt;
     }
+    if (c < t.n) {  // 1-3 left-over taps
+        const f4 nxt = lp4[(c >> 2) + 1];
+        const float w[8] = {cur.x, cur.y, cur.z, cur.w, nxt.x, nxt.y, nxt.z, nxt.w};
 #pragma unroll
-    for (int r = 0; r < TR; r++)
-        if (y0 + r < rows) dst[blockIdx.z * dfield + (size_t)(y0 + r) * dstride + x] = acc[r];
+        for (int kk = 0; kk < 3; kk++) {
+            if (c + kk < t.n) {
+                const float tap = t.k[c + kk];
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = fmaf(w[kk + j], tap, acc[j]);
+            }
+        }
+    }
+    if (y0 + r < rows) {
+        float *o = dst + blockIdx.z * dfield + (size_t)(y0 + r) * dstride + x0 + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (x0 + 4 * q + j < cols) o[j] = acc[j];
+    }
+    }
 }
 
 __global__ __launch_bounds__(256) void filter_cols_lds_kernel(const float *__restrict__ src,
@@ -102,16 +144,18 @@ __global__ __launch_bounds__(256) void filter_cols_lds_kernel(const float *__res
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const float *sp = src + blockIdx.z * sfield;
     const int c = threadIdx.x & 63, x = x0 + c < cols ? x0 + c : cols - 1;
-    for (int base = 0; base < ph; base += 4 * 4) {  // 4 rows per pass of the workgroup, 4 passes in flight
-        float v[4];
+    {
+        // every load of the tile in flight at once: row r = (threadIdx.x >> 6) + 4 k of the staged column
+        constexpr int NB = (32 + 62 + 3) / 4;  // n <= 63
+        float v[NB];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int r = base + 4 * k + (threadIdx.x >> 6);
+        for (int k = 0; k < NB; k++) {
+            const int r = 4 * k + (threadIdx.x >> 6);
             v[k] = sp[(size_t)reflect101(y0 - a + (r < ph ? r : ph - 1), rows) * sstride + x];
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int r = base + 4 * k + (threadIdx.x >> 6);
+        for (int k = 0; k < NB; k++) {
+            const int r = 4 * k + (threadIdx.x >> 6);
             if (r < ph) fl_lds[r * TW + c] = v[k];
         }
     }
@@ -121,11 +165,35 @@ __global__ __launch_bounds__(256) void filter_cols_lds_kernel(const float *__res
     float acc[RP];
 #pragma unroll
     for (int j = 0; j < RP; j++) acc[j] = 0.f;
+    // 8 vertically adjacent outputs per thread, taps four at a time: a chunk needs staged rows
+    // [4c, 4c + 11) of the thread's column = 7 it already holds + 4 new LDS reads, and does 32 FMAs.
     const float *lp = fl_lds + rb * TW + c;
-    for (int k = 0; k < t.n; k++) {
-        const float w = t.k[k];
+    float w[12];
 #pragma unroll
-        for (int j = 0; j < RP; j++) acc[j] = fmaf(lp[(j + k) * TW], w, acc[j]);
+    for (int i = 0; i < 7; i++) w[i] = lp[i * TW];
+    int k0 = 0;
+    for (; k0 + 4 <= t.n; k0 += 4) {
+#pragma unroll
+        for (int i = 7; i < 11; i++) w[i] = lp[(k0 + i) * TW];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const float tap = t.k[k0 + kk];
+#pragma unroll
+            for (int j = 0; j < RP; j++) acc[j] = fmaf(w[kk + j], tap, acc[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; i++) w[i] = w[i + 4];
+    }
+    if (k0 < t.n) {  // 1-3 left-over taps: rows up to k0 + 2 + 7
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            if (k0 + kk < t.n) {
+                w[7 + kk] = lp[(k0 + 7 + kk) * TW];
+                const float tap = t.k[k0 + kk];
+#pragma unroll
+                for (int j = 0; j < RP; j++) acc[j] = fmaf(w[kk + j], tap, acc[j]);
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < RP; j++)
@@ -136,8 +204,8 @@ int launch_filter_rows(hipStream_t s, const float *src, int sstride, size_t sfie
                        int dstride, size_t dfield, int rows, int cols, int nfields,
                        const Taps &t) {
     if (t.n >= 5) {
-        filter_rows_lds_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 4), nfields), 256,
-                                 (size_t)4 * (256 + t.n - 1) * sizeof(float), s>>>(
+        filter_rows_lds_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 8), nfields), 256,
+                                 (size_t)8 * (((256 + t.n - 1 + 3) & ~3) + 4) * sizeof(float), s>>>(
             src, sstride, sfield, dst, dstride, dfield, rows, cols, t);
         MICV_LAUNCH_CHECK();
         return MICV_OK;
