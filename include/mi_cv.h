@@ -125,6 +125,14 @@ int micv_lk_flow_pyr_batch_dev(micv_ctx *ctx, const float *prev, const float *ne
                                int levels, float *u, float *v, size_t opair_stride,
                                size_t ostride, micv_stream stream);
 
+/* Diagnostic, host only (no device call): the work list the optional chain / streamed launches of the
+ * level kernel walk (MICV_OPT_LK_CHAIN, MICV_OPT_LK_STREAM) for a rows x cols level of `batch` pairs.
+ * Entry i = (tile x, first tile y, tiles in the chain, pair), 0 tiles = padding; tiles are
+ * tile_w x tile_h pixels.  *count = entries of the list (also when entries_xycp is NULL or smaller).
+ * Every tile of every pair must appear in exactly one entry -- tests/test_capi_and_host.py checks it. */
+int micv_lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, int32_t *entries_xycp,
+                          int64_t capacity, int64_t *count, int *tile_w, int *tile_h);
+
 /* One iteration of the coarse-to-fine loop of lk::calcOpticalFlowPyr (OpticalFlow.cpp:135-163) on
  * one pyramid level, restricted to output rows [row_begin, row_end): the building block of
  * row-sharded execution (a rank owns a band of rows of every level and exchanges only coarse-flow
@@ -279,13 +287,22 @@ int micv_sift_descriptors_host(micv_ctx *ctx, const float *gx, const float *gy, 
 #define MICV_STEREO_SERIAL      4 /* serial::disparitySSD as written (DisparitySSD.cpp:35-61):
                                      per-term round() into an int sum, search clamped to the padded
                                      image, best = (99999999, 0) initially.  SSD only. */
+#define MICV_STEREO_ROLLING     8 /* column sums as the CUDA kernels keep them (DisparitySSD.cu:97-138,
+                                     DisparityNCorr.cu:117-173): strips of ROWS_PER_THREAD = 40 rows;
+                                     a strip's first row sums its 2r+1 terms top -> bottom from 0, each
+                                     further row subtracts the term that left the window from the
+                                     previous row's sum, then adds the one that entered.  Same result
+                                     as the fresh sums on integer-valued images; on general f32 the
+                                     two round differently.  Runs a slower, strip-serial kernel. */
 
 /* cuda::disparitySSD / serial::disparitySSD, ps2_cpp/lib/DisparitySSD.cu:143-207 and
  * DisparitySSD.cpp:9-62 (a12).  disp is rows x cols int8 (CV_8SC1), dstride in bytes.
  * flags = 0: CUDA-path semantics with the window corrected to (2r+1)^2 columns (clamp-to-edge
  * addressing, every d in [min,max] tried in ascending order, strict '<').
- * flags = COLS_2R | MIN_SSD_5E6: the CUDA kernel exactly as written.  flags = SERIAL: the CPU
- * function exactly as written. */
+ * flags = COLS_2R | MIN_SSD_5E6 | ROLLING: the CUDA kernel as written, source order of operations,
+ * no contraction (COLS_2R | MIN_SSD_5E6 alone keeps its window and threshold but sums every row's
+ * columns afresh -- identical on integer-valued images).  flags = SERIAL: the CPU function exactly as
+ * written. */
 int micv_disparity_ssd_dev(micv_ctx *ctx, const float *left, const float *right, int rows,
                            int cols, size_t stride, int window_rad, int min_disparity,
                            int max_disparity, int flags, int8_t *disp, size_t dstride,

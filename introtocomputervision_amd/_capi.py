@@ -30,7 +30,7 @@ f32 = C.c_float
 f64 = C.c_double
 
 OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
-STEREO_COLS_2R, STEREO_MIN_SSD_5E6 = 1, 2
+STEREO_COLS_2R, STEREO_MIN_SSD_5E6, STEREO_SERIAL, STEREO_ROLLING = 1, 2, 4, 8
 # micv_ctx_set_option (include/mi_cv.h): none of these changes a result
 (OPT_LK_STREAM_GROUPS, OPT_LK_FORCE_GENERIC, OPT_LK_NARROW_TILES, OPT_SOBEL_GENERIC, OPT_HARRIS_GENERIC,
  OPT_NMS_SCAN, OPT_STEREO_ROWS, OPT_LK_CHAIN, OPT_LK_SHORT_TILES, OPT_LK_STREAM) = range(1, 11)
@@ -72,6 +72,7 @@ SIGNATURES = {
     "micv_lk_flow_pyr_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz, vp]),
     "micv_lk_flow_pyr_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz]),
     "micv_lk_flow_pyr_batch_dev": (i32, [vp, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
+    "micv_lk_schedule_host": (i32, [i32, i32, i32, i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
     "micv_lk_level_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "micv_lk_level_batch_dev": (i32, [vp, vp, vp, i32, sz, i32, i32, sz, i32, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
     "micv_gaussian_pyramid_batch_dev": (i32, [vp, vp, i32, sz, i32, i32, sz, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), vp]),

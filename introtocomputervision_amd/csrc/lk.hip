@@ -508,6 +508,30 @@ int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next,
     return MICV_OK;
 }
 
+int micv_lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, int32_t *entries_xycp,
+                          int64_t capacity, int64_t *count, int *tile_w, int *tile_h) {
+    MICV_REQUIRE(count && tile_w && tile_h, "micv_lk_schedule_host: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0 && batch >= 1 && max_chain >= 1 && max_chain <= 32,
+                 "micv_lk_schedule_host: bad argument");
+    std::vector<int4> v;
+    const int th = lk_schedule_host(rows, cols, batch, win, max_chain, &v);
+    if (th == 0) {
+        set_error("micv_lk_schedule_host: window %d has no scheduled launch", win);
+        return MICV_EUNSUPPORTED;
+    }
+    *tile_w = 64;
+    *tile_h = th;
+    *count = (int64_t)v.size();
+    if (entries_xycp)
+        for (int64_t i = 0; i < (int64_t)v.size() && i < capacity; i++) {
+            entries_xycp[4 * i] = v[i].x;
+            entries_xycp[4 * i + 1] = v[i].y;
+            entries_xycp[4 * i + 2] = v[i].z;
+            entries_xycp[4 * i + 3] = v[i].w;
+        }
+    return MICV_OK;
+}
+
 int micv_lk_level_dev(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
                       size_t stride, int win, const float *flow_u, const float *flow_v,
                       int flow_rows, int flow_cols, int row_begin, int row_end, float *u, float *v,

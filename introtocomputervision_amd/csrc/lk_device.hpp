@@ -40,6 +40,9 @@ __device__ __forceinline__ float avg2(float a, float b) { return a * 0.5f + b * 
 __device__ __forceinline__ double lk_exact_diff(float a, float b, float c, float d) {
     return fma((double)a, (double)b, -((double)c * (double)d));  // == a*b - c*d in double
 }
+//    An infinite det does occur (an infinite pixel, or window sums that overflow): the Newton steps
+//    turn rcp(inf) = 0 into NaN where the division gives 0, so the chain ends in the division's own
+//    v_div_fixup (one instruction: 1/inf = 0, NaN stays NaN, every other det passes through).
 __device__ __forceinline__ double lk_rcp_normal(double x) {
     double r = __builtin_amdgcn_rcp(x);
     double e = fma(-x, r, 1.0);
@@ -47,7 +50,7 @@ __device__ __forceinline__ double lk_rcp_normal(double x) {
     e = fma(-x, r, 1.0);
     r = fma(r, e, r);
     e = fma(-x, r, 1.0);  // residual of the quotient 1 * r
-    return fma(e, r, r);
+    return __builtin_amdgcn_div_fixup(fma(e, r, r), x, 1.0);
 }
 __device__ __forceinline__ void lk_solve(float sxx, float sxy, float syy, float sxt, float syt,
                                          float &u, float &v) {
@@ -62,6 +65,16 @@ __device__ __forceinline__ void lk_solve(float sxx, float sxy, float syy, float 
     }
 }
 
+// cvRound(float) as the reference's x86-64 OpenCV 3.4.1 executes it inside cv::remap
+// (OpticalFlow.cpp:119; _mm_cvtss_si32 / _mm_cvtps_epi32): round half to even into 32 bits, and
+// INT_MIN ("integer indefinite") for a NaN and for every value that does not fit an int32.  The map
+// cell is then (-2^26 -> saturate_cast<short> = -32768, fraction 0): all four taps are outside the
+// image, the sample is the border constant.  v_cvt_i32_f32 alone saturates and turns NaN into 0.
+__device__ __forceinline__ int cv_round_i32(float v) {
+    const int r = __float2int_rn(v);
+    return fabsf(v) < 2147483648.f ? r : (int)0x80000000;
+}
+
 // The same sample, with the four taps served from an LDS copy of `next` when they fall inside
 // the staged window [nx0, nx0+NW) x [ny0, ny0+NH) (which must lie inside the image) and from
 // global memory otherwise.  Coordinates, weights and the blend are identical to warp_sample.
@@ -72,7 +85,13 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
                                                     float dv) {
     // (xf, yf) = the pixel's coordinates already as floats (exact: the caller counts rows in float)
     const float mx = xf + du, my = yf + dv;
-    const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
+    const float tx = mx * 32.f, ty = my * 32.f;
+    // The saturating conversion serves the window test: a coordinate beyond the int range lands far
+    // outside the window either way (INT_MAX >> 5 or INT_MIN >> 5 against cvRound's INT_MIN >> 5), and
+    // inside the window it is cvRound exactly.  Only a NaN needs help -- it converts to 0, which may
+    // well be a window cell -- and gets it from ONE ordered compare of both coordinates.
+    const int sx = __float2int_rn(tx), sy = __float2int_rn(ty);
+    const bool ordered = !__builtin_isunordered(tx, ty);
     const int fx = sx & 31, fy = sy & 31;
     const float ax1 = (float)fx * 0.03125f, ay1 = (float)fy * 0.03125f;
     // weights as aligned pairs, so the four weight products and the four tap products are two packed
@@ -83,7 +102,7 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
     // the 16-bit clamp of cv::remap's integer map only matters outside the window: the window test
     // runs on the unclamped cell (no wrap: |sx >> 5| < 2^26), the clamp moves into the fallback
     const int lx = (sx >> 5) - nx0, ly = (sy >> 5) - ny0;
-    if ((unsigned)lx < (unsigned)(NW - 1) && (unsigned)ly < (unsigned)(NH - 1)) {
+    if (ordered && (unsigned)lx < (unsigned)(NW - 1) && (unsigned)ly < (unsigned)(NH - 1)) {
         // cell index by one full-rate 24-bit multiply-add (a plain `ly * NW + lx` turns into the
         // quarter-rate v_mul_lo_u32, and LLVM folds __mul24 and shift pairs back into it), and the
         // address as ONE register the four taps hang off by immediate offsets (two ds_read2_b32;
@@ -100,7 +119,11 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
         v2 = p[NW];
         v3 = p[NW + 1];
     } else {
-        const int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
+        // cvRound proper.  Where it differs from the conversion above (NaN, beyond the int range) every
+        // tap is the border constant 0 and the weights formed from the other value's fraction bits do
+        // not matter: they are finite and non-negative, the sample is +0 either way.
+        const int cx = cv_round_i32(tx), cy = cv_round_i32(ty);
+        const int ix = clampi(cx >> 5, -32768, 32767), iy = clampi(cy >> 5, -32768, 32767);
         const bool x0 = (unsigned)ix < (unsigned)cols, x1 = (unsigned)(ix + 1) < (unsigned)cols;
         const bool y0 = (unsigned)iy < (unsigned)rows, y1 = (unsigned)(iy + 1) < (unsigned)rows;
         const float *p = src + (ptrdiff_t)iy * stride + ix;
@@ -123,7 +146,7 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
 __device__ __forceinline__ float warp_sample(const float *__restrict__ src, int rows, int cols,
                                              int stride, int x, int y, float du, float dv) {
     const float mx = (float)x + du, my = (float)y + dv;
-    const int sx = __float2int_rn(mx * 32.f), sy = __float2int_rn(my * 32.f);
+    const int sx = cv_round_i32(mx * 32.f), sy = cv_round_i32(my * 32.f);
     const int fx = sx & 31, fy = sy & 31;
     const int ix = clampi(sx >> 5, -32768, 32767), iy = clampi(sy >> 5, -32768, 32767);
     const float ax1 = (float)fx * 0.03125f, ax0 = 1.f - ax1;

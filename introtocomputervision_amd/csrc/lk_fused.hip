@@ -1225,11 +1225,18 @@ static void build_chain_schedule(int rows, int cols, int batch, int max_chain, s
             for (int tx = 0; tx < tiles_x; tx++)
                 if (!interior(tx, ty)) border.push_back(make_int4(tx, ty, 1, p));
         // interior rows of a column are contiguous (the predicate is separable); cut them per segment so
-        // that one segment's chains of all columns are neighbours in the class list
+        // that one segment's chains of all columns are neighbours in the class list.  The row range comes
+        // from the y half of the predicate alone: probing a column (r02 probed tiles_x / 2) fails when that
+        // column is not x-interior -- cols 194..206 have tiles_x = 4 and only column 1 interior -- and the
+        // interior tiles then landed in neither list.
+        auto interior_y = [&](int ty) {
+            const int ry0 = ty * C::TH - C::H;
+            return ry0 - E >= 0 && ry0 + C::RH + E <= rows;
+        };
         int iy0 = 0;
-        while (iy0 < tiles_y && !interior(tiles_x / 2, iy0)) iy0++;
+        while (iy0 < tiles_y && !interior_y(iy0)) iy0++;
         int iy1 = iy0;
-        while (iy1 < tiles_y && interior(tiles_x / 2, iy1)) iy1++;
+        while (iy1 < tiles_y && interior_y(iy1)) iy1++;
         int y = iy0;
         while (y < iy1) {
             const int rem = iy1 - y;
@@ -1258,6 +1265,17 @@ static void build_chain_schedule(int rows, int cols, int batch, int max_chain, s
 }
 
 bool lk_fused_supports(int win) { return win == 15 || win == 7 || win == 21 || win == 11; }
+
+// Host-only view of the schedule the chain / streamed launches walk (micv_lk_schedule_host): lets a
+// CPU test check that every (tile x, tile y, pair) is covered exactly once.
+int lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, std::vector<int4> *out) {
+    switch (win) {
+        case 15: build_chain_schedule<LkCfg<7, 512>>(rows, cols, batch, max_chain, out); return 32;
+        case 11: build_chain_schedule<LkCfg<5, 512>>(rows, cols, batch, max_chain, out); return 32;
+        case 7: build_chain_schedule<LkCfg<3, 512>>(rows, cols, batch, max_chain, out); return 32;
+        default: return 0;
+    }
+}
 
 // The cached device copy of a launch shape's schedule (built on first use).
 template <typename C>

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.hpp"
 
+#include <vector>
+
 namespace micv {
 
 enum LkFlowMode {
@@ -28,7 +30,7 @@ struct LkLevelArgs {
     int y_shift = 0;  // set by the launcher: tile rows start at tile_y * TH + y_shift (band launches)
     int narrow = 0;  // MICV_OPT_LK_NARROW_TILES: 256-thread form of the win-15 kernel
     // Tile chains (lk_fused.hip): ctx owns the cached schedules; max_chain = MICV_OPT_LK_CHAIN
-    // (0 = automatic, 1 = off, n = longest chain).  Host side only.
+    // (0 and 1 = off, n > 1 = longest chain, -1 = the schedule's order with single tiles).  Host side only.
     micv_ctx *ctx = nullptr;
     int max_chain = 0;
     int short_tiles = 0;  // MICV_OPT_LK_SHORT_TILES: 0 = automatic (64x16 tiles under one round), -1 = never
@@ -43,6 +45,9 @@ struct LkLevelArgs {
 };
 
 bool lk_fused_supports(int win);
+// Host-only: the (tile x, first tile y, count, pair) entries of the chain / streamed launch schedule,
+// 8 per round (one per XCD, count 0 = padding).  Returns the tile height, 0 for windows without one.
+int lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, std::vector<int4> *out);
 int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a);
 
 }  // namespace micv

@@ -219,6 +219,83 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
     }
 }
 
+// MICV_STEREO_ROLLING: the column sums as the CUDA kernels keep them (DisparitySSD.cu:97-138,
+// DisparityNCorr.cu:117-173).  Rows are cut into strips of ROWS_PER_THREAD = 40 (DisparitySSD.cu:17);
+// the first row of a strip sums its 2r+1 terms top -> bottom from 0, every further row takes the
+// previous row's column sum, subtracts the term that left the window and then adds the one that
+// entered (two roundings per row).  The chain is serial down the strip, so a wave owns a whole strip
+// of 64 window columns: per disparity it walks the 40 rows once with the running sums in registers;
+// the strip's best costs / disparities sit in wave-private LDS (40 x 64 lanes), horizontal sums run as
+// the same systolic DPP chain as above.  A compatibility mode: images are read straight from global
+// memory (clamp-to-edge = the reference's textures), any radius up to 31.
+constexpr int ST_STRIP = 40, ST_ROLL_WAVES = 2;
+
+template <bool NCC>
+__global__ __launch_bounds__(64 * ST_ROLL_WAVES) void stereo_rolling_kernel(StereoArgs a, int r) {
+    __shared__ float s_best[ST_ROLL_WAVES][ST_STRIP][64];
+    __shared__ signed char s_bestd[ST_ROLL_WAVES][ST_STRIP][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int outw = 64 - 2 * r;
+    const int seg = blockIdx.x * ST_ROLL_WAVES + wave;  // this wave's run of output columns
+    const int y0 = blockIdx.y * ST_STRIP;
+    if (seg * outw >= a.cols) return;  // whole wave; waves never synchronise with each other
+    const int nr = a.rows - y0 < ST_STRIP ? a.rows - y0 : ST_STRIP;
+    const int xc = seg * outw - r + lane;  // window column of this lane (unclamped)
+    const int xl = clampi(xc, 0, a.cols - 1);
+    const int xo = (a.wcols == 2 * r + 1) ? xc - r : xc - r + 1;  // output whose window ENDS at this lane
+    const bool lane_ok = lane >= a.wcols - 1 && xo >= seg * outw && xo < (seg + 1) * outw && xo < a.cols;
+    for (int j = 0; j < nr; j++) {
+        s_best[wave][j][lane] = a.init_best;
+        s_bestd[wave][j][lane] = -1;
+    }
+    auto sum_cols = [&](float cs) {
+        float acc = cs;
+        for (int k = 1; k < a.wcols; k++) acc = dpp_shr1(acc) + cs;
+        return acc;
+    };
+    for (int d = a.min_d; d <= a.max_d; d++) {
+        const int xr = clampi(xc + d, 0, a.cols - 1);
+        float p = 0.f, aa = 0.f, bb = 0.f;
+        auto term = [&](int y, bool add) {
+            const int yy = clampi(y, 0, a.rows - 1);
+            const float l = a.left[(size_t)yy * a.stride + xl], rv = a.right[(size_t)yy * a.stride + xr];
+            if (NCC) {
+                const float t0 = l * rv, t1 = l * l, t2 = rv * rv;
+                p = add ? p + t0 : p - t0;
+                aa = add ? aa + t1 : aa - t1;
+                bb = add ? bb + t2 : bb - t2;
+            } else {
+                const float diff = l - rv, sq = diff * diff;
+                p = add ? p + sq : p - sq;
+            }
+        };
+        for (int wy = -r; wy <= r; wy++) term(y0 + wy, true);
+        for (int j = 0; j < nr; j++) {
+            if (j > 0) {
+                term(y0 + j - 1 - r, false);
+                term(y0 + j + r, true);
+            }
+            const float tot = sum_cols(p);
+            float score;
+            bool better;
+            if (NCC) {
+                const float at = sum_cols(aa), ai = sum_cols(bb);
+                score = tot / sqrtf(at * ai);  // DisparityNCorr.cu:164
+                better = score > s_best[wave][j][lane];
+            } else {
+                score = tot;
+                better = score < s_best[wave][j][lane];  // DisparitySSD.cu:133
+            }
+            if (better) {
+                s_best[wave][j][lane] = score;
+                s_bestd[wave][j][lane] = (signed char)d;
+            }
+        }
+    }
+    if (lane_ok)
+        for (int j = 0; j < nr; j++) a.disp[(size_t)(y0 + j) * a.dstride + xo] = (int8_t)s_bestd[wave][j][lane];
+}
+
 // Any radius: one thread per pixel, same arithmetic order, no reuse.
 template <int MODE>
 __global__ __launch_bounds__(256) void stereo_generic_kernel(StereoArgs a, int r) {
@@ -312,8 +389,10 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
     MICV_REQUIRE(min_d <= max_d && min_d >= -128 && max_d <= 127,
                  "%s: disparities [%d, %d] do not fit the int8 output (CV_8SC1)", fn, min_d, max_d);
     MICV_REQUIRE(stride_ok(stride, cols, 4) && dstride >= (size_t)cols, "%s: bad stride", fn);
-    MICV_REQUIRE((flags & ~7) == 0, "%s: unknown flags 0x%x", fn, flags);
+    MICV_REQUIRE((flags & ~15) == 0, "%s: unknown flags 0x%x", fn, flags);
     MICV_REQUIRE(!(ncc && (flags & MICV_STEREO_SERIAL)), "%s: SERIAL applies to SSD only", fn);
+    MICV_REQUIRE(!((flags & MICV_STEREO_SERIAL) && (flags & MICV_STEREO_ROLLING)),
+                 "%s: SERIAL and ROLLING describe different reference functions", fn);
     MICV_REQUIRE(!((flags & MICV_STEREO_COLS_2R) && rad == 0), "%s: COLS_2R needs radius >= 1", fn);
     MICV_HIP(hipSetDevice(ctx->device));
     StereoArgs a;
@@ -323,7 +402,7 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
     a.init_best = ncc ? 0.f : ((flags & MICV_STEREO_MIN_SSD_5E6) ? 5000000.f : INFINITY);
     a.disp = disp; a.dstride = (int)dstride;
     a.energy = nullptr; a.e_width = 0; a.s_lo = 0;
-    if (ncc && rad >= 1 && rad <= 10) {
+    if (ncc && rad >= 1 && rad <= 10 && !(flags & MICV_STEREO_ROLLING)) {
         // positions a window's last column can take: lanes reach from -R to past cols + R (whole
         // 64-lane strips), shifted by every disparity
         const int outw = 64 - 2 * rad;
@@ -334,6 +413,13 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
         a.energy = static_cast<const float *>(scratch);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & MICV_STEREO_ROLLING) {
+        const dim3 grid(cdiv(cdiv(cols, 64 - 2 * rad), ST_ROLL_WAVES), cdiv(rows, ST_STRIP));
+        if (ncc) stereo_rolling_kernel<true><<<grid, 64 * ST_ROLL_WAVES, 0, s>>>(a, rad);
+        else stereo_rolling_kernel<false><<<grid, 64 * ST_ROLL_WAVES, 0, s>>>(a, rad);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     const int rpw = ctx->opt[MICV_OPT_STEREO_ROWS];
     if (ncc) return launch_stereo<ST_NCC>(s, a, rad, rpw);
     if (flags & MICV_STEREO_SERIAL) return launch_stereo<ST_SSD_SERIAL>(s, a, rad, rpw);

@@ -317,12 +317,22 @@ class RowShardBatch:
                                           ostride, cols * 4, stream))
 
     def run(self, prev, nxt, u, v, stream=None):
+        """Kernels go to `stream` (a raw HIP stream handle; default: torch's current stream).  The halo
+        exchange is torch work -- slab copies and the RCCL point-to-point ops order themselves against
+        torch's CURRENT stream -- so it is issued with `stream` made current: launches and exchange are
+        then one in-order sequence whatever stream the caller passed (r02 raced when they differed)."""
+        import contextlib
+
         import torch
-        s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+        cur = torch.cuda.current_stream(prev.device)
+        s = stream if stream is not None else cur.cuda_stream
+        same = int(s or 0) == int(cur.cuda_stream or 0)
+        on_s = contextlib.nullcontext() if same else torch.cuda.stream(torch.cuda.ExternalStream(int(s), device=prev.device))
         self.build_pyramids(prev, nxt, s)
         for l in range(self.levels - 1, -1, -1):
             if l < self.levels - 1:
-                self.comm.exchange_batch(self.plan, l + 1, self.flow[l + 1])
+                with on_s:
+                    self.comm.exchange_batch(self.plan, l + 1, self.flow[l + 1])
             self.level(l, prev, nxt, u, v, s)
 
 

@@ -323,17 +323,25 @@ inline void disparity(bool ncc, const Mat &left, const Mat &right, const size_t 
 
 // `cuda::` = the CUDA kernels as written (2r-column window, 5e6 cut-off); `serial::` = the CPU
 // functions as written.  micv_disparity_*(flags = 0) is the corrected (2r+1)^2 definition.
+// The CUDA kernels also keep ROLLING column sums down 40-row strips (DisparitySSD.cu:97-138), which
+// round differently from fresh sums on non-integer images.  ps2's inputs are 8-bit images converted to
+// float (ps2_cpp/src/main.cpp:21-48), where both give the same disparities, so the shim stays on the fast
+// kernel; build with -DMICV_SHIM_STEREO_ROLLING=1 to get the strip-serial sums for arbitrary f32 input.
+#ifndef MICV_SHIM_STEREO_ROLLING
+#define MICV_SHIM_STEREO_ROLLING 0
+#endif
 namespace cuda {
 using micv_shim::Mat;
+constexpr int kStereoRolling = MICV_SHIM_STEREO_ROLLING ? MICV_STEREO_ROLLING : 0;
 inline void disparitySSD(const Mat &left, const Mat &right, const size_t windowRad,
                          const int minDisparity, const int maxDisparity, Mat &disparity) {
     micv_shim::disparity(false, left, right, windowRad, minDisparity, maxDisparity,
-                         MICV_STEREO_COLS_2R | MICV_STEREO_MIN_SSD_5E6, disparity);
+                         MICV_STEREO_COLS_2R | MICV_STEREO_MIN_SSD_5E6 | kStereoRolling, disparity);
 }
 inline void disparityNCorr(const Mat &left, const Mat &right, const size_t windowRad,
                            const int minDisparity, const int maxDisparity, Mat &disparity) {
     micv_shim::disparity(true, left, right, windowRad, minDisparity, maxDisparity,
-                         MICV_STEREO_COLS_2R, disparity);
+                         MICV_STEREO_COLS_2R | kStereoRolling, disparity);
 }
 inline void houghLinesAccumulate(const Mat &edgeMask, const unsigned int rhoBinSize,
                                  const unsigned int thetaBinSize, Mat &accumulator) {

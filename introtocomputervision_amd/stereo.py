@@ -3,11 +3,14 @@ ProblemSets/ps2_cpp/include/DisparitySSD.h:18-43, DisparityNCorr.h:19-44)."""
 import numpy as np
 
 from . import _buf as B
-from ._capi import STEREO_COLS_2R, STEREO_MIN_SSD_5E6, check, lib
+from ._capi import STEREO_COLS_2R, STEREO_MIN_SSD_5E6, STEREO_ROLLING, STEREO_SERIAL, check, lib
 from .lk import _ctx_for
 
-STEREO_SERIAL = 4
+# window and threshold of DisparitySSD.cu, every row's column sums formed afresh (the fast kernel)
 AS_WRITTEN_CUDA = STEREO_COLS_2R | STEREO_MIN_SSD_5E6
+# + the kernel's rolling subtract / add column sums down 40-row strips (DisparitySSD.cu:97-138): differs
+# from AS_WRITTEN_CUDA only on images that are not integer-valued
+AS_WRITTEN_CUDA_ROLLING = AS_WRITTEN_CUDA | STEREO_ROLLING
 
 
 def _run(dev_fn, host_fn, left, right, windowRad, minDisparity, maxDisparity, flags, ctx):

@@ -60,8 +60,13 @@ int orc_sobel(const float *src, int rows, int cols, size_t sstride, int ksize, f
 int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t stride,
                 int win, float *u, float *v, size_t ostride);
 
+/* cvRound(float) of the reference's x86-64 OpenCV 3.4.1 build: round half to even into 32 bits,
+ * INT_MIN ("integer indefinite") for NaN and for values that do not fit an int32. */
+int orc_cv_round(float v);
+
 /* cv::remap(src,dst,mapx,mapy,INTER_LINEAR) with BORDER_CONSTANT(0): 1/32-pixel
- * fixed-point coordinates, 4-tap float weights. */
+ * fixed-point coordinates cvRound(v * 32) (orc_cv_round: a NaN / infinite / out-of-range map
+ * entry gives the border constant), 4-tap float weights. */
 void orc_remap_linear(const float *src, int rows, int cols, size_t sstride,
                       const float *mapx, const float *mapy, size_t mstride,
                       float *dst, int drows, int dcols, size_t dstride);
@@ -133,6 +138,13 @@ int orc_sift_descriptors(const float *gx, const float *gy, int rows, int cols, s
 
 #define ORC_STEREO_COLS_2R     1  /* reproduce CUDA's `i < 2*windowRad` column count (DisparitySSD.cu:84) */
 #define ORC_STEREO_MIN_SSD_5E6 2  /* keep -1 where best SSD >= 5e6 (DisparitySSD.cu:16,177-178) */
+#define ORC_STEREO_ROLLING     8  /* column sums as the CUDA kernels keep them (DisparitySSD.cu:97-138,
+                                     DisparityNCorr.cu:117-173): rows are cut into strips of
+                                     ROWS_PER_THREAD = 40; the first row of a strip sums its 2r+1 terms
+                                     top -> bottom from 0, every further row takes the previous row's
+                                     column sum, subtracts the term that left the window and then adds
+                                     the one that entered it (two roundings per row, float).  Equal to
+                                     the fresh sums for integer-valued images, not for general f32. */
 
 /* disparitySSD.  CUDA-path addressing (clamp-to-edge textures, every d in [minD,maxD]
  * evaluated, strict '<' so the lowest d wins ties; DisparitySSD.cu:54-140) with the window

@@ -178,6 +178,17 @@ int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t
 
 static int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 
+/* cvRound(float) as OpenCV 3.4.1 executes it on the reference's x86-64 build (core/fast_math.hpp:
+ * _mm_cvtss_si32; the vector body of RemapInvoker uses _mm_cvtps_epi32): round half to even in
+ * 32 bits, and the "integer indefinite" value INT_MIN for a NaN and for every value whose rounded
+ * result does not fit an int32.  Written out so that it does not depend on sizeof(long) or on what
+ * lrintf() returns outside the int range.  With INT_MIN the map cell is (-2^26 -> saturate_cast<short>
+ * = -32768, fraction 0): every tap is outside the image and cv::remap writes the border constant. */
+int orc_cv_round(float v) {
+    if (!(v > -2147483648.f && v < 2147483648.f)) return (int)(-2147483647 - 1);
+    return (int)rintf(v); /* default rounding mode: to nearest even; the result fits an int */
+}
+
 /* cv::remap, CV_32FC1 maps, INTER_LINEAR, BORDER_CONSTANT(0)
  * (OpenCV 3.4.1 imgproc/src/imgwarp.cpp: RemapInvoker + remapBilinear<Cast<float,float>>). */
 void orc_remap_linear(const float *src, int rows, int cols, size_t sstride,
@@ -185,8 +196,8 @@ void orc_remap_linear(const float *src, int rows, int cols, size_t sstride,
                       float *dst, int drows, int dcols, size_t dstride) {
     for (int y = 0; y < drows; y++)
         for (int x = 0; x < dcols; x++) {
-            int sx = (int)lrintf(AT(mapx, mstride, y, x) * 32.f); /* cvRound(v*INTER_TAB_SIZE) */
-            int sy = (int)lrintf(AT(mapy, mstride, y, x) * 32.f);
+            int sx = orc_cv_round(AT(mapx, mstride, y, x) * 32.f); /* cvRound(v*INTER_TAB_SIZE) */
+            int sy = orc_cv_round(AT(mapy, mstride, y, x) * 32.f);
             int fx = sx & 31, fy = sy & 31;
             int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
             /* BilinearTab_f: 1-D taps {1 - k/32, k/32}, 2-D weight = vy*vx */

@@ -103,9 +103,75 @@ static float tex(const float *img, int rows, int cols, size_t stride, int x, int
     return AT(img, stride, clampi(y, 0, rows - 1), clampi(x, 0, cols - 1));
 }
 
+
+/* The CUDA kernels' rolling column sums (ORC_STEREO_ROLLING): DisparitySSD.cu:27-141 and
+ * DisparityNCorr.cu:28-175 restated strip by strip.  ncc = 0: SSD; ncc = 1: cross-correlation. */
+#define ORC_STEREO_STRIP 40 /* ROWS_PER_THREAD, DisparitySSD.cu:17 / DisparityNCorr.cu:17 */
+static int stereo_rolling(const float *left, const float *right, int rows, int cols, size_t stride,
+                          int rad, int min_d, int max_d, int flags, int ncc, int8_t *disp, size_t dstride) {
+    const int wcols = (flags & ORC_STEREO_COLS_2R) ? 2 * rad : 2 * rad + 1;
+    const size_t n = (size_t)(cols + 2 * rad);
+    float *cs = (float *)malloc(3 * n * sizeof(float));
+    float *best = (float *)malloc((size_t)ORC_STEREO_STRIP * cols * sizeof(float));
+    for (int y0 = 0; y0 < rows; y0 += ORC_STEREO_STRIP) {
+        const int nr = rows - y0 < ORC_STEREO_STRIP ? rows - y0 : ORC_STEREO_STRIP;
+        for (int j = 0; j < nr; j++)
+            for (int x = 0; x < cols; x++) {
+                best[(size_t)j * cols + x] = ncc ? 0.f : ((flags & ORC_STEREO_MIN_SSD_5E6) ? 5000000.f : INFINITY);
+                AT(disp, dstride, y0 + j, x) = -1;
+            }
+        for (int d = min_d; d <= max_d; d++) {
+            for (int j = 0; j < nr; j++) {
+                const int y = y0 + j;
+                for (int xc = -rad; xc < cols + rad; xc++) {
+                    float *p = cs + (xc + rad), *aa = p + n, *bb = p + 2 * n;
+                    if (j == 0) { /* :68-81 / :77-95: from 0, top -> bottom */
+                        *p = 0.f; *aa = 0.f; *bb = 0.f;
+                        for (int wy = -rad; wy <= rad; wy++) {
+                            float a = tex(left, rows, cols, stride, xc, y + wy);
+                            float b = tex(right, rows, cols, stride, xc + d, y + wy);
+                            if (ncc) { *p += a * b; *aa += a * a; *bb += b * b; }
+                            else { float diff = a - b; *p += diff * diff; }
+                        }
+                    } else { /* :101-109 / :120-134: minus the row that left, plus the row that entered */
+                        float a = tex(left, rows, cols, stride, xc, y - 1 - rad);
+                        float b = tex(right, rows, cols, stride, xc + d, y - 1 - rad);
+                        if (ncc) { *p -= a * b; *aa -= a * a; *bb -= b * b; }
+                        else { float diff = a - b; *p -= diff * diff; }
+                        a = tex(left, rows, cols, stride, xc, y + rad);
+                        b = tex(right, rows, cols, stride, xc + d, y + rad);
+                        if (ncc) { *p += a * b; *aa += a * a; *bb += b * b; }
+                        else { float diff = a - b; *p += diff * diff; }
+                    }
+                }
+                for (int x = 0; x < cols; x++) {
+                    float tot = 0.f, at = 0.f, ai = 0.f;
+                    for (int i = 0; i < wcols; i++) { /* left -> right */
+                        tot += cs[x + i];
+                        if (ncc) { at += cs[n + x + i]; ai += cs[2 * n + x + i]; }
+                    }
+                    float *b = best + (size_t)j * cols + x;
+                    if (ncc) {
+                        float nc = tot / sqrtf(at * ai); /* DisparityNCorr.cu:164 */
+                        if (nc > *b) { *b = nc; AT(disp, dstride, y, x) = (int8_t)d; }
+                    } else if (tot < *b) { /* DisparitySSD.cu:133 */
+                        *b = tot;
+                        AT(disp, dstride, y, x) = (int8_t)d;
+                    }
+                }
+            }
+        }
+    }
+    free(cs);
+    free(best);
+    return 0;
+}
+
 int orc_disparity_ssd(const float *left, const float *right, int rows, int cols, size_t stride,
                       int rad, int min_d, int max_d, int flags, int8_t *disp, size_t dstride) {
     if (rad < 0 || rad > 31 || min_d > max_d || min_d < -128 || max_d > 127) return -1;
+    if (flags & ORC_STEREO_ROLLING)
+        return stereo_rolling(left, right, rows, cols, stride, rad, min_d, max_d, flags, 0, disp, dstride);
     int wcols = (flags & ORC_STEREO_COLS_2R) ? 2 * rad : 2 * rad + 1; /* DisparitySSD.cu:84 */
     float *colsum = (float *)malloc((size_t)(cols + 2 * rad) * sizeof(float));
     for (int y = 0; y < rows; y++) {
@@ -172,6 +238,8 @@ int orc_disparity_ssd_serial(const float *left, const float *right, int rows, in
 int orc_disparity_ncorr(const float *left, const float *right, int rows, int cols, size_t stride,
                         int rad, int min_d, int max_d, int flags, int8_t *disp, size_t dstride) {
     if (rad < 0 || rad > 31 || min_d > max_d || min_d < -128 || max_d > 127) return -1;
+    if (flags & ORC_STEREO_ROLLING)
+        return stereo_rolling(left, right, rows, cols, stride, rad, min_d, max_d, flags, 1, disp, dstride);
     int wcols = (flags & ORC_STEREO_COLS_2R) ? 2 * rad : 2 * rad + 1; /* DisparityNCorr.cu:99 */
     size_t n = (size_t)(cols + 2 * rad);
     float *cs = (float *)malloc(3 * n * sizeof(float));

@@ -54,6 +54,7 @@ def _sig(name, res, args):
 
 
 _reflect = _sig("orc_reflect101", i32, [i32, i32])
+_cvround = _sig("orc_cv_round", i32, [f32])
 _gk = _sig("orc_gaussian_kernel", None, [i32, f64, vp])
 _sep = _sig("orc_sep_filter", None, [vp, i32, i32, sz, vp, i32, vp, i32, vp, sz])
 _sobel = _sig("orc_sobel", i32, [vp, i32, i32, sz, i32, f32, vp, vp, sz])
@@ -70,6 +71,10 @@ _togray = _sig("orc_to_gray_f32", i32, [vp, i32, i32, sz, i32, i32, vp, sz])
 
 def reflect101(p, n):
     return _reflect(p, n)
+
+
+def cv_round(v):
+    return _cvround(float(np.float32(v)))
 
 
 def gaussian_kernel(n, sigma):

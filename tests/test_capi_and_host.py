@@ -119,3 +119,39 @@ def test_no_environment_knobs_in_the_default_build():
     blob = open(so, "rb").read()
     for knob in (b"MICV_LK_STOP", b"MICV_LK_GROUPS", b"MICV_FORCE_GENERIC", b"MICV_LK_NT"):
         assert knob not in blob, knob
+
+
+def _schedule(rows, cols, batch, win, max_chain):
+    import ctypes as C
+    from introtocomputervision_amd import _capi
+    n, tw, th = _capi.i64(), _capi.i32(), _capi.i32()
+    _capi.check(_capi.lib.micv_lk_schedule_host(rows, cols, batch, win, max_chain, None, 0, C.byref(n),
+                                                C.byref(tw), C.byref(th)))
+    buf = np.zeros((n.value, 4), np.int32)
+    _capi.check(_capi.lib.micv_lk_schedule_host(rows, cols, batch, win, max_chain, buf.ctypes.data, n.value,
+                                                C.byref(n), C.byref(tw), C.byref(th)))
+    return buf, tw.value, th.value
+
+
+@pytest.mark.parametrize("win", [15, 11, 7])
+def test_chain_schedule_covers_every_tile_exactly_once(win):
+    """the schedule of the chain / streamed launches probed column tiles_x/2 for the
+    interior rows; for cols 194..206 that column is not x-interior and the interior tiles of column 1
+    were never scheduled.  Host-only check over the widths around every tile-count change."""
+    shapes = [(200, 400), (400, 200), (200, 194), (200, 206), (270, 480), (135, 240), (540, 960), (1080, 1920),
+              (33, 64), (64, 65), (300, 129), (97, 333)]
+    shapes += [(200, c) for c in range(120, 330, 7)] + [(r, 200) for r in range(40, 300, 13)]
+    for rows, cols in shapes:
+        for batch in (1, 3):
+            for max_chain in (1, 2, 4, 32):
+                sched, tw, th = _schedule(rows, cols, batch, win, max_chain)
+                assert len(sched) % 8 == 0
+                tiles_x, tiles_y = -(-cols // tw), -(-rows // th)
+                seen = np.zeros((batch, tiles_y, tiles_x), np.int32)
+                for x, y, cnt, p in sched:
+                    assert 0 <= cnt <= max_chain
+                    if cnt == 0:
+                        continue
+                    assert 0 <= p < batch and 0 <= x < tiles_x and 0 <= y and y + cnt <= tiles_y, (rows, cols, x, y, cnt)
+                    seen[p, y:y + cnt, x] += 1
+                assert (seen == 1).all(), (win, rows, cols, batch, max_chain, np.argwhere(seen != 1)[:5])

@@ -138,3 +138,59 @@ def test_hough_votes_and_peaks():
     cy, cx, r = circles[0]
     py, px = np.unravel_index(ca.argmax(), ca.shape)
     assert abs(py - cy) <= 2 and abs(px - cx) <= 2
+
+
+def test_cv_round_is_the_32_bit_sse_conversion():
+    """cvRound as cv::remap executes it on the reference's x86-64 build (_mm_cvtss_si32 /
+    _mm_cvtps_epi32): half to even, INT_MIN for NaN and for anything that does not fit an int32
+    (`(int)lrintf()` wrapped mod 2^32 on this LP64 host)."""
+    INT_MIN = -2 ** 31
+    kat = [(0.5, 0), (1.5, 2), (2.5, 2), (-0.5, 0), (-1.5, -2), (-2.5, -2), (31.49, 31), (1e6 + 0.5, 1000000),
+           (2147483520.0, 2147483520), (-2147483520.0, -2147483520),
+           (2147483648.0, INT_MIN), (-2147483648.0, INT_MIN), (3e9 * 32, INT_MIN), (-3e9 * 32, INT_MIN),
+           (1e30, INT_MIN), (float("inf"), INT_MIN), (float("-inf"), INT_MIN), (float("nan"), INT_MIN)]
+    for v, want in kat:
+        assert orc.cv_round(v) == want, (v, orc.cv_round(v), want)
+    rng = np.random.default_rng(5)
+    for v in (rng.standard_normal(2000) * 1e5).astype(np.float32):
+        assert orc.cv_round(v) == int(np.rint(np.float64(v)))  # numpy rint = half to even
+
+
+def test_remap_of_non_finite_and_far_coordinates_is_the_border_constant():
+    img = synth.smooth_noise(4, 20, 30) + 1.0  # strictly positive: a sampled pixel could not be 0
+    mx = np.tile(np.arange(30, dtype=np.float32), (20, 1))
+    my = np.tile(np.arange(20, dtype=np.float32)[:, None], (1, 30))
+    base = orc.remap_linear(img, mx, my)
+    assert np.array_equal(base, img)
+    bad = [np.nan, np.inf, -np.inf, 3e9, -3e9, 2.0 ** 26, -(2.0 ** 26), 1e30, 6.8e7, -6.8e7]
+    for k, b in enumerate(bad):
+        for which in (0, 1):
+            m = [mx.copy(), my.copy()]
+            m[which][3 + k, 4] = b
+            out = orc.remap_linear(img, m[0], m[1])
+            assert out[3 + k, 4] == 0.0 and not np.signbit(out[3 + k, 4]), (b, which, out[3 + k, 4])
+            out[3 + k, 4] = img[3 + k, 4]
+            assert np.array_equal(out, img)
+
+
+@pytest.mark.parametrize("ncc", [False, True])
+def test_rolling_column_sums_equal_fresh_sums_on_integer_images_only(ncc):
+    """ORC_STEREO_ROLLING (DisparitySSD.cu:97-138): subtract / add column sums down 40-row strips.
+    Integer-valued images: every partial sum is exact, so the disparities equal the fresh-sum ones.
+    General f32 images: the two round differently and some pixels flip."""
+    fn = orc.disparity_ncorr if ncc else orc.disparity_ssd
+    l, r, _ = synth.stereo_pair(3, 95, 150)  # spans three strips, the last one short
+    small = (l % 16).astype(np.float32), (r % 16).astype(np.float32)  # NCC's sums stay below 2^24
+    for flags in (0, 1 | 2):
+        a = fn(*small, 3, -12, 4, flags)
+        b = fn(*small, 3, -12, 4, flags | 8)
+        assert np.array_equal(a, b), flags
+    rng = np.random.default_rng(9)
+    lf = (l * (1 + 1e-3 * rng.standard_normal(l.shape))).astype(np.float32)
+    # a nearly periodic right image: many near-ties, so last-bit differences decide some pixels
+    rf = np.roll(lf, 5, axis=1) * np.float32(1.0000001)
+    a = fn(lf, rf, 3, -12, 4, 0)
+    b = fn(lf, rf, 3, -12, 4, 8)
+    assert a.shape == b.shape and b.min() >= -12 and b.max() <= 4
+    # strip starts are fresh sums in both: rows 0, 40, 80 agree everywhere
+    assert np.array_equal(a[[0, 40, 80]], b[[0, 40, 80]])
