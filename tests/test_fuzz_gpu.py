@@ -33,13 +33,19 @@ def host(t):
 
 
 def same(a, b):
+    """True when equal (float32: equal bit patterns, NaN == NaN); otherwise raises with the first cells."""
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
-    if a.shape != b.shape or a.dtype != b.dtype:
-        return False
+    assert a.shape == b.shape and a.dtype == b.dtype, (a.shape, b.shape, a.dtype, b.dtype)
     if a.dtype != np.float32:
-        return np.array_equal(a, b)
-    na, nb = np.isnan(a), np.isnan(b)
-    return np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
+        bad = a != b
+    else:
+        na, nb = np.isnan(a), np.isnan(b)
+        bad = (na != nb) | (~na & ~nb & (a.view(np.uint32) != b.view(np.uint32)))
+    if bad.any():
+        idx = np.argwhere(bad)
+        raise AssertionError(f"{len(idx)} of {a.size} cells differ, first {idx[:5].tolist()}: "
+                             f"got {a[bad][:5].tolist()}, want {b[bad][:5].tolist()}")
+    return True
 
 
 def image(seed, rows, cols, kind):
@@ -62,7 +68,7 @@ seed = st.integers(0, 2 ** 31 - 1)
 kind = st.integers(0, 3)
 
 
-@settings(max_examples=40, **COMMON)
+@settings(max_examples=300, **COMMON)
 @given(shape, pad, seed, kind, st.sampled_from([1, 3, 5, 7, 11, 15, 21, 23, 43]), st.integers(1, 5), st.booleans())
 def test_fuzz_lk(shape, pad, seed, kind, win, levels, shift):
     from introtocomputervision_amd import lk
@@ -74,11 +80,13 @@ def test_fuzz_lk(shape, pad, seed, kind, win, levels, shift):
     gu, gv = lk.calcOpticalFlowPyr(dev(prev, pad), dev(nxt, pad), winSize=win, levels=levels)
     assert same(host(gu), eu) and same(host(gv), ev), (rows, cols, pad, win, levels)
     if levels == 1:
+        # the single-level function returns the solve's own values (a -0 stays -0; the pyramid adds it to a +0 base)
         su, sv = lk.calcOpticalFlow(dev(prev, pad), dev(nxt, pad), winSize=win)
-        assert same(host(su), eu) and same(host(sv), ev)
+        e1u, e1v = orc.lk_flow(prev, nxt, win)
+        assert same(host(su), e1u) and same(host(sv), e1v)
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=200, **COMMON)
 @given(shape, pad, seed, st.floats(0.0, 40.0), st.booleans())
 def test_fuzz_warp_pyr_resize(shape, pad, seed, amp, wild):
     from introtocomputervision_amd import lk, pyr
@@ -103,7 +111,7 @@ def test_fuzz_warp_pyr_resize(shape, pad, seed, amp, wild):
         assert same(host(g), e)
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=200, **COMMON)
 @given(shape, pad, seed, kind, st.sampled_from([1, 3, 5, 7]), st.sampled_from([3, 5, 7, 9]),
        st.floats(0.5, 3.0), st.integers(1, 9))
 def test_fuzz_harris(shape, pad, seed, kind, ksize, window, sigma, min_dist):
@@ -122,7 +130,7 @@ def test_fuzz_harris(shape, pad, seed, kind, ksize, window, sigma, min_dist):
     assert same(host(corners), ecorners) and np.array_equal(host(locs), elocs)
 
 
-@settings(max_examples=30, **COMMON)
+@settings(max_examples=300, **COMMON)
 @given(st.tuples(st.integers(1, 100), st.integers(1, 150)), pad, seed, st.integers(0, 12), st.integers(-40, 20),
        st.integers(0, 40), st.sampled_from([0, 1, 2, 3, 8, 9, 11]), st.booleans(), st.booleans())
 def test_fuzz_stereo(shape, pad, seed, rad, min_d, span, flags, ncc, integer):
@@ -146,7 +154,7 @@ def test_fuzz_stereo(shape, pad, seed, rad, min_d, span, flags, ncc, integer):
     assert np.array_equal(host(got), exp), (rows, cols, rad, min_d, max_d, flags, ncc, int((host(got) != exp).sum()))
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=150, **COMMON)
 @given(st.tuples(st.integers(2, 120), st.integers(2, 160)), pad, seed, st.floats(0.0, 0.2), st.integers(1, 3),
        st.integers(1, 5), st.integers(1, 30), st.integers(1, 20))
 def test_fuzz_hough(shape, pad, seed, density, rho_bin, theta_bin, radius, num_peaks):
