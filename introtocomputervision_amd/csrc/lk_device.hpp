@@ -78,31 +78,46 @@ __device__ __forceinline__ int cv_round_i32(float v) {
 // The same sample, with the four taps served from an LDS copy of `next` when they fall inside
 // the staged window [nx0, nx0+NW) x [ny0, ny0+NH) (which must lie inside the image) and from
 // global memory otherwise.  Coordinates, weights and the blend are identical to warp_sample.
-template <int NW, int NH>
+//
+// xy32 = (32 x, 32 y) of the pixel (exact floats: the caller counts in float), flow = (du, dv).
+//  * cv::remap's fixed-point coordinate is cvRound((x + du) * 32).  (x + du) * 32 = fma(du, 32, 32 x)
+//    bit for bit: scaling by 32 is exact, so both round the same real number once (over- and underflow
+//    included: x is an integer, so x + du is subnormal only for x = 0, where both are exact).  One
+//    packed fma for both coordinates instead of a packed add and a packed multiply.
+//  * With r = rndne(t) (the float the conversion rounds to) and q = r / 32 (exact), the map cell is
+//    floor(q) and the 5-bit fraction over 32 is q - floor(q): one v_cvt_flr_i32_f32 and one
+//    v_fract_f32 per coordinate replace convert, shift, mask, convert back and scale (r03: 36 -> 30
+//    VALU instructions per warped pixel).  Both are exact for every finite r (q has at most five
+//    fraction bits); an infinite or NaN coordinate never gets that far (see the window test).
+//  * FS = 32 for a flow given as such; FS = 64 when the caller hands over HALF the flow (pyrUp's value
+//    before OpticalFlow.cpp:142's "* 2"): (2 a) * 32 = a * 64 exactly, so the doubling costs nothing
+//    where only the warp needs it (the halo pixels of a tile).
+template <int NW, int NH, int FS = 32>
 __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N, int nx0, int ny0,
                                                     const float *__restrict__ src, int rows,
-                                                    int cols, int stride, float xf, float yf, float du,
-                                                    float dv) {
-    // (xf, yf) = the pixel's coordinates already as floats (exact: the caller counts rows in float)
-    const float mx = xf + du, my = yf + dv;
-    const float tx = mx * 32.f, ty = my * 32.f;
-    // The saturating conversion serves the window test: a coordinate beyond the int range lands far
-    // outside the window either way (INT_MAX >> 5 or INT_MIN >> 5 against cvRound's INT_MIN >> 5), and
-    // inside the window it is cvRound exactly.  Only a NaN needs help -- it converts to 0, which may
-    // well be a window cell -- and gets it from ONE ordered compare of both coordinates.
-    const int sx = __float2int_rn(tx), sy = __float2int_rn(ty);
-    const bool ordered = !__builtin_isunordered(tx, ty);
-    const int fx = sx & 31, fy = sy & 31;
-    const float ax1 = (float)fx * 0.03125f, ay1 = (float)fy * 0.03125f;
-    // weights as aligned pairs, so the four weight products and the four tap products are two packed
-    // multiplies each with a broadcast operand (the scalar form made the compiler shuffle halves)
+                                                    int cols, int stride,
+                                                    float __attribute__((ext_vector_type(2))) xy32,
+                                                    float __attribute__((ext_vector_type(2))) flow) {
     typedef float v2f_ __attribute__((ext_vector_type(2)));
-    const v2f_ X = {1.f - ax1, ax1}, Y = {1.f - ay1, ay1};
-    float v0, v1, v2, v3;
+    const v2f_ t = __builtin_elementwise_fma(flow, (v2f_){(float)FS, (float)FS}, xy32);
+    const v2f_ r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};  // v_rndne_f32
+    const v2f_ q = r * (v2f_){0.03125f, 0.03125f};
+    // The saturating floor-conversion serves the window test: a coordinate beyond the int range lands
+    // far outside the window (INT_MAX or INT_MIN against a window a few dozen cells wide: the
+    // subtraction may wrap, it cannot wrap INTO the window), and inside the window the cell is
+    // cvRound(t) >> 5 exactly.  Only a NaN needs help -- it converts to 0, which may well be a window
+    // cell -- and gets it from ONE ordered compare of both coordinates.
+    int ix, iy;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix) : "v"(q.x));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy) : "v"(q.y));
+    const bool ordered = !__builtin_isunordered(t.x, t.y);
+    float ax1, ay1, v0, v1, v2, v3;
     // the 16-bit clamp of cv::remap's integer map only matters outside the window: the window test
-    // runs on the unclamped cell (no wrap: |sx >> 5| < 2^26), the clamp moves into the fallback
-    const int lx = (sx >> 5) - nx0, ly = (sy >> 5) - ny0;
+    // runs on the unclamped cell, the clamp moves into the fallback
+    const int lx = ix - nx0, ly = iy - ny0;
     if (ordered && (unsigned)lx < (unsigned)(NW - 1) && (unsigned)ly < (unsigned)(NH - 1)) {
+        ax1 = __builtin_amdgcn_fractf(q.x);
+        ay1 = __builtin_amdgcn_fractf(q.y);
         // cell index by one full-rate 24-bit multiply-add (a plain `ly * NW + lx` turns into the
         // quarter-rate v_mul_lo_u32, and LLVM folds __mul24 and shift pairs back into it), and the
         // address as ONE register the four taps hang off by immediate offsets (two ds_read2_b32;
@@ -119,26 +134,30 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
         v2 = p[NW];
         v3 = p[NW + 1];
     } else {
-        // cvRound proper.  Where it differs from the conversion above (NaN, beyond the int range) every
-        // tap is the border constant 0 and the weights formed from the other value's fraction bits do
-        // not matter: they are finite and non-negative, the sample is +0 either way.
-        const int cx = cv_round_i32(tx), cy = cv_round_i32(ty);
-        const int ix = clampi(cx >> 5, -32768, 32767), iy = clampi(cy >> 5, -32768, 32767);
-        const bool x0 = (unsigned)ix < (unsigned)cols, x1 = (unsigned)(ix + 1) < (unsigned)cols;
-        const bool y0 = (unsigned)iy < (unsigned)rows, y1 = (unsigned)(iy + 1) < (unsigned)rows;
-        const float *p = src + (ptrdiff_t)iy * stride + ix;
+        // cvRound proper (INT_MIN for NaN and beyond the int range: every tap is then the border
+        // constant), cell and fraction from its integer result as cv::remap forms them
+        const int cx = cv_round_i32(t.x), cy = cv_round_i32(t.y);
+        ax1 = (float)(cx & 31) * 0.03125f;
+        ay1 = (float)(cy & 31) * 0.03125f;
+        const int gx = clampi(cx >> 5, -32768, 32767), gy = clampi(cy >> 5, -32768, 32767);
+        const bool x0 = (unsigned)gx < (unsigned)cols, x1 = (unsigned)(gx + 1) < (unsigned)cols;
+        const bool y0 = (unsigned)gy < (unsigned)rows, y1 = (unsigned)(gy + 1) < (unsigned)rows;
+        const float *p = src + (ptrdiff_t)gy * stride + gx;
         v0 = (x0 && y0) ? p[0] : 0.f;
         v1 = (x1 && y0) ? p[1] : 0.f;
         v2 = (x0 && y1) ? p[stride] : 0.f;
         v3 = (x1 && y1) ? p[stride + 1] : 0.f;
     }
+    // weights as aligned pairs, so the four weight products and the four tap products are two packed
+    // multiplies each with a broadcast operand (the scalar form made the compiler shuffle halves)
+    const v2f_ X = {1.f - ax1, ax1}, Y = {1.f - ay1, ay1};
     // r = v0*(ay0*ax0) + v1*(ay0*ax1) + v2*(ay1*ax0) + v3*(ay1*ax1), summed left to right
     const v2f_ w0 = (v2f_){Y.x, Y.x} * X, w1 = (v2f_){Y.y, Y.y} * X;
     const v2f_ p0 = (v2f_){v0, v1} * w0, p1 = (v2f_){v2, v3} * w1;
-    float r = p0.x + p0.y;
-    r = r + p1.x;
-    r = r + p1.y;
-    return r;
+    float s = p0.x + p0.y;
+    s = s + p1.x;
+    s = s + p1.y;
+    return s;
 }
 
 // lk::warp (OpticalFlow.cpp:111-119) for one pixel: map = (x + du, y + dv); cv::remap

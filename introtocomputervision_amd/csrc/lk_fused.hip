@@ -588,7 +588,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             asm("" : "+s"(nx0s), "+s"(ny0s));
             auto march = [&](int lx, int ly0, float *bu8, float *bv8) {
                 const int gx = rx0 + lx, gy0 = ry0 + ly0;
-                const float xf = (float)gx, yf0 = (float)gy0;
+                // 32 x and 32 y of the job's first pixel, as floats (exact; rows advance by adding 32)
+                const float xf32 = 32.f * (float)gx, yf32 = 32.f * (float)gy0;
                 // one address register for the job's four stores (rows at immediate offsets)
                 typedef __attribute__((address_space(3))) float lds_float;
                 lds_float *wrow = (lds_float *)(Wp + ly0 * PS + lx);
@@ -654,30 +655,37 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     for (int o = 0; o < 2; o++) {
                         const int j = 2 * p + o;
                         float bu, bv;
+                        v2f half_uv;  // MODE COARSE: pyrUp's value before the "* 2" of OpticalFlow.cpp:142,144
                         if (MODE == LK_FLOW_COARSE) {
                             const int i1 = o ? p + 1 : p, i3 = o ? p + 2 : p + 1;
-                            // border tiles: tap 0 of image row 0 and tap 4 of image row rows-1 (see above)
-                            const v2f r0 = (!INT && gy0 + j == 0) ? ruv[p + 2] : ruv[p];
-                            const v2f r4 = (!INT && gy0 + j == rows - 1) ? ruv[p] : ruv[p + 2];
+                            // border tiles: tap 0 of image row 0 and tap 4 of image row rows-1 (see above).
+                            // The two candidates go through an opaque copy: LLVM otherwise rewrites the
+                            // select of two array elements as an indexed read of ruv[] = 16 v_cndmask each.
+                            v2f ra = ruv[p], rc = ruv[p + 2];
+                            if (!INT) asm("" : "+v"(ra), "+v"(rc));
+                            const v2f r0 = (!INT && gy0 + j == 0) ? rc : ra;
+                            const v2f r4 = (!INT && gy0 + j == rows - 1) ? ra : rc;
                             v2f auv = r0 * (v2f){g5[0], g5[0]};
                             auv = __builtin_elementwise_fma(ruv[i1], (v2f){g5[1], g5[1]}, auv);
                             auv = __builtin_elementwise_fma(ruv[p + 1], (v2f){g5[2], g5[2]}, auv);
                             auv = __builtin_elementwise_fma(ruv[i3], (v2f){g5[3], g5[3]}, auv);
                             auv = __builtin_elementwise_fma(r4, (v2f){g5[4], g5[4]}, auv);
+                            half_uv = auv;
                             auv = auv * (v2f){2.f, 2.f};  // OpticalFlow.cpp:142,144
                             bu = auv.x;
                             bv = auv.y;
                         } else {
                             bu = fu_[j];
                             bv = fv_[j];
+                            half_uv = (v2f){bu, bv};
                         }
                         bu8[j] = bu;
                         bv8[j] = bv;
                         // warp right away: the flow pair's live range ends here.  Carry tiles need
                         // the warped image from region row LYC on (the base flow of every own row)
                         if (!CARRY || ly0 + j >= LY0)
-                            wrow[j * PS] = warp_sample_staged<NW, NH>(
-                                Nx, nx0s, ny0s, next, rows, cols, istride, xf, yf0 + (float)j, bu, bv);
+                            wrow[j * PS] = warp_sample_staged<NW, NH, MODE == LK_FLOW_COARSE ? 64 : 32>(
+                                Nx, nx0s, ny0s, next, rows, cols, istride, (v2f){xf32, yf32 + 32.f * (float)j}, half_uv);
                         // 512-thread tiles run at a 128-VGPR budget: keep the rows from interleaving
                         if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
                     }
