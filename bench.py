@@ -119,6 +119,8 @@ def parse_args(argv=None):
                          "passes of tools/profile.sh use 1 so a level-0 dispatch covers the whole batch")
     ap.add_argument("--lk-chain", type=int, default=0,
                     help="MICV_OPT_LK_CHAIN of every context: 0 = the library's rule, 1 = no tile chains, n = longest chain")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="micv_ctx_set_option on every context, e.g. --opt OPT_LK_TALL_TILES=1 (A/B and PMC runs)")
     ap.add_argument("--preroll-s", type=float, default=0.25,
                     help="seconds of untimed steps before the warm-up steps (clock pre-roll; 0 = none)")
     ap.add_argument("--sustained-s", type=float, default=2.0,
@@ -276,6 +278,12 @@ def main(argv=None):
     ctx.set_lk_groups(args.lk_groups)
     from introtocomputervision_amd import _capi as _c
     ctx.set_option(_c.OPT_LK_CHAIN, args.lk_chain)
+
+    def apply_opts(c):
+        for kv in args.opt:
+            k, v = kv.split("=")
+            c.set_option(getattr(_c, k), int(v))
+    apply_opts(ctx)
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     if args.mode == "rowshard":
@@ -302,6 +310,7 @@ def main(argv=None):
             lanes.append((Context(local_rank), torch.cuda.Stream(dev), (torch.empty_like(prev), torch.empty_like(prev))))
             lanes[-1][0].set_lk_groups(args.lk_groups)
             lanes[-1][0].set_option(_c.OPT_LK_CHAIN, args.lk_chain)
+            apply_opts(lanes[-1][0])
         counter = [0]
 
         def step():

@@ -111,7 +111,7 @@ struct micv_ctx {
     std::vector<IoBlock> io_cache;
     // Tile-chain schedules of the fused LK level kernel (lk_fused.hip), one per launch shape.
     struct LkSched {
-        int rows, cols, batch, r, max_chain;
+        int rows, cols, batch, r, max_chain, th;
         void *dev;
         int nblocks;
     };

@@ -175,6 +175,7 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
         a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
+        a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
         bool out_in_cur = false;
         if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
         if (level == 0) {
@@ -414,6 +415,7 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
         a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
+        a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
         return launch_lk_level_fused(s, a);
     }
     void *scratch;
@@ -465,6 +467,7 @@ int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next,
         a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
         a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
         a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
+        a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
         a.flow_pair = 0;
         if (!flow_u) {
             a.mode = LK_FLOW_NONE;

@@ -104,6 +104,10 @@ struct LkCfg {
     static constexpr bool FAST = (H % RPT == 0) && (RW % 4 == 0);
 };
 
+// Second argument of __launch_bounds__ (waves per SIMD the register allocation must allow): 512-thread
+// tiles run two workgroups per CU, the 1024-thread 64x64 tile one -- four waves per SIMD either way.
+constexpr int lk_waves_per_simd(int nt) { return nt >= 1024 ? 4 : nt / 128; }
+
 // ---- phase 4 building blocks ------------------------------------------------------------------
 
 // Row-buffer addressing: row q, 16-byte chunk ch lives at chunk (ch ^ 2*(q&3)).  The row
@@ -166,25 +170,26 @@ __device__ __forceinline__ void pk_fma_skew(v2f &acc, v2f p, v2f gpair) {
         asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(p), "s"(gpair));
 }
 
-template <typename C, int J, int S>
-__device__ __forceinline__ void skew_step(v2f &acc, const v2f (&P)[C::WV * 2], const TapsN<C::W> &g) {
-    constexpr int I = J + S;  // index of the product both lanes use at this step
+template <int W, int NP, int J, int S>
+__device__ __forceinline__ void skew_step(v2f &acc, const v2f (&P)[NP], const TapsN<W> &g) {
+    constexpr int I = J + S;  // index of the value both lanes use at this step
+    static_assert(I < 2 * NP, "skewed chain reads inside its window");
     const float pv = (I & 1) ? P[I >> 1].y : P[I >> 1].x;
     if (S == 0) {
         acc.x = fmaf(pv, g.k[0], 0.f);  // output J, tap 0; output J+1 has not started
         acc.y = 0.f;
-    } else if (S == C::W) {
-        acc.y = fmaf(pv, g.k[C::W - 1], acc.y);  // output J+1, last tap; output J is complete
+    } else if (S == W) {
+        acc.y = fmaf(pv, g.k[W - 1], acc.y);  // output J+1, last tap; output J is complete
     } else {
         const v2f gp = {g.k[S - 1], g.k[S]};
         pk_fma_skew<I & 1>(acc, P[I >> 1], gp);
     }
 }
 
-template <typename C, int J, int... S>
-__device__ __forceinline__ void skew_chain(v2f &acc, const v2f (&P)[C::WV * 2], const TapsN<C::W> &g,
+template <int W, int NP, int J, int... S>
+__device__ __forceinline__ void skew_chain(v2f &acc, const v2f (&P)[NP], const TapsN<W> &g,
                                            std::integer_sequence<int, S...>) {
-    (skew_step<C, J, S>(acc, P, g), ...);
+    (skew_step<W, NP, J, S>(acc, P, g), ...);
 }
 
 // Four adjacent outputs of the row pass of the product field a*b, windows given as aligned pairs.
@@ -195,8 +200,8 @@ __device__ __forceinline__ void row_taps_skew(const v2f (&a)[C::WV * 2], const v
 #pragma unroll
     for (int i = 0; i < C::WV * 2; i++) P[i] = a[i] * b[i];  // v_pk_mul_f32, each product once
     v2f acc0, acc1;
-    skew_chain<C, 0>(acc0, P, g, std::make_integer_sequence<int, C::W + 1>{});
-    skew_chain<C, 2>(acc1, P, g, std::make_integer_sequence<int, C::W + 1>{});
+    skew_chain<C::W, C::WV * 2, 0>(acc0, P, g, std::make_integer_sequence<int, C::W + 1>{});
+    skew_chain<C::W, C::WV * 2, 2>(acc1, P, g, std::make_integer_sequence<int, C::W + 1>{});
     *reinterpret_cast<float4 *>(out) = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
 }
 
@@ -212,21 +217,36 @@ __device__ __forceinline__ void load_window_pairs(const float *__restrict__ A, i
     }
 }
 
-// Column pass: thread (c, r0) produces 8 vertically adjacent window sums from one row buffer.
+// Column pass: thread (c, r0) produces RPT vertically adjacent window sums from one row buffer.
+// The outputs go in pairs (j, j + 1) through the same skewed packed chain as the row pass (r03): at
+// step s output j takes tap s and output j + 1 tap s - 1, both on the staged value v[j + s], so every
+// FMA of the pass is one lane of a v_pk_fma_f32 and each output still runs its own chain over taps
+// 0..2R in order -- the bits of the scalar loop it replaces (4 x 15 v_fma_f32 -> 2 x 16 packed).
+template <typename C, int... PJ>
+__device__ __forceinline__ void col_pairs(const v2f (&V)[(C::RPT + 2 * C::R + 1) / 2], float (&S)[C::RPT],
+                                          const TapsN<C::W> &g, std::integer_sequence<int, PJ...>) {
+    constexpr int NP = (C::RPT + 2 * C::R + 1) / 2;
+    v2f acc[C::RPT / 2];
+    (skew_chain<C::W, NP, 2 * PJ>(acc[PJ], V, g, std::make_integer_sequence<int, C::W + 1>{}), ...);
+#pragma unroll
+    for (int i = 0; i < C::RPT / 2; i++) {
+        S[2 * i] = acc[i].x;
+        S[2 * i + 1] = acc[i].y;
+    }
+}
+
 template <typename C>
 __device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S)[C::RPT],
                                          const TapsN<C::W> &g, int c, int r0) {
-    constexpr int R = C::R;
-    float v[C::RPT + 2 * R];
+    constexpr int R = C::R, NV = C::RPT + 2 * R, NP = (NV + 1) / 2;
+    static_assert(C::RPT % 2 == 0, "column outputs in pairs");
+    v2f V[NP];
 #pragma unroll
-    for (int i = 0; i < C::RPT + 2 * R; i++) v[i] = rb[rb_off(r0 + i, c >> 2) + (c & 3)];
-#pragma unroll
-    for (int j = 0; j < C::RPT; j++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < C::W; k++) acc = fmaf(v[j + k], g.k[k], acc);
-        S[j] = acc;
+    for (int i = 0; i < NP; i++) {
+        V[i].x = rb[rb_off(r0 + 2 * i, c >> 2) + (c & 3)];
+        V[i].y = 2 * i + 1 < NV ? rb[rb_off(r0 + 2 * i + 1, c >> 2) + (c & 3)] : 0.f;
     }
+    col_pairs<C>(V, S, g, std::make_integer_sequence<int, C::RPT / 2>{});
 }
 
 // ---- the tile body ---------------------------------------------------------------------------
@@ -1091,7 +1111,7 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
 }
 
 template <int R, int MODE, int NTV, int THV = 32>
-__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+__global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
     using C = LkCfg<R, NTV, THV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int E = C::M > 2 ? C::M : 2;
@@ -1111,7 +1131,7 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_kernel(LkLevelArgs a,
 // tile_y, count, pair), carrying the gradient rows from one tile to the next.  A 1-D grid: the
 // host-built schedule already contains the batch, the XCD-aware placement and the order of issue.
 template <int R, int NTV>
-__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_chain_kernel(LkLevelArgs a, TapsN<2 * R + 1> g,
+__global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_chain_kernel(LkLevelArgs a, TapsN<2 * R + 1> g,
                                                                         const int4 *__restrict__ sched) {
     using C = LkCfg<R, NTV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1140,11 +1160,11 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_chain_kernel(LkLevelA
 // is DMA'd at its own start but not awaited until the warp phase is over (in-kernel stamps of the
 // plain launch: a tile spends 32 % of its life waiting for phase 0).  tickets[0..7] = per-XCD
 // counters, tickets[8] = workgroups that have left; the last one out zeroes them for the next launch.
-template <int R, int NTV>
-__global__ __launch_bounds__(NTV, NTV / 128) void lk_level_stream_kernel(LkLevelArgs a, TapsN<2 * R + 1> g,
+template <int R, int NTV, int THV = 32>
+__global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_stream_kernel(LkLevelArgs a, TapsN<2 * R + 1> g,
                                                                          const int4 *__restrict__ sched, int per_xcd,
                                                                          unsigned *__restrict__ tickets) {
-    using C = LkCfg<R, NTV>;
+    using C = LkCfg<R, NTV, THV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int slot;
     const int tid = threadIdx.x;
@@ -1183,7 +1203,7 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_stream_kernel(LkLevel
                 __syncthreads();
             }
             flush();  // the previous tile's stores ride behind this tile's first phases
-            lk_tile<R, LK_FLOW_COARSE, true, NTV, false, 32, true>(a, g, lds, e.x, e.y, e.w, false, &link);
+            lk_tile<R, LK_FLOW_COARSE, true, NTV, false, THV, true>(a, g, lds, e.x, e.y, e.w, false, &link);
             pending = e;
             e = link.next;
             staged = link.next_staged;
@@ -1191,7 +1211,7 @@ __global__ __launch_bounds__(NTV, NTV / 128) void lk_level_stream_kernel(LkLevel
             flush();
             int tk = 0;
             if (tid == 0) tk = (int)atomicAdd(link.counter, 1u);
-            lk_tile<R, LK_FLOW_COARSE, false, NTV, false, 32, false, true>(a, g, lds, e.x, e.y, e.w);
+            lk_tile<R, LK_FLOW_COARSE, false, NTV, false, THV, false, true>(a, g, lds, e.x, e.y, e.w);
             if (tid == 0) slot = tk;
             __syncthreads();
             t = __builtin_amdgcn_readfirstlane(slot);
@@ -1289,7 +1309,8 @@ int lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, std:
 template <typename C>
 static int get_schedule(const LkLevelArgs &a, int max_chain, const int4 **sched, int *nblocks) {
     for (auto &e : a.ctx->lk_sched)
-        if (e.rows == a.rows && e.cols == a.cols && e.batch == a.batch && e.r == C::R && e.max_chain == max_chain) {
+        if (e.rows == a.rows && e.cols == a.cols && e.batch == a.batch && e.r == C::R && e.max_chain == max_chain &&
+            e.th == C::TH) {
             *sched = static_cast<const int4 *>(e.dev);
             *nblocks = e.nblocks;
             return MICV_OK;
@@ -1308,7 +1329,7 @@ static int get_schedule(const LkLevelArgs &a, int max_chain, const int4 **sched,
         for (auto &e : a.ctx->lk_sched) (void)hipFree(e.dev);
         a.ctx->lk_sched.clear();
     }
-    a.ctx->lk_sched.push_back({a.rows, a.cols, a.batch, C::R, max_chain, dev, (int)host.size()});
+    a.ctx->lk_sched.push_back({a.rows, a.cols, a.batch, C::R, max_chain, C::TH, dev, (int)host.size()});
     *sched = static_cast<const int4 *>(dev);
     *nblocks = (int)host.size();
     return MICV_OK;
@@ -1346,7 +1367,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         set_error("lk fused: bad row band [%d, %d) for %d rows", a.row_begin, a.row_end, a.rows);
         return MICV_EINVAL;
     }
-    if constexpr (C::FAST && C::RW % 4 == 0 && C::NW % 4 == 0 && THV == 32 && NTV == 512) {
+    if constexpr (C::FAST && C::RW % 4 == 0 && C::NW % 4 == 0 && ((THV == 32 && NTV == 512) || (THV == 64 && NTV == 1024))) {
         // Streamed launch (MICV_OPT_LK_STREAM = 1; off by default): whole frames with a coarse flow whose
         // images the LDS-DMA can address (16-byte rows).  Measured on MI355X (8 x 1080p, tools/stream_bench.py,
         // one box): level-0 launch 0.244 ms against 0.220 ms for the plain grid -- the loop's staging
@@ -1369,14 +1390,15 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             int dev = 0;
             MICV_HIP(hipGetDevice(&dev));
             if (stream_dev != dev) {
-                MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_stream_kernel<R, NTV>),
+                MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_stream_kernel<R, NTV, THV>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
                 MICV_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
                 stream_dev = dev;
             }
-            long want = 2L * n_cu < tiles ? 2L * n_cu : tiles;
+            const long per_cu = NTV >= 1024 ? 1 : 2;  // resident workgroups per CU
+            long want = per_cu * n_cu < tiles ? per_cu * n_cu : tiles;
             const int grid = (int)((want + 7) / 8) * 8;
-            lk_level_stream_kernel<R, NTV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps, sched, nblocks / 8, tickets);
+            lk_level_stream_kernel<R, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps, sched, nblocks / 8, tickets);
             MICV_LAUNCH_CHECK();
             return MICV_OK;
         }
@@ -1469,6 +1491,10 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             const long short_tiles = (long)cdiv(a.cols, 64) * (cdiv(a.row_end > 0 ? a.row_end : a.rows, 16)) * a.batch;
             const long short_limit = a.short_tiles > 0 ? a.short_tiles : 512;  // one round at two workgroups per CU
             if (short_tiles <= short_limit && a.short_tiles >= 0) return launch_r<7, 512, 16>(s, a);
+            // MICV_OPT_LK_TALL_TILES: 64x64 tiles, 1024 threads, one workgroup per CU (131.6 KB of LDS): the
+            // structural cut of the halo overhead (phases 0-3 on 80x80 for 64x64 = 1.56x instead of 1.875x,
+            // row pass 78 rows for 64 = 1.22x instead of 1.44x).  Launches of at least four rounds only.
+            if (a.tall_tiles && (long)cdiv(a.cols, 64) * cdiv(a.rows, 64) * a.batch >= 1024) return launch_r<7, 1024, 64>(s, a);
             return launch_r<7, 512>(s, a);
         }
         case 7: return a.narrow ? launch_r<3, 256>(s, a) : launch_r<3, 512>(s, a);  // 512 threads: the staged / marching body

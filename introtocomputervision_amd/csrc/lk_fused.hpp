@@ -34,6 +34,7 @@ struct LkLevelArgs {
     micv_ctx *ctx = nullptr;
     int max_chain = 0;
     int short_tiles = 0;  // MICV_OPT_LK_SHORT_TILES: 0 = automatic (64x16 tiles under one round), -1 = never
+    int tall_tiles = 0;    // MICV_OPT_LK_TALL_TILES: 1 = 64x64 tiles / 1024 threads for big win-15 launches
     int stream_tiles = 0;  // MICV_OPT_LK_STREAM: 1 = persistent grid with staging ahead (lk_level_stream_kernel), 0 = off
     // -DMICV_DIAG builds only (the default build compiles neither in):
     //  * stamps (micv_profile_lk_phases): when non-null, wave 0 of every workgroup adds the
