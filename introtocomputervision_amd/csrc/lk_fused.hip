@@ -859,8 +859,21 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 v2f ptx[3], pty[3], wtx[3], wty[3], pcc[3], wcc[3];
                 auto rowpass = [&](int ly, int slot) {
                     const float *pr = P + ly * PS + lx, *wr = Wp + ly * PS + lx;
-                    const v2f pa = {pr[-1], pr[0]}, pb = {pr[0], pr[1]}, pc = {pr[1], pr[2]};
-                    const v2f wa = {wr[-1], wr[0]}, wb = {wr[0], wr[1]}, wc = {wr[1], wr[2]};
+                    v2f pa, pb, pc, wa, wb, wc;
+                    if constexpr (((H - R) & 1) == 1 && (PS & 1) == 0) {
+                        // lx is odd (qx even, H - R odd): (pr[-1], pr[0]) and (pr[1], pr[2]) are 8-byte
+                        // aligned pairs -> two ds_read_b64 per image row, lanes 8 bytes apart = one
+                        // conflict-free sweep of the bank row.  As scalars the compiler emits ds_read2_b32
+                        // at a 2-float lane stride: 2-way conflicts in its 32-bank mode (r02: 26 % of the
+                        // phase's LDS cycles were conflict cycles).
+                        const v2f p01 = *reinterpret_cast<const v2f *>(pr - 1), p23 = *reinterpret_cast<const v2f *>(pr + 1);
+                        const v2f w01 = *reinterpret_cast<const v2f *>(wr - 1), w23 = *reinterpret_cast<const v2f *>(wr + 1);
+                        pa = p01; pb = (v2f){p01.y, p23.x}; pc = p23;
+                        wa = w01; wb = (v2f){w01.y, w23.x}; wc = w23;
+                    } else {
+                        pa = (v2f){pr[-1], pr[0]}; pb = (v2f){pr[0], pr[1]}; pc = (v2f){pr[1], pr[2]};
+                        wa = (v2f){wr[-1], wr[0]}; wb = (v2f){wr[0], wr[1]}; wc = (v2f){wr[1], wr[2]};
+                    }
                     ptx[slot] = pc - pa;
                     pty[slot] = __builtin_elementwise_fma(pc, s1v, __builtin_elementwise_fma(pb, s2v, pa * s1v));
                     wtx[slot] = wc - wa;
