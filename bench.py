@@ -379,6 +379,29 @@ def main(argv=None):
         lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
         torch.cuda.synchronize()
 
+    # The drop-in path a cv::Mat caller links (micv_lk_flow_pyr_host: upload, kernels, download, sync in
+    # every call, like OpticalFlow.cpp:12-39 / Pyramids.cu:34-73): one pair per call, pageable inputs,
+    # preallocated outputs.  PCIe-inclusive, reported beside `value`, never as `value`.
+    host_pair_ms = None
+    if args.mode == "pairs" and rank == 0:
+        from introtocomputervision_amd._capi import check as _check, lib as _lib
+        hu = np.zeros((ROWS, COLS), np.float32)
+        hv = np.zeros((ROWS, COLS), np.float32)
+        hctx = Context(local_rank)
+
+        def host_call():
+            _check(_lib.micv_lk_flow_pyr_host(hctx.handle, prev_h[0].ctypes.data, next_h[0].ctypes.data, ROWS, COLS,
+                                              COLS * 4, WIN, LEVELS, hu.ctypes.data, hv.ctypes.data, COLS * 4))
+        for _ in range(3):
+            host_call()
+        ts = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            host_call()
+            ts.append(time.perf_counter() - t0)
+        host_pair_ms = sorted(ts)[len(ts) // 2] * 1e3
+        hctx.close()
+
     # sanity of what was measured: known translation comes back (not part of the timing)
     if args.mode == "rowshard":
         chk_u, chk_v = u[0, a0 + 8:b0 - 8, 64:-64], v[0, a0 + 8:b0 - 8, 64:-64]
@@ -486,6 +509,9 @@ def main(argv=None):
                 "one_pass_at_a_time_ms_per_step": serial_ms,
                 "single_pair_ms": single_pair_ms,
                 "single_pair_Mpix_s": None if not single_pair_ms else ROWS * COLS / single_pair_ms / 1e3,
+                "host_pair_ms": host_pair_ms,
+                "host_pair_note": "micv_lk_flow_pyr_host, one 1080p pair per call: 33.2 MB over PCIe (pageable "
+                                  "= pinned = 53 GB/s here: 0.62 ms) + the device call; PCIe-inclusive, not `value`",
             },
             "sustained": sustained,
             "algorithmic_GBps_pipeline": value * 1e6 * algorithmic_bytes_pair(ROWS, COLS, LEVELS)

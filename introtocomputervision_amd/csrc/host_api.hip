@@ -33,16 +33,24 @@ struct DevBuf {
         }                                                         \
     } while (0)
 
+// A continuous cv::Mat (step == row bytes: what cv::Mat::create gives) goes as ONE linear copy; only a
+// pitched view (an ROI) needs the 2-D form.  Pageable host memory is fine: the runtime pins the pages
+// for the transfer and reaches the same 53 GB/s as hipHostMalloc'd memory on this platform
+// (tools/probes/pcie_probe.py), so there is no staging ring to copy through.
 static int up2d(void *dst, const void *src, size_t sstride, size_t row_bytes, int rows,
                 hipStream_t s) {
-    MICV_HIP(hipMemcpy2DAsync(dst, row_bytes, src, sstride, row_bytes, rows, hipMemcpyHostToDevice,
-                              s));
+    if (sstride == row_bytes || rows == 1)
+        MICV_HIP(hipMemcpyAsync(dst, src, row_bytes * (size_t)rows, hipMemcpyHostToDevice, s));
+    else
+        MICV_HIP(hipMemcpy2DAsync(dst, row_bytes, src, sstride, row_bytes, rows, hipMemcpyHostToDevice, s));
     return MICV_OK;
 }
 static int down2d(void *dst, size_t dstride, const void *src, size_t row_bytes, int rows,
                   hipStream_t s) {
-    MICV_HIP(hipMemcpy2DAsync(dst, dstride, src, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost,
-                              s));
+    if (dstride == row_bytes || rows == 1)
+        MICV_HIP(hipMemcpyAsync(dst, src, row_bytes * (size_t)rows, hipMemcpyDeviceToHost, s));
+    else
+        MICV_HIP(hipMemcpy2DAsync(dst, dstride, src, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, s));
     return MICV_OK;
 }
 
