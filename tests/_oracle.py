@@ -23,6 +23,9 @@ def build(force=False):
 
 
 def _load():
+    alt = os.environ.get("ORACLE_SO")  # another build of the same checker, e.g. oracle/liboracle_asan.so
+    if alt:
+        return C.CDLL(alt if os.path.isabs(alt) else os.path.join(ROOT, alt))
     build()
     try:
         return C.CDLL(SO)

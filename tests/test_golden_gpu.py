@@ -61,3 +61,15 @@ def test_harris_stereo_hough_against_golden(G):
     assert np.array_equal(host(hough.houghLinesAccumulate(m, 2, 3)), G["hough_lines_b23"])
     assert np.array_equal(host(hough.findLocalMaxima(acc, 8, 30)).astype(np.uint32), G["hough_peaks"])
     assert np.array_equal(host(hough.houghCirclesAccumulate(m, 12)), G["hough_circles_r12"])
+
+
+def test_contract_corners_against_golden(G):
+    """r03 entries: cvRound's INT_MIN for non-finite / far map entries, the rolling column sums."""
+    from introtocomputervision_amd import lk, stereo
+    w = host(lk.warp(dev(G["img"]), dev(G["warp_nonfinite_du"]), dev(G["warp_nonfinite_dv"])))
+    assert w.tobytes() == G["warp_nonfinite"].tobytes()
+    for y, x in ((3, 4), (5, 6), (7, 8), (9, 10), (11, 12)):
+        assert G["warp_nonfinite"][y, x] == 0.0
+    L, Rr = dev(G["st_left_f"]), dev(G["st_right"])
+    assert np.array_equal(host(stereo.disparitySSD(L, Rr, 3, -24, 0, stereo.AS_WRITTEN_CUDA_ROLLING)), G["ssd_r3_rolling"])
+    assert np.array_equal(host(stereo.disparityNCorr(L + 1, Rr + 1, 3, -24, 0, 1 | 8)), G["ncc_r3_rolling"])
