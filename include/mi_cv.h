@@ -77,6 +77,19 @@ int micv_memcpy2d_d2h(micv_ctx *ctx, void *dst, size_t dpitch, const void *src, 
                       size_t width_bytes, int rows);
 
 /* ---------------------------------------------------------------- common/ (a17) ---- */
+/* Kernel-timing log lines.  The reference brackets each kernel with a GpuTimer and logs
+ * "<kernel> execution took {} ms" through spdlog (ps4_cpp/lib/Harris.cu:144-155,290;
+ * ps2_cpp/lib/DisparitySSD.cu:192-203, DisparityNCorr.cu:236-247; ps1_cpp/src/Hough.cu:289,345,391;
+ * ps5_cpp/lib/Pyramids.cu:69,123).  With a sink registered here (process-wide; NULL removes it), the
+ * `_host` entry points of exactly those functions time their device call with an event pair and call
+ * fn(kernel, ms, user) after their final synchronisation, `kernel` being the reference's kernel name
+ * ("cornerResponseKernel", "refineCornersKernel", "disparitySSDKernel", "disparityNCorrKernel",
+ * "houghLinesAccumulateKernel", "houghCirclesAccumulateKernel", "findLocalMaximaKernel",
+ * "pyrDownsampleKernel", "pyrUpsampleKernel").  The shim formats the reference's lines from it
+ * (micv_shim::log_kernel_times_to).  Costs nothing when no sink is set. */
+typedef void (*micv_kernel_log_fn)(const char *kernel, float ms, void *user);
+int micv_set_kernel_log(micv_kernel_log_fn fn, void *user);
+
 /* common::warmup, common/src/CudaWarmup.cu:5-19 (10 blocks x 64 threads). */
 int micv_warmup(micv_ctx *ctx, micv_stream stream);
 /* common::divRoundUp, common/include/common/Utils.h:12-15: max(1, ceil(float(n)/float(d))). */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "micv_profile_lk_level": (i32, [vp, i32, C.POINTER(f64), C.POINTER(i64)]),
     "micv_profile_lk_pairs": (i32, [vp, C.POINTER(i32)]),
     "micv_profile_lk_phases": (i32, [vp, i32, vp]),
+    "micv_set_kernel_log": (i32, [vp, vp]),
     "micv_warmup": (i32, [vp, vp]),
     "micv_div_round_up": (sz, [sz, sz]),
     "micv_timer_create": (i32, [C.POINTER(vp)]),
@@ -228,6 +229,20 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+KERNEL_LOG_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_float, vp)
+_kernel_log_keepalive = []
+
+
+def set_kernel_log(fn):
+    """fn(kernel_name: str, ms: float) for every timed `_host` call, or None to remove the sink."""
+    if fn is None:
+        check(lib.micv_set_kernel_log(None, None))
+        return
+    cb = KERNEL_LOG_FN(lambda name, ms, user: fn(name.decode(), float(ms)))
+    _kernel_log_keepalive.append(cb)  # the library keeps the pointer: the thunk must outlive it
+    check(lib.micv_set_kernel_log(C.cast(cb, vp), None))
 
 
 class Timer:

@@ -2,6 +2,7 @@
 // This is the behaviour of the reference's cv::Mat functions (upload -> kernel -> sync ->
 // download inside every call, e.g. Harris.cu:118-158, Pyramids.cu:45-72); it is PCIe-bound
 // by construction.  Device buffers are allocated per call like the reference's GpuMats.
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
@@ -61,10 +62,48 @@ using namespace micv;
 // Every `_host` function enqueues asynchronous copies; whichever way it returns (an error in a
 // later step included) the stream is drained first, so no D2H copy into the caller's buffer is
 // still in flight and no cached device block is handed out again while something uses it.
+//
+// Kernel-timing log lines: the reference brackets its kernels with a GpuTimer and
+// logs "<kernel> execution took {} ms" (Harris.cu:144-155, DisparitySSD.cu:192-203, Hough.cu:277-289,
+// Pyramids.cu:61-69).  With a sink registered (micv_set_kernel_log) the `_host` entry point of each of
+// those functions records an event pair around its device call and, after the final synchronisation,
+// hands (the reference's kernel name, milliseconds) to the sink; without one nothing is recorded.
+static std::atomic<micv_kernel_log_fn> g_log_fn{nullptr};
+static std::atomic<void *> g_log_user{nullptr};
+
 struct HostSync {
     hipStream_t s;
-    ~HostSync() { (void)hipStreamSynchronize(s); }
+    const char *name = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void begin(const char *kernel) {
+        if (!g_log_fn.load(std::memory_order_relaxed)) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+        name = kernel;
+        (void)hipEventRecord(e0, s);
+    }
+    void end() {
+        if (name) (void)hipEventRecord(e1, s);
+    }
+    ~HostSync() {
+        (void)hipStreamSynchronize(s);
+        if (name) {
+            float ms = 0.f;
+            const micv_kernel_log_fn fn = g_log_fn.load(std::memory_order_relaxed);
+            if (fn && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) fn(name, ms, g_log_user.load(std::memory_order_relaxed));
+        }
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
 };
+
+// The device call of a `_host` function, bracketed for the kernel log (a no-op without a sink).
+#define MICV_TIMED(kernel, call)       \
+    do {                               \
+        host_sync_.begin(kernel);      \
+        const int rc_timed_ = (call);  \
+        host_sync_.end();              \
+        if (rc_timed_ != MICV_OK) return rc_timed_; \
+    } while (0)
 
 #define HOST_PROLOGUE(fn)                                    \
     MICV_REQUIRE(ctx != nullptr, fn ": ctx is null");        \
@@ -74,6 +113,12 @@ struct HostSync {
     HostSync host_sync_{s}
 
 extern "C" {
+
+int micv_set_kernel_log(micv_kernel_log_fn fn, void *user) {
+    g_log_user.store(user, std::memory_order_relaxed);
+    g_log_fn.store(fn, std::memory_order_release);
+    return MICV_OK;
+}
 
 int micv_lk_flow_pyr_host(micv_ctx *ctx, const float *prev, const float *next, int rows, int cols,
                           size_t stride, int win, int levels, float *u, float *v, size_t ostride) {
@@ -191,7 +236,7 @@ int micv_pyr_down_host(micv_ctx *ctx, const float *src, int rows, int cols, size
     DevBuf ds((size_t)rows * cols * 4), dd((size_t)dr * dc * 4);
     MICV_ALLOC_OK(ds); MICV_ALLOC_OK(dd);
     MICV_TRY(up2d(ds.p, src, sstride, (size_t)cols * 4, rows, s));
-    MICV_TRY(micv_pyr_down_dev(ctx, ds.as<float>(), rows, cols, (size_t)cols * 4, dd.as<float>(),
+    MICV_TIMED("pyrDownsampleKernel", micv_pyr_down_dev(ctx, ds.as<float>(), rows, cols, (size_t)cols * 4, dd.as<float>(),
                                (size_t)dc * 4, s));
     if (dr > 0 && dc > 0) MICV_TRY(down2d(dst, dstride, dd.p, (size_t)dc * 4, dr, s));
     MICV_HIP(hipStreamSynchronize(s));
@@ -207,7 +252,7 @@ int micv_pyr_up_host(micv_ctx *ctx, const float *src, int rows, int cols, size_t
     DevBuf ds((size_t)rows * cols * 4), dd((size_t)rows * cols * 16);
     MICV_ALLOC_OK(ds); MICV_ALLOC_OK(dd);
     MICV_TRY(up2d(ds.p, src, sstride, (size_t)cols * 4, rows, s));
-    MICV_TRY(micv_pyr_up_dev(ctx, ds.as<float>(), rows, cols, (size_t)cols * 4, dd.as<float>(),
+    MICV_TIMED("pyrUpsampleKernel", micv_pyr_up_dev(ctx, ds.as<float>(), rows, cols, (size_t)cols * 4, dd.as<float>(),
                              (size_t)cols * 8, s));
     MICV_TRY(down2d(dst, dstride, dd.p, (size_t)cols * 8, 2 * rows, s));
     MICV_HIP(hipStreamSynchronize(s));
@@ -278,7 +323,7 @@ int micv_harris_response_host(micv_ctx *ctx, const float *gx, const float *gy, i
     MICV_ALLOC_OK(dx); MICV_ALLOC_OK(dy); MICV_ALLOC_OK(dr);
     MICV_TRY(up2d(dx.p, gx, gstride, rb, rows, s));
     MICV_TRY(up2d(dy.p, gy, gstride, rb, rows, s));
-    MICV_TRY(micv_harris_response_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb, win,
+    MICV_TIMED("cornerResponseKernel", micv_harris_response_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb, win,
                                       sigma, alpha, dr.as<float>(), rb, s));
     MICV_TRY(down2d(resp, rstride, dr.p, rb, rows, s));
     MICV_HIP(hipStreamSynchronize(s));
@@ -297,7 +342,7 @@ int micv_harris_refine_host(micv_ctx *ctx, const float *resp, int rows, int cols
     DevBuf dr(n), dc(n), dl((size_t)cap * 8), dn(8);
     MICV_ALLOC_OK(dr); MICV_ALLOC_OK(dc); MICV_ALLOC_OK(dl); MICV_ALLOC_OK(dn);
     MICV_TRY(up2d(dr.p, resp, rstride, rb, rows, s));
-    MICV_TRY(micv_harris_refine_dev(ctx, dr.as<float>(), rows, cols, rb, threshold, min_distance,
+    MICV_TIMED("refineCornersKernel", micv_harris_refine_dev(ctx, dr.as<float>(), rows, cols, rb, threshold, min_distance,
                                     dc.as<float>(), rb, dl.as<int32_t>(), cap, dn.as<int64_t>(), s));
     MICV_TRY(down2d(corners, cstride, dc.p, rb, rows, s));
     MICV_HIP(hipMemcpyAsync(count, dn.p, 8, hipMemcpyDeviceToHost, s));
@@ -383,10 +428,10 @@ static int stereo_host(bool ncc, micv_ctx *ctx, const float *left, const float *
     MICV_TRY(up2d(dl.p, left, stride, rb, rows, s));
     MICV_TRY(up2d(dr.p, right, stride, rb, rows, s));
     if (ncc)
-        MICV_TRY(micv_disparity_ncorr_dev(ctx, dl.as<float>(), dr.as<float>(), rows, cols, rb, rad,
+        MICV_TIMED("disparityNCorrKernel", micv_disparity_ncorr_dev(ctx, dl.as<float>(), dr.as<float>(), rows, cols, rb, rad,
                                           min_d, max_d, flags, dd.as<int8_t>(), cols, s));
     else
-        MICV_TRY(micv_disparity_ssd_dev(ctx, dl.as<float>(), dr.as<float>(), rows, cols, rb, rad,
+        MICV_TIMED("disparitySSDKernel", micv_disparity_ssd_dev(ctx, dl.as<float>(), dr.as<float>(), rows, cols, rb, rad,
                                         min_d, max_d, flags, dd.as<int8_t>(), cols, s));
     MICV_TRY(down2d(disp, dstride, dd.p, (size_t)cols, rows, s));
     MICV_HIP(hipStreamSynchronize(s));
@@ -415,7 +460,7 @@ int micv_hough_lines_host(micv_ctx *ctx, const uint8_t *mask, int rows, int cols
     DevBuf dm((size_t)rows * cols), da((size_t)rb * tb * 4);
     MICV_ALLOC_OK(dm); MICV_ALLOC_OK(da);
     MICV_TRY(up2d(dm.p, mask, mstride, (size_t)cols, rows, s));
-    MICV_TRY(micv_hough_lines_dev(ctx, dm.as<uint8_t>(), rows, cols, cols, rho_bin, theta_bin,
+    MICV_TIMED("houghLinesAccumulateKernel", micv_hough_lines_dev(ctx, dm.as<uint8_t>(), rows, cols, cols, rho_bin, theta_bin,
                                   da.as<int32_t>(), s));
     MICV_HIP(hipMemcpyAsync(acc, da.p, (size_t)rb * tb * 4, hipMemcpyDeviceToHost, s));
     MICV_HIP(hipStreamSynchronize(s));
@@ -430,7 +475,7 @@ int micv_hough_circles_host(micv_ctx *ctx, const uint8_t *mask, int rows, int co
     DevBuf dm((size_t)rows * cols), da((size_t)rows * cols * 4);
     MICV_ALLOC_OK(dm); MICV_ALLOC_OK(da);
     MICV_TRY(up2d(dm.p, mask, mstride, (size_t)cols, rows, s));
-    MICV_TRY(micv_hough_circles_dev(ctx, dm.as<uint8_t>(), rows, cols, cols, radius,
+    MICV_TIMED("houghCirclesAccumulateKernel", micv_hough_circles_dev(ctx, dm.as<uint8_t>(), rows, cols, cols, radius,
                                     da.as<int32_t>(), s));
     MICV_HIP(hipMemcpyAsync(acc, da.p, (size_t)rows * cols * 4, hipMemcpyDeviceToHost, s));
     MICV_HIP(hipStreamSynchronize(s));
@@ -445,7 +490,7 @@ int micv_hough_peaks_host(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
     DevBuf da((size_t)rows * cols * 4), dp((size_t)num_peaks * 8 + 8), dn(8);
     MICV_ALLOC_OK(da); MICV_ALLOC_OK(dp); MICV_ALLOC_OK(dn);
     MICV_HIP(hipMemcpyAsync(da.p, acc, (size_t)rows * cols * 4, hipMemcpyHostToDevice, s));
-    MICV_TRY(micv_hough_peaks_dev(ctx, da.as<int32_t>(), rows, cols, num_peaks, threshold,
+    MICV_TIMED("findLocalMaximaKernel", micv_hough_peaks_dev(ctx, da.as<int32_t>(), rows, cols, num_peaks, threshold,
                                   dp.as<uint32_t>(), dn.as<int64_t>(), s));
     MICV_HIP(hipMemcpyAsync(count, dn.p, 8, hipMemcpyDeviceToHost, s));
     MICV_HIP(hipStreamSynchronize(s));

@@ -17,6 +17,7 @@
 #pragma once
 
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -58,6 +59,31 @@ inline void create_continuous(GpuMat &m, int rows, int cols, int type) { m.creat
 #endif
 
 namespace micv_shim {
+
+// The reference's kernel-timing log lines (ps4_cpp/lib/Harris.cu:155,290, ps2_cpp/lib/DisparitySSD.cu:203,
+// DisparityNCorr.cu:247, ps1_cpp/src/Hough.cu:289,345,391, ps5_cpp/lib/Pyramids.cu:69,123):
+//     micv_shim::log_kernel_times_to([](const std::string &line) { spdlog::get("file_logger")->info(line); });
+// makes every shim call of those functions emit "<kernel> execution took <ms> ms" ("<kernel> took <ms> ms"
+// for the two pyramid kernels, as the reference words them) through the given sink; an empty function
+// removes it.  One sink per process (the drivers log from their main thread only).
+inline std::function<void(const std::string &)> &kernel_log_sink() {
+    static std::function<void(const std::string &)> sink;
+    return sink;
+}
+inline void log_kernel_times_to(std::function<void(const std::string &)> sink) {
+    kernel_log_sink() = std::move(sink);
+    if (!kernel_log_sink()) {
+        micv_set_kernel_log(nullptr, nullptr);
+        return;
+    }
+    micv_set_kernel_log(
+        [](const char *kernel, float ms, void *) {
+            const std::string k(kernel);
+            const bool pyr = k.compare(0, 3, "pyr") == 0;
+            if (kernel_log_sink()) kernel_log_sink()(k + (pyr ? " took " : " execution took ") + std::to_string(ms) + " ms");
+        },
+        nullptr);
+}
 
 inline void check(int rc) {
     if (rc != MICV_OK) throw std::runtime_error(std::string("micv: ") + micv_last_error());

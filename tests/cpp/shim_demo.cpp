@@ -5,6 +5,7 @@
 // directory, writes raw results next to them; tests/test_shim_gpu.py compares with the oracle.
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,18 @@ int main(int argc, char **argv) {
     const std::string dir = argv[1];
     const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]);
     try {
+        // the reference's "<kernel> execution took {} ms" lines, as its file logger would receive them
+        std::vector<std::string> log_lines;
+        micv_shim::log_kernel_times_to([&log_lines](const std::string &line) { log_lines.push_back(line); });
+        struct LogDump {
+            const std::string path;
+            std::vector<std::string> &lines;
+            ~LogDump() {
+                std::ofstream f(path);
+                for (auto &l : lines) f << l << "\n";
+                micv_shim::log_kernel_times_to(nullptr);
+            }
+        } log_dump{dir + "/kernel_log.txt", log_lines};
         // ---- ps5: hierarchical LK, window 15 (config/ps5.yaml lk_window_size_4), depth 4 --------
         Mat prev = load(dir + "/prev.f32", rows, cols, micv_shim::F32);
         Mat next = load(dir + "/next.f32", rows, cols, micv_shim::F32);

@@ -155,3 +155,25 @@ def test_chain_schedule_covers_every_tile_exactly_once(win):
                     assert 0 <= p < batch and 0 <= x < tiles_x and 0 <= y and y + cnt <= tiles_y, (rows, cols, x, y, cnt)
                     seen[p, y:y + cnt, x] += 1
                 assert (seen == 1).all(), (win, rows, cols, batch, max_chain, np.argwhere(seen != 1)[:5])
+
+
+def test_cmake_build_exports_the_same_abi(tmp_path):
+    """The top-level CMakeLists.txt (HIP language, gfx950) is the integration entry point SURVEY.md section 7
+    describes: configure + build it from scratch and check that its libmicv.so exports exactly the symbols
+    include/mi_cv.h declares, and links neither torch nor the oracle."""
+    import shutil
+    import subprocess
+    if not (shutil.which("cmake") and shutil.which("ninja") and os.path.exists("/opt/rocm/lib/llvm/bin/clang++")):
+        pytest.skip("cmake / ninja / ROCm clang not available")
+    b = str(tmp_path / "build")
+    r = subprocess.run(["cmake", "-S", ROOT, "-B", b, "-G", "Ninja"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(["cmake", "--build", b], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    so = os.path.join(b, "libmicv.so")
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r" T (micv_[a-z0-9_]+)$", syms, flags=re.M)))
+    assert exported == header_functions()
+    deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+    assert "amdhip64" in deps and "torch" not in deps and "oracle" not in deps
+    assert os.path.exists(os.path.join(b, "liboracle.so"))

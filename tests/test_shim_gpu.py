@@ -130,3 +130,49 @@ def test_shim_matches_oracle(tmp_path):
     em, ed = tm.oracle_ratio(eidx, edist, 0.75)
     assert len(em) > 0 and np.array_equal(rd("good.i32", np.int32).reshape(-1, 2), em)
     assert np.array_equal(rd("good_dist.f32", np.float32), ed)
+    # the reference's kernel-timing log lines, through micv_shim::log_kernel_times_to
+    import re
+    log = open(os.path.join(d, "kernel_log.txt")).read().splitlines()
+    pat = re.compile(r"^(\w+Kernel) (execution )?took ([0-9.]+) ms$")
+    seen = {}
+    for line in log:
+        m = pat.match(line)
+        assert m, line
+        assert (m.group(2) is None) == m.group(1).startswith("pyr"), line  # Pyramids.cu:69,123 say "took"
+        assert 0.0 < float(m.group(3)) < 1000.0, line
+        seen[m.group(1)] = seen.get(m.group(1), 0) + 1
+    for k in ("cornerResponseKernel", "refineCornersKernel", "disparitySSDKernel", "houghLinesAccumulateKernel",
+              "findLocalMaximaKernel", "pyrUpsampleKernel"):
+        assert seen.get(k, 0) >= 1, (k, seen)
+
+
+@pytest.mark.gpu
+def test_kernel_log_callback_python():
+    """micv_set_kernel_log through the ctypes mirror: names and plausible times for every timed `_host`
+    call, nothing after the sink is removed."""
+    from introtocomputervision_amd import _capi, harris, hough, pyr, stereo, synth
+    got = []
+    _capi.set_kernel_log(lambda name, ms: got.append((name, ms)))
+    try:
+        img = synth.checkerboard(120, 160, 20, seed=1)
+        gx, gy = harris.getGradients(img, 3)
+        R = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04)
+        harris.refineCorners(R, 5e8, 5)
+        l, r, _ = synth.stereo_pair(1, 60, 90)
+        stereo.disparitySSD(l, r, 3, -10, 0)
+        stereo.disparityNCorr(l + 1, r + 1, 3, -10, 0)
+        m = synth.hough_mask(90, 130, n_lines=3, radii=(12,))[0]
+        acc = hough.houghLinesAccumulate(m, 1, 1)
+        hough.houghCirclesAccumulate(m, 12)
+        hough.findLocalMaxima(acc, 5, 20)
+        pyr.pyrDown(img)
+        pyr.pyrUp(img)
+    finally:
+        _capi.set_kernel_log(None)
+    assert [n for n, _ in got] == ["cornerResponseKernel", "refineCornersKernel", "disparitySSDKernel",
+                                   "disparityNCorrKernel", "houghLinesAccumulateKernel", "houghCirclesAccumulateKernel",
+                                   "findLocalMaximaKernel", "pyrDownsampleKernel", "pyrUpsampleKernel"]
+    assert all(0.0 < ms < 1000.0 for _, ms in got)
+    n = len(got)
+    pyr.pyrDown(img)
+    assert len(got) == n
