@@ -105,6 +105,59 @@ def cpu_baseline(sample_pairs, hip_uv=None):
     return out, parity
 
 
+def measure_traffic_live(pairs, extra_opts):
+    """HBM traffic and VALU instructions of the level-0 launch, measured NOW: three child runs of this
+    bench under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU in separate passes, no tracing
+    flags -- the pool's rule and the guide's recipe), one stream group and one pass at a time so that a
+    level-0 dispatch covers the whole batch.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled
+    (MI355X_MICROARCH.md section HBM: gfx950 tallies 64 B per 128-B request of a wide coalesced read).
+    Returns None when rocprofv3 is missing or a pass fails (the caller then falls back to the committed
+    profiles/traffic.json, labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    means = {}
+    kernel = None
+    tmp = tempfile.mkdtemp(prefix="micv_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   "python3", os.path.abspath(__file__), "--cpu-pairs", "0", "--steps", "3", "--warmup", "1",
+                   "--no-profile-pass", "--lk-groups", "1", "--inflight", "1", "--sustained-s", "0", "--preroll-s", "0",
+                   "--pairs", str(pairs), "--no-pmc"] + [x for o in extra_opts for x in ("--opt", o)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("MICV_BENCH_FORCE_DIST", None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if r.returncode != 0:
+                return None
+            per = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "lk_level" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per.setdefault((row["Kernel_Name"].split("(")[0].replace("void ", ""), int(row["Grid_Size"])),
+                                       []).append(float(row["Counter_Value"]))
+            if not per:
+                return None
+            key = max(per, key=lambda k: k[1])  # the largest grid = pyramid level 0
+            means[counter] = sum(per[key]) / len(per[key])
+            kernel = key[0]
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = means["FETCH_SIZE"] * 1024, means["WRITE_SIZE"] * 1024
+    return {"kernel": kernel, "pairs_per_launch": pairs, "fetch_bytes_raw": fetch, "fetch_bytes_x2_gfx950": 2 * fetch,
+            "write_bytes": write, "level0_hbm_bytes_per_launch": 2 * fetch + write,
+            "valu_insts_per_launch": means["SQ_INSTS_VALU"],
+            "method": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, three child "
+                      "passes of bench.py (3 steps, one stream group, one pass at a time); KiB -> bytes; FETCH_SIZE "
+                      "doubled per MI355X_MICROARCH.md section HBM"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +174,9 @@ def parse_args(argv=None):
                     help="MICV_OPT_LK_CHAIN of every context: 0 = the library's rule, 1 = no tile chains, n = longest chain")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="micv_ctx_set_option on every context, e.g. --opt OPT_LK_TALL_TILES=1 (A/B and PMC runs)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure roofline.traffic / roofline.valu live (three short rocprofv3 --pmc child "
+                         "runs, ~25 s); fall back to the committed profiles/traffic.json")
     ap.add_argument("--preroll-s", type=float, default=0.25,
                     help="seconds of untimed steps before the warm-up steps (clock pre-roll; 0 = none)")
     ap.add_argument("--sustained-s", type=float, default=2.0,
@@ -166,15 +222,17 @@ def launch_ranks(args, argv):
     return proc.returncode
 
 
-def valu_roofline(lvl0_ms, pairs_per_launch):
-    """VALU axis of the dominant kernel: wave-VALU instructions per launch from the committed
-    rocprofv3 PMC pass (profiles/traffic.json, SQ_INSTS_VALU), the issue time they need on
-    1024 SIMDs at 4 cycles each, and the useful arithmetic rate against the FP32 vector peak."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        tj = json.load(open(path))
-    except Exception:
-        return None
+def valu_roofline(lvl0_ms, pairs_per_launch, tj=None, source=None):
+    """VALU axis of the dominant kernel: wave-VALU instructions per launch (SQ_INSTS_VALU, measured live
+    by measure_traffic_live or taken from the committed profiles/traffic.json), the issue time they need
+    on 1024 SIMDs at 4 cycles each, and the useful arithmetic rate against the FP32 vector peak."""
+    if tj is None:
+        path = os.path.join(ROOT, "profiles", "traffic.json")
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            return None
+        source = f"profiles/traffic.json ({tj.get('profile', 'rocprofv3 --pmc SQ_INSTS_VALU')}, not this run)"
     insts = tj.get("valu_insts_per_launch")
     if not insts or tj.get("pairs_per_launch") != pairs_per_launch:
         return None
@@ -190,7 +248,7 @@ def valu_roofline(lvl0_ms, pairs_per_launch):
         "useful_tflops": useful_tflops,
         "peak_tflops": VALU_PEAK_TFLOPS,
         "frac": useful_tflops / VALU_PEAK_TFLOPS,
-        "source": f"profiles/traffic.json ({tj.get('profile', 'rocprofv3 --pmc SQ_INSTS_VALU')}, not this run)",
+        "source": source,
     }
 
 
@@ -441,9 +499,16 @@ def main(argv=None):
         pairs_per_launch = ctx.profile_lk_pairs() or B  # the library splits the batch into stream groups
         k_bytes = level0_kernel_bytes_pair(ROWS, COLS, LEVELS) * pairs_per_launch
         achieved = k_bytes / (lvl_ms[0] * 1e-3) / 1e9
-        traffic, traffic_source, kernel_name = None, None, ctx.lk_level_kernel_name()
+        traffic, traffic_source, kernel_name = None, None, ctx.lk_level_kernel_name(WIN, ROWS, COLS, pairs_per_launch)
+        live = None
+        if rank == 0 and n_gpus == 1 and not args.no_pmc:
+            live = measure_traffic_live(pairs_per_launch, args.opt)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")  # from rocprofv3 --pmc runs
-        if os.path.exists(tpath):
+        if live is not None:
+            traffic = live["level0_hbm_bytes_per_launch"]
+            kernel_name = live["kernel"].replace("micv::", "")
+            traffic_source = live["method"]
+        elif os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("pairs_per_launch") == pairs_per_launch:
@@ -461,7 +526,8 @@ def main(argv=None):
             "traffic": traffic, "traffic_source": traffic_source,
             "bytes_per_launch": k_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_ms": lvl_ms[0],
             "level_ms": lvl_ms,
-            "valu": valu_roofline(lvl_ms[0], pairs_per_launch),
+            "valu": valu_roofline(lvl_ms[0], pairs_per_launch, live, live["method"] if live else None),
+            "traffic_detail": live,
             "binding_axis": "valu",
             "note": "HBM figures as the contract asks; the kernel itself is f32-VALU-issue bound "
                     "(5 x 15-tap separable window sums) -- see `valu`.  Timed in a second pass of the "

@@ -189,9 +189,25 @@ class Context:
         """Stream groups a batch of pairs is split into (0 = library default)."""
         self.set_option(OPT_LK_STREAM_GROUPS, n)
 
-    def lk_level_kernel_name(self, win=15):
-        narrow = self.get_option(OPT_LK_NARROW_TILES)
-        return f"lk_level_kernel<{win // 2},COARSE,{256 if narrow or win != 15 else 512}>"
+    def lk_level_kernel_name(self, win=15, rows=1080, cols=1920, batch=8):
+        """The level-kernel instantiation launch_lk_level_fused picks for a rows x cols level of `batch` pairs with
+        a doubling coarse flow (mode 1), following csrc/lk_fused.hip's dispatch and this context's options."""
+        r = win // 2
+        if self.get_option(OPT_LK_NARROW_TILES):
+            return f"lk_level_kernel<{r}, 1, 256, 32>"
+        if win == 21:
+            return "lk_level_kernel<10, 1, 512, 16>"
+        if win != 15:
+            return f"lk_level_kernel<{r}, 1, 512, 32>"
+        short = self.get_option(OPT_LK_SHORT_TILES)
+        if short >= 0 and -(-cols // 64) * -(-rows // 16) * batch <= (short if short > 0 else 512):
+            return "lk_level_kernel<7, 1, 512, 16>"
+        tall = self.get_option(OPT_LK_TALL_TILES) and -(-cols // 64) * -(-rows // 64) * batch >= 1024
+        if self.get_option(OPT_LK_STREAM):
+            return "lk_level_stream_kernel<7, 1024, 64>" if tall else "lk_level_stream_kernel<7, 512, 32>"
+        if self.get_option(OPT_LK_CHAIN) > 1 or self.get_option(OPT_LK_CHAIN) < 0:
+            return "lk_level_chain_kernel<7, 512>"
+        return "lk_level_kernel<7, 1, 1024, 64>" if tall else "lk_level_kernel<7, 1, 512, 32>"
 
     def profile(self, on=True):
         check(lib.micv_profile_enable(self._h, 1 if on else 0))
