@@ -288,3 +288,35 @@ def test_rolling_at_the_reference_geometry(mods):
     exp = orc.disparity_ssd(left, right, 7, -95, 0, 1 | 2 | 8)
     got = host(stereo.disparitySSD(dev(left), dev(right), 7, -95, 0, stereo.AS_WRITTEN_CUDA_ROLLING))
     assert np.array_equal(got, exp), (got != exp).sum()
+
+
+@pytest.mark.parametrize("kind", ["flat_noise", "constant", "zeros", "periodic", "huge", "tiny", "mixed_sign"])
+def test_ncc_near_ties_and_degenerate_windows(mods, kind):
+    """disparityNCorr decides `nc > best` on a v_rsq_f32 estimate and forms the correctly rounded scores only
+    when the estimate is too close to call (r03).  Inputs made of ties and near-ties (every candidate within
+    2^-19 of the best), degenerate windows (zero energy: 0 / 0), and magnitudes outside v_rsq_f32's range drive
+    that exact path; the disparities must equal the oracle's, which always forms the exact score."""
+    lk, pyr, stereo, synth = mods
+    rng = np.random.default_rng(4)
+    rows, cols = 60, 150
+    if kind == "flat_noise":
+        left = (rng.random((rows, cols)) * 1e-3 + 7.3).astype(np.float32)
+        right = (rng.random((rows, cols)) * 1e-3 + 7.3).astype(np.float32)
+    elif kind == "constant":
+        left = np.full((rows, cols), 3.0, np.float32); right = np.full((rows, cols), 5.0, np.float32)
+    elif kind == "zeros":
+        left = np.zeros((rows, cols), np.float32); right = np.zeros((rows, cols), np.float32)
+        left[20:40, 50:100] = rng.random((20, 50)); right[25:45, 40:90] = rng.random((20, 50))
+    elif kind == "periodic":
+        base = np.tile(np.array([1, 4, 2, 8], np.float32), cols // 4 + 2)[:cols]
+        left = np.tile(base, (rows, 1)); right = np.roll(left, 2, axis=1).copy()
+    elif kind == "huge":
+        left = (rng.random((rows, cols)) * 1e17 + 1e16).astype(np.float32); right = np.roll(left, 3, axis=1) * np.float32(1.5)
+    elif kind == "tiny":
+        left = (rng.random((rows, cols)) * 1e-17 + 1e-18).astype(np.float32); right = np.roll(left, 3, axis=1) * np.float32(1.5)
+    else:
+        left = rng.standard_normal((rows, cols)).astype(np.float32); right = rng.standard_normal((rows, cols)).astype(np.float32)
+    for rad, flags in ((3, 0), (5, 1), (12, 0)):
+        exp = orc.disparity_ncorr(left, right, rad, -20, 6, flags)
+        got = host(stereo.disparityNCorr(dev(left), dev(right), rad, -20, 6, flags))
+        assert np.array_equal(got, exp), (kind, rad, flags, int((got != exp).sum()))
