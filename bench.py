@@ -185,6 +185,10 @@ def parse_args(argv=None):
                     help="pairs: every rank owns whole frame pairs (default, weak scaling, no data-path "
                          "collective); rowshard: every pair is split by rows over all ranks with a "
                          "coarse-flow halo exchange per level (strong scaling, RCCL point-to-point)")
+    ap.add_argument("--next-margin", type=int, default=None,
+                    help="rowshard mode: declared bound on |dv| in level-0 rows; ranks build `next` for band + margin only, "
+                         "a device-side check makes a step fall back to the whole frame when the bound is exceeded "
+                         "(default: whole frame on every rank)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the ranks (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true",
@@ -351,11 +355,17 @@ def main(argv=None):
             for t in (prev, nxt):
                 dist.broadcast(t, src=0)
         runner = shard.RowShardBatch(ctx, ROWS, COLS, LEVELS, WIN, B, rank, n_gpus,
-                                     comm=shard.DistComm(rank, n_gpus) if dist is not None else None)
+                                     comm=shard.DistComm(rank, n_gpus) if dist is not None else None,
+                                     next_margin=args.next_margin)
         a0, b0 = runner.band0
+        margin_stats = [0, 0]  # steps, steps on which the declared margin sufficed
 
         def step():
-            runner.run(prev, nxt, u, v, stream)
+            if args.next_margin is None:
+                runner.run(prev, nxt, u, v, stream)
+            else:
+                margin_stats[0] += 1
+                margin_stats[1] += 1 if runner.run_checked(prev, nxt, u, v, stream) else 0
     else:
         # `--inflight F` batches in flight: step i runs on context / HIP stream / output buffers
         # i mod F (a context owns its scratch arena and aux streams, so passes on different contexts
@@ -575,6 +585,8 @@ def main(argv=None):
                 "one_pass_at_a_time_ms_per_step": serial_ms,
                 "single_pair_ms": single_pair_ms,
                 "single_pair_Mpix_s": None if not single_pair_ms else ROWS * COLS / single_pair_ms / 1e3,
+                "next_margin": args.next_margin if args.mode == "rowshard" else None,
+                "next_margin_sufficed_frac": (margin_stats[1] / max(1, margin_stats[0])) if args.mode == "rowshard" and args.next_margin is not None else None,
                 "host_pair_ms": host_pair_ms,
                 "host_pair_note": "micv_lk_flow_pyr_host, one 1080p pair per call: 33.2 MB over PCIe (pageable "
                                   "= pinned = 53 GB/s here: 0.62 ms) + the device call; PCIe-inclusive, not `value`",

@@ -139,6 +139,16 @@ int micv_lk_flow_pyr_batch_dev(micv_ctx *ctx, const float *prev, const float *ne
                                int levels, float *u, float *v, size_t opair_stride,
                                size_t ostride, micv_stream stream);
 
+/* Row-sharded execution with a DECLARED bound on the vertical flow: a rank that holds
+ * only band + margin rows of `next` must know when a flow value would make lk::warp read beyond them.
+ * Sets bit 0 of *flag (device memory, zeroed by the caller) when |v| > bound or v is not finite anywhere in
+ * rows [row_begin, row_end) of the `batch` fields (field i at v + i*pair_stride bytes); asynchronous on
+ * `stream`, no host synchronisation.  introtocomputervision_amd/shard.py reruns the step with the whole
+ * frame when the flag comes back set. */
+int micv_flow_bound_check_dev(micv_ctx *ctx, const float *v, int batch, size_t pair_stride, int rows, int cols,
+                              size_t stride, int row_begin, int row_end, float bound, uint32_t *flag,
+                              micv_stream stream);
+
 /* Diagnostic, host only (no device call): the work list the optional chain / streamed launches of the
  * level kernel walk (MICV_OPT_LK_CHAIN, MICV_OPT_LK_STREAM) for a rows x cols level of `batch` pairs.
  * Entry i = (tile x, first tile y, tiles in the chain, pair), 0 tiles = padding; tiles are

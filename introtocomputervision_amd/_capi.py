@@ -73,6 +73,7 @@ SIGNATURES = {
     "micv_lk_flow_pyr_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz, vp]),
     "micv_lk_flow_pyr_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz]),
     "micv_lk_flow_pyr_batch_dev": (i32, [vp, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
+    "micv_flow_bound_check_dev": (i32, [vp, vp, i32, sz, i32, i32, sz, i32, i32, f32, vp, vp]),
     "micv_lk_schedule_host": (i32, [i32, i32, i32, i32, i32, vp, i64, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
     "micv_lk_level_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     "micv_lk_level_batch_dev": (i32, [vp, vp, vp, i32, sz, i32, i32, sz, i32, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),

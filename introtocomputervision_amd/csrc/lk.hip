@@ -80,6 +80,21 @@ __global__ __launch_bounds__(256) void lk_warp_kernel(const float *__restrict__ 
                                                dv[(size_t)y * fstride + x]);
 }
 
+// micv_flow_bound_check_dev: raises *flag when a flow value of the given rows exceeds `bound` in magnitude
+// (or is not finite).  One atomic per wave that sees a violation.
+__global__ __launch_bounds__(256) void flow_bound_kernel(const float *__restrict__ v, size_t pair_elems, int stride,
+                                                         int cols, int row_begin, int nrows, float bound,
+                                                         unsigned *__restrict__ flag) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    bool bad = false;
+    if (x < cols && y < nrows) {
+        const float t = v[blockIdx.z * pair_elems + (size_t)(row_begin + y) * stride + x];
+        bad = !(fabsf(t) <= bound);  // true for NaN as well
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 int launch_warp(hipStream_t s, const float *src, int sstride, const float *du, const float *dv,
                 int fstride, int rows, int cols, float *dst, int dstride) {
     lk_warp_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(src, sstride, du, dv, fstride,
@@ -508,6 +523,23 @@ int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next,
         MICV_TRY(lk_level_generic(s, pb, (int)(stride / 4), warped, cols, rows, cols, win, bu, bv, cols,
                                   u + b * ope, v + b * ope, (int)(ostride / 4), gen));
     }
+    return MICV_OK;
+}
+
+int micv_flow_bound_check_dev(micv_ctx *ctx, const float *v, int batch, size_t pair_stride, int rows, int cols,
+                              size_t stride, int row_begin, int row_end, float bound, uint32_t *flag,
+                              micv_stream stream) {
+    MICV_REQUIRE(ctx && v && flag, "micv_flow_bound_check: null argument");
+    MICV_REQUIRE(rows > 0 && cols > 0 && batch >= 1 && batch <= 65535 && row_begin >= 0 && row_begin <= row_end && row_end <= rows,
+                 "micv_flow_bound_check: bad size or row range");
+    MICV_REQUIRE(stride_ok(stride, cols, 4) && pair_stride % 4 == 0 && (batch == 1 || pair_stride >= stride * (size_t)rows),
+                 "micv_flow_bound_check: bad stride");
+    MICV_REQUIRE(bound >= 0.f, "micv_flow_bound_check: negative bound");
+    if (row_begin == row_end) return MICV_OK;
+    MICV_HIP(hipSetDevice(ctx->device));
+    flow_bound_kernel<<<dim3(cdiv(cols, 64), cdiv(row_end - row_begin, 4), batch), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        v, pair_stride / 4, (int)(stride / 4), cols, row_begin, row_end - row_begin, bound, flag);
+    MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
 

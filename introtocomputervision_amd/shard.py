@@ -247,11 +247,16 @@ class RowShardBatch:
     Static halos: of `prev` a band reads only IMAGE_MARGIN rows beyond itself (a deployment ships
     band + margin, and the rank builds only those pyramid rows).  `next` is read at (y + dv) by the
     warp, and LK's flow is unbounded where the window is nearly degenerate (isolated pixels with
-    |dv| of hundreds occur on the synthetic pairs): exact parity needs the whole `next` level on
-    every rank, so its pyramid is built in full (SURVEY.md section 8e's "declared bound" would trade
-    those pixels' parity for memory; it is not taken)."""
+    |dv| of hundreds occur on the synthetic pairs).  Two ways to hold it:
+      * next_margin=None (default): the whole `next` level on every rank -- exact, no check needed;
+      * next_margin=m (level-0 rows, SURVEY.md section 8e's "declared bound on max |dv|"): the rank builds
+        `next` for its band + IMAGE_MARGIN + ceil(m / 2^l) + 2 rows per level only, and a device-side check
+        (micv_flow_bound_check_dev, no host sync) raises a flag when the coarse flow a level is about to
+        expand exceeds what those rows cover.  run_checked() reads the flag after the step and, when it is
+        set, repeats the step on the whole frame: the result is exact either way, the margin only decides
+        how often the cheap path suffices."""
 
-    def __init__(self, ctx, rows, cols, levels, win, batch, rank, world, comm=None, device=None):
+    def __init__(self, ctx, rows, cols, levels, win, batch, rank, world, comm=None, device=None, next_margin=None):
         import torch
         self.ctx, self.levels, self.win, self.batch, self.rank, self.world = ctx, levels, win, batch, rank, world
         if win // 2 + 1 > IMAGE_MARGIN:
@@ -270,6 +275,22 @@ class RowShardBatch:
             lo.append(max(0, a - IMAGE_MARGIN))
             hi.append(min(dims[l][0], b + IMAGE_MARGIN))
         self.img_rows = (lo, hi)
+        self.next_margin = next_margin
+        self.next_rows = None
+        self.flag = None
+        if next_margin is not None:
+            if next_margin < 0:
+                raise ValueError("next_margin must be >= 0")
+            nlo, nhi, self.level_margin = [], [], []
+            for l in range(levels):
+                a, b = self.plan.band(l, rank)
+                m = -(-int(next_margin) // (1 << l)) + 2
+                self.level_margin.append(m)
+                nlo.append(max(0, a - IMAGE_MARGIN - m))
+                nhi.append(min(dims[l][0], b + IMAGE_MARGIN + m))
+            self.next_rows = (nlo, nhi)
+            self.flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.full_next = next_margin is None  # which rows of `next` the pyramid holds right now
 
     def _pyr_ptrs(self, pyr):
         import ctypes as C
@@ -289,7 +310,11 @@ class RowShardBatch:
         if restrict:
             lo = (C.c_int * self.levels)(*self.img_rows[0])
             hi = (C.c_int * self.levels)(*self.img_rows[1])
-        for src, pyr, a, b in ((prev, self.ppyr, lo, hi), (nxt, self.npyr, None, None)):
+        nlo = nhi = None
+        if restrict and self.next_rows is not None and not self.full_next:
+            nlo = (C.c_int * self.levels)(*self.next_rows[0])
+            nhi = (C.c_int * self.levels)(*self.next_rows[1])
+        for src, pyr, a, b in ((prev, self.ppyr, lo, hi), (nxt, self.npyr, nlo, nhi)):
             check(lib.micv_gaussian_pyramid_batch_dev(self.ctx.handle, src.data_ptr(), B, rows * cols * 4, rows, cols,
                                                       cols * 4, self.levels, self._pyr_ptrs(pyr), a, b, stream))
 
@@ -333,7 +358,49 @@ class RowShardBatch:
             if l < self.levels - 1:
                 with on_s:
                     self.comm.exchange_batch(self.plan, l + 1, self.flow[l + 1])
+                if self.next_rows is not None and not self.full_next:
+                    self._check_bound(l, s)
             self.level(l, prev, nxt, u, v, s)
+
+    def _check_bound(self, l, stream):
+        """Level l is about to warp `next` by 2 * pyrUp(v_{l+1}), a convex combination of the coarse rows this
+        rank holds (its band + halo): |dv_l| <= 2 max |v_{l+1}| over them.  Flag when that exceeds the rows of
+        `next` built for level l."""
+        from ._capi import check, lib
+        f = self.flow[l + 1]
+        fr, fc = self.plan.dims[l + 1]
+        r0, r1 = self.plan.needed(l + 1, self.rank)
+        check(lib.micv_flow_bound_check_dev(self.ctx.handle, f.data_ptr() + fr * fc * 4, self.batch, 2 * fr * fc * 4,
+                                            fr, fc, fc * 4, r0, r1, float(self.level_margin[l]) / 2.0,
+                                            self.flag.data_ptr(), stream))
+
+    def violated(self):
+        """True when the last run() met a vertical flow beyond the declared margin (host synchronisation)."""
+        return self.flag is not None and bool(self.flag.item())
+
+    def run_checked(self, prev, nxt, u, v, stream=None):
+        """run() with the declared margin; when the bound check fires, the same step again on the whole
+        `next` frame.  Returns True when the margin sufficed.  Every rank must take the same branch (the
+        exchange is collective in spirit): the flag is OR-reduced over the ranks when a process group exists."""
+        if self.next_rows is None:
+            self.run(prev, nxt, u, v, stream)
+            return True
+        self.flag.zero_()
+        self.full_next = False
+        self.run(prev, nxt, u, v, stream)
+        flag = self.flag
+        dist = getattr(self.comm, "dist", None)
+        if dist is not None and self.world > 1:
+            flag = self.flag.clone()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if not bool(flag.item()):
+            return True
+        self.full_next = True  # fall back: the whole `next` pyramid, no bound to check
+        try:
+            self.run(prev, nxt, u, v, stream)
+        finally:
+            self.full_next = False
+        return False
 
 
 def run_virtual_batch(runners, prev, nxt, u, v, stream=None, poison=None, shared_pyramids=True):
@@ -361,3 +428,43 @@ def run_virtual_batch(runners, prev, nxt, u, v, stream=None, poison=None, shared
                 a, b = r.plan.band(l, r.rank)
                 r.flow[l][:, :, :a] = poison
                 r.flow[l][:, :, b:] = poison
+
+
+def run_virtual_batch_checked(runners, prev, nxt, u, v, stream=None, poison=None):
+    """run_checked() for virtual ranks: every rank builds only the rows of `next` its declared margin covers
+    (runners built with next_margin=...), the bound checks run per rank and level, and when any rank's flag
+    is raised ALL ranks repeat the step on the whole frame -- the decision a distributed run takes after
+    OR-reducing the flags.  Returns True when the margin sufficed."""
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+    r0 = runners[0]
+
+    def one_pass(full):
+        for r in runners:
+            r.full_next = full
+            if r.flag is not None:
+                r.flag.zero_()
+            r.build_pyramids(prev, nxt, s, restrict=True)
+        for l in range(r0.levels - 1, -1, -1):
+            if l < r0.levels - 1:
+                for src, dst, a, b in r0.plan.transfers(l + 1):
+                    runners[dst].flow[l + 1][:, :, a:b].copy_(runners[src].flow[l + 1][:, :, a:b])
+                if not full:
+                    for r in runners:
+                        r._check_bound(l, s)
+            for r in runners:
+                r.level(l, prev, nxt, u, v, s)
+                if poison is not None and l > 0:
+                    a, b = r.plan.band(l, r.rank)
+                    r.flow[l][:, :, :a] = poison
+                    r.flow[l][:, :, b:] = poison
+        return any(r.violated() for r in runners) if not full else False
+
+    try:
+        if not one_pass(False):
+            return True
+        one_pass(True)
+        return False
+    finally:
+        for r in runners:
+            r.full_next = False

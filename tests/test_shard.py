@@ -219,3 +219,45 @@ def test_row_sharded_batch_matches_unsharded(rows, cols, levels, world, batch, s
     assert torch.equal(u, gu) and torch.equal(v, gv)
     eu, ev = orc.lk_flow_pyr(pairs[0][0], pairs[0][1], 15, levels)
     assert np.array_equal(u[0].cpu().numpy(), eu) and np.array_equal(v[0].cpu().numpy(), ev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,margin,expect_ok", [("textured", 64, True), ("textured", 0, False), ("smooth", 24, False)])
+def test_declared_next_margin_with_fallback(kind, margin, expect_ok):
+    """SURVEY.md section 8e's "declared bound on max |dv|": ranks build `next` only for band + margin rows (the
+    rest of their pyramid buffers is NaN here), a device-side check watches the coarse flow, and a raised flag
+    makes every rank repeat the step on the whole frame.  Exact either way.  `textured`: white-noise frames,
+    every window well conditioned, flow (3, -2) everywhere -> a 64-row margin suffices (the largest |dv| is 29), 0 rows do not;
+    `smooth`: the bench's frames, whose nearly degenerate windows throw isolated flows of hundreds of pixels
+    -> the fallback runs."""
+    import torch
+    from introtocomputervision_amd import lk
+    from introtocomputervision_amd._capi import Context
+    rows, cols, levels, world, batch = 540, 960, 5, 4, 2
+    ctx = Context(0)
+    if kind == "textured":
+        rng = np.random.default_rng(3)
+        pairs = []
+        for i in range(batch):
+            big = (rng.random((rows + 8, cols + 8)) * 255).astype(np.float32)
+            k = np.array([1, 2, 1], np.float32) / 4  # a little smoothing so that sub-sampled levels keep texture
+            big = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 0, big)
+            big = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 1, big).astype(np.float32)
+            pairs.append((np.ascontiguousarray(big[4:4 + rows, 4:4 + cols]), np.ascontiguousarray(big[2:2 + rows, 7:7 + cols])))
+    else:
+        pairs = [synth.lk_pair(0x5EED0005 + i, rows, cols, 3, -2) for i in range(batch)]
+    prev = torch.from_numpy(np.stack([p for p, _ in pairs])).cuda()
+    nxt = torch.from_numpy(np.stack([n for _, n in pairs])).cuda()
+    gu, gv = lk.calcOpticalFlowPyrBatch(prev, nxt, 15, levels, ctx=ctx)
+    runners = [shard.RowShardBatch(ctx, rows, cols, levels, 15, batch, g, world, next_margin=margin) for g in range(world)]
+    for r in runners:
+        for t in r.ppyr[1:] + r.npyr[1:]:
+            t.fill_(float("nan"))
+    u = torch.full_like(prev, float("nan"))
+    v = torch.full_like(prev, float("nan"))
+    ok = shard.run_virtual_batch_checked(runners, prev, nxt, u, v, poison=float("nan"))
+    torch.cuda.synchronize()
+    assert ok == expect_ok, (kind, margin, float(gv.abs().max()))
+    assert torch.equal(u, gu) and torch.equal(v, gv)
+    if expect_ok:  # the cheap path really skipped rows: some level's `next` buffer still holds NaN rows
+        assert any(bool(torch.isnan(t).any()) for t in runners[1].npyr[1:])
