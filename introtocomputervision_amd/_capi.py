@@ -197,13 +197,14 @@ class Context:
         if self.get_option(OPT_LK_NARROW_TILES):
             return f"lk_level_kernel<{r}, 1, 256, 32>"
         if win == 21:
-            return "lk_level_kernel<10, 1, 512, 16>"
+            big = self.get_option(OPT_LK_TALL_TILES) >= 0 and -(-cols // 64) * -(-rows // 32) * batch >= 512
+            return "lk_level_kernel<10, 1, 1024, 32>" if big else "lk_level_kernel<10, 1, 512, 16>"
         if win != 15:
             return f"lk_level_kernel<{r}, 1, 512, 32>"
         short = self.get_option(OPT_LK_SHORT_TILES)
         if short >= 0 and -(-cols // 64) * -(-rows // 16) * batch <= (short if short > 0 else 512):
             return "lk_level_kernel<7, 1, 512, 16>"
-        tall = self.get_option(OPT_LK_TALL_TILES) and -(-cols // 64) * -(-rows // 64) * batch >= 1024
+        tall = self.get_option(OPT_LK_TALL_TILES) > 0 and -(-cols // 64) * -(-rows // 64) * batch >= 1024
         if self.get_option(OPT_LK_STREAM):
             return "lk_level_stream_kernel<7, 1024, 64>" if tall else "lk_level_stream_kernel<7, 512, 32>"
         if self.get_option(OPT_LK_CHAIN) > 1 or self.get_option(OPT_LK_CHAIN) < 0:

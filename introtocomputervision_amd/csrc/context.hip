@@ -277,7 +277,7 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
     if (option == MICV_OPT_LK_STREAM)
         MICV_REQUIRE(value >= 0 && value <= 1, "micv_ctx_set_option: streamed launch must be 0 or 1");
     if (option == MICV_OPT_LK_TALL_TILES)
-        MICV_REQUIRE(value >= 0 && value <= 1, "micv_ctx_set_option: tall tiles must be 0 or 1");
+        MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: tall tiles must be -1, 0 or 1");
     ctx->opt[option] = value;
     return MICV_OK;
 }

@@ -1507,13 +1507,20 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             // MICV_OPT_LK_TALL_TILES: 64x64 tiles, 1024 threads, one workgroup per CU (131.6 KB of LDS): the
             // structural cut of the halo overhead (phases 0-3 on 80x80 for 64x64 = 1.56x instead of 1.875x,
             // row pass 78 rows for 64 = 1.22x instead of 1.44x).  Launches of at least four rounds only.
-            if (a.tall_tiles && (long)cdiv(a.cols, 64) * cdiv(a.rows, 64) * a.batch >= 1024) return launch_r<7, 1024, 64>(s, a);
+            if (a.tall_tiles > 0 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 64) * a.batch >= 1024) return launch_r<7, 1024, 64>(s, a);
             return launch_r<7, 512>(s, a);
         }
         case 7: return a.narrow ? launch_r<3, 256>(s, a) : launch_r<3, 512>(s, a);  // 512 threads: the staged / marching body
         case 21:  // the reference's default winSize (OpticalFlow.h:9,18): halo 12, 64x16 tiles fit two workgroups per CU
             // (64x32 tiles need 92 KB of LDS = one workgroup per CU: measured 17.6 Gpix/s against 18.6)
-            return a.narrow ? launch_r<10, 256>(s, a) : launch_r<10, 512, 16>(s, a);
+            if (a.narrow) return launch_r<10, 256>(s, a);
+            // Launches of at least two rounds: 64x32 tiles worked by 1024 threads (2 output rows per thread, 92 KB
+            // of LDS = one workgroup of 16 waves per CU) instead of two 512-thread 64x16 tiles per CU: the halo
+            // overhead falls from 3.4x to 2.4x (phases 0-3) and from 2.25x to 1.6x (row pass), which at this
+            // window outweighs what one workgroup per CU loses at its barriers (r03, 4 x 1080p: level 0
+            // 236 -> 223 us; the same trade LOSES at window 15, see MICV_OPT_LK_TALL_TILES).  -1 = never.
+            if (a.tall_tiles >= 0 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 32) * a.batch >= 512) return launch_r<10, 1024, 32>(s, a);
+            return launch_r<10, 512, 16>(s, a);
         case 11: return a.narrow ? launch_r<5, 256>(s, a) : launch_r<5, 512>(s, a);
         default:
             set_error("lk fused: window %d has no tiled instantiation", a.win);

@@ -534,3 +534,23 @@ def test_tall_tiles_are_bit_exact(mods, rows, cols, levels, batch, streamed):
         assert torch.equal(u, ref_u) and torch.equal(v, ref_v), rep
     eu, ev = orc.lk_flow_pyr(prev[0], nxt[0], 15, levels)
     assert np.array_equal(host(u[0]), eu) and np.array_equal(host(v[0]), ev)
+
+
+@pytest.mark.parametrize("rows,cols,levels,batch", [(540, 960, 3, 4), (1080, 1920, 5, 1), (517, 1111, 3, 2), (300, 400, 2, 1)])
+def test_window_21_tile_forms_are_bit_exact(mods, rows, cols, levels, batch):
+    """Window 21 (the reference's default winSize, OpticalFlow.h:9,18): big launches run 64x32 tiles with 1024
+    threads, small ones 64x16 tiles with 512 (MICV_OPT_LK_TALL_TILES = -1 forces the latter).  Same bits,
+    equal to the oracle."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(100 + i, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    outs = []
+    for opt in (0, -1, 1):
+        ctx = _capi.Context(0)
+        ctx.set_option(_capi.OPT_LK_TALL_TILES, opt)
+        outs.append(lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 21, levels, ctx=ctx))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+    eu, ev = orc.lk_flow_pyr(prev[0], nxt[0], 21, levels)
+    assert np.array_equal(host(outs[0][0][0]), eu) and np.array_equal(host(outs[0][1][0]), ev)
