@@ -118,10 +118,12 @@ struct micv_ctx {
     std::vector<LkSched> lk_sched;
     // Ticket counters of the streamed LK level launch: 16 slots of 16 words (8 per-XCD counters, the
     // count of workgroups that have left, padding), zero when idle (the launch resets its own slot);
-    // handed out round-robin, so launches in flight at the same time use different slots.
+    // one slot per stream the context has launched on (context.hip).
     unsigned *lk_tickets = nullptr;
-    int lk_ticket_rr = 0;
-    int lk_ticket_slot(unsigned **out);
+    static constexpr int kLkTicketSlots = 16;
+    hipStream_t lk_ticket_stream[kLkTicketSlots] = {};
+    int lk_ticket_used = 0;
+    int lk_ticket_slot(hipStream_t stream, unsigned **out);
     // Hough trig tables (hough.hip), uploaded once per context: [0] theta = -90.., [1] theta = 0..
     void *trig_tables[2] = {nullptr, nullptr};
     void *io_acquire(size_t bytes);

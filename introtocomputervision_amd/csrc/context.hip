@@ -200,6 +200,7 @@ int micv_ctx_create(int device, micv_ctx **out) {
 void micv_ctx_destroy(micv_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();  // launches in flight may still use the arena, the schedules or the ticket slots
     (void)micv_profile_reset(ctx);
     if (ctx->stamps) (void)hipFree(ctx->stamps);
     for (int i = 0; i < 3; i++) {
@@ -217,19 +218,32 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     delete ctx;
 }
 
-int micv_ctx::lk_ticket_slot(unsigned **out) {
-    constexpr int kSlots = 16, kWords = 16;
+// Ticket counters of the streamed level launch.  One slot PER STREAM (round-robin slots could put
+// two launches that run at the same time on different streams onto one slot, where they would take tickets
+// off each other): launches on one stream are ordered, so they may share their slot -- the last workgroup
+// out of a launch zeroes it for the next.  A context that meets more than kLkTicketSlots different streams
+// gets MICV_EUNSUPPORTED and the caller takes the plain launch.
+int micv_ctx::lk_ticket_slot(hipStream_t stream, unsigned **out) {
+    constexpr int kWords = 16;
     if (!lk_tickets) {
         void *p = nullptr;
-        MICV_HIP(hipMalloc(&p, kSlots * kWords * sizeof(unsigned)));
-        hipError_t e = hipMemset(p, 0, kSlots * kWords * sizeof(unsigned));
+        MICV_HIP(hipMalloc(&p, kLkTicketSlots * kWords * sizeof(unsigned)));
+        hipError_t e = hipMemset(p, 0, kLkTicketSlots * kWords * sizeof(unsigned));
         if (e != hipSuccess) {
             (void)hipFree(p);
             MICV_HIP(e);
         }
         lk_tickets = static_cast<unsigned *>(p);
     }
-    *out = lk_tickets + (size_t)(lk_ticket_rr++ % kSlots) * kWords;
+    int slot = -1;
+    for (int i = 0; i < lk_ticket_used; i++)
+        if (lk_ticket_stream[i] == stream) slot = i;
+    if (slot < 0) {
+        if (lk_ticket_used >= kLkTicketSlots) return MICV_EUNSUPPORTED;
+        slot = lk_ticket_used++;
+        lk_ticket_stream[slot] = stream;
+    }
+    *out = lk_tickets + (size_t)slot * kWords;
     return MICV_OK;
 }
 

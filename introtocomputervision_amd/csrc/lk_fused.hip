@@ -1397,7 +1397,9 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             int nblocks = 0;
             MICV_TRY(get_schedule<C>(a, 1, &sched, &nblocks));
             unsigned *tickets = nullptr;
-            MICV_TRY(a.ctx->lk_ticket_slot(&tickets));
+            const int trc = a.ctx->lk_ticket_slot(s, &tickets);
+            if (trc != MICV_OK && trc != MICV_EUNSUPPORTED) return trc;
+            if (trc == MICV_OK) {
             static thread_local int stream_dev = -1;
             static thread_local int n_cu = 0;
             int dev = 0;
@@ -1414,6 +1416,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             lk_level_stream_kernel<R, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(a, taps, sched, nblocks / 8, tickets);
             MICV_LAUNCH_CHECK();
             return MICV_OK;
+            }  // no ticket slot left for this stream: the plain launch below
         }
     }
     if constexpr (C::CHAIN_OK) {

@@ -92,12 +92,26 @@ class cpu:  # noqa: N801
 gpu = cpu
 
 
-def getAnglesFromGradients(gradX, gradY, ctx=None):
-    """sift::getAnglesFromGradients (Descriptors.cpp:7-25) -> angles (radians)."""
+def _check_grad_pair(gradX, gradY, *device_lists):
+    """gradX / gradY go to the kernels with ONE shape and pitch: both must agree (and live on one device,
+    together with any list the kernel indexes them by)."""
     B.check2d(gradX, np.float32, name="gradX")
     B.check2d(gradY, np.float32, name="gradY")
+    if B.is_dev(gradX) != B.is_dev(gradY):
+        raise ValueError("gradX and gradY: one is a device tensor, the other is not")
     if tuple(gradX.shape) != tuple(gradY.shape) or B.stride_bytes(gradX) != B.stride_bytes(gradY):
         raise ValueError("gradX and gradY differ in size / stride")
+    if B.is_dev(gradX):
+        if gradY.device != gradX.device:
+            raise ValueError("gradX and gradY live on different devices")
+        for name, t in device_lists:
+            if not (B.is_dev(t) and t.is_cuda and t.device == gradX.device):
+                raise ValueError(f"{name}: must be a CUDA tensor on gradX's device (numpy inputs take the host path)")
+
+
+def getAnglesFromGradients(gradX, gradY, ctx=None):
+    """sift::getAnglesFromGradients (Descriptors.cpp:7-25) -> angles (radians)."""
+    _check_grad_pair(gradX, gradY)
     rows, cols = gradX.shape
     ang = B.empty_like_shape(gradX, (rows, cols))
     c = _ctx_for(gradX, ctx)
@@ -114,8 +128,7 @@ def getAnglesFromGradients(gradX, gradY, ctx=None):
 def getKeypoints(gradX, gradY, cornerLocs, size, ctx=None):
     """sift::getKeypoints (Descriptors.cpp:27-47) -> [n, 4] float32 (x, y, size, angle_deg):
     the fields of the cv::KeyPoint the reference constructs."""
-    B.check2d(gradX, np.float32, name="gradX")
-    B.check2d(gradY, np.float32, name="gradY")
+    _check_grad_pair(gradX, gradY, ("cornerLocs", cornerLocs)) if B.is_dev(gradX) else _check_grad_pair(gradX, gradY)
     rows, cols = gradX.shape
     c = _ctx_for(gradX, ctx)
     n = int(cornerLocs.shape[0])
@@ -139,8 +152,7 @@ def computeDescriptors(gradX, gradY, keypoints, ctx=None):
     """The descriptor step of Solution::siftHelper (ps4_cpp/src/Solution.cpp:166-169,
     cv::xfeatures2d::SIFT::compute): [n, 4] keypoints (x, y, size, angle_deg) as getKeypoints returns
     them -> [n, 128] float32 descriptors (4 x 4 x 8 bins, 8-bit values).  Arithmetic: DESIGN.md §2."""
-    B.check2d(gradX, np.float32, name="gradX")
-    B.check2d(gradY, np.float32, name="gradY")
+    _check_grad_pair(gradX, gradY, ("keypoints", keypoints)) if B.is_dev(gradX) else _check_grad_pair(gradX, gradY)
     rows, cols = gradX.shape
     c = _ctx_for(gradX, ctx)
     if B.is_dev(gradX):

@@ -9,17 +9,29 @@ import numpy as np
 from . import _buf as B
 from ._capi import Context, check, lib
 
-_default_ctx = {}
+from collections import OrderedDict
+
+_default_ctx = OrderedDict()
+_DEFAULT_CTX_MAX = 8
 
 
 def default_context(device=0, stream=0):
     """One default context per (device, stream): a context owns ONE scratch arena and its auxiliary
     streams, so launches from two streams must not share it (they would race on the arena with no
-    error).  Callers that manage streams themselves pass their own Context per stream."""
+    error).  The cache holds the 8 most recently used pairs; an evicted context is destroyed (its arena,
+    streams and cached device blocks are freed), so a caller that runs under many short-lived torch
+    streams does not grow device memory without bound.  Long-running callers pass their own Context."""
     key = (int(device), int(stream or 0))
-    if key not in _default_ctx:
-        _default_ctx[key] = Context(device)
-    return _default_ctx[key]
+    ctx = _default_ctx.get(key)
+    if ctx is None:
+        ctx = Context(device)
+        _default_ctx[key] = ctx
+        while len(_default_ctx) > _DEFAULT_CTX_MAX:
+            _, old = _default_ctx.popitem(last=False)
+            old.close()  # micv_ctx_destroy synchronises the device before freeing what launches may still use
+    else:
+        _default_ctx.move_to_end(key)
+    return ctx
 
 
 def _ctx_for(a, ctx):
