@@ -170,11 +170,28 @@ __device__ __forceinline__ void pk_fma_skew(v2f &acc, v2f p, v2f gpair) {
         asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(p), "s"(gpair));
 }
 
-template <int W, int NP, int J, int S>
+// Where value I of a chain's window lives: register pair PAIR, half HALF.  The skewed step picks one half of
+// one aligned pair by op_sel, so ANY fixed placement works -- the chains are indifferent to which two values
+// share a register pair.  SlotAdjacent: (I, I+1) together, what a ds_read_b128 of a row delivers (row pass).
+// SlotStride4: (I, I+4) together, what ONE ds_read2st64_b32 delivers from the XOR-swizzled row buffers
+// (rows q and q+4 share a swizzle class, so one base register + two immediate offsets reach both): the
+// column pass then needs no v_mov to assemble its pairs (r03: 33 of the 219 instructions of a column pass
+// were such moves).
+struct SlotAdjacent {
+    static constexpr int pair(int i) { return i >> 1; }
+    static constexpr int half(int i) { return i & 1; }
+};
+struct SlotStride4 {
+    static constexpr int pair(int i) { return (i >> 3) * 4 + (i & 3); }
+    static constexpr int half(int i) { return (i >> 2) & 1; }
+};
+
+template <typename SL, int W, int NP, int J, int S>
 __device__ __forceinline__ void skew_step(v2f &acc, const v2f (&P)[NP], const TapsN<W> &g) {
     constexpr int I = J + S;  // index of the value both lanes use at this step
-    static_assert(I < 2 * NP, "skewed chain reads inside its window");
-    const float pv = (I & 1) ? P[I >> 1].y : P[I >> 1].x;
+    constexpr int PI = SL::pair(I), H = SL::half(I);
+    static_assert(PI < NP, "skewed chain reads inside its window");
+    const float pv = H ? P[PI].y : P[PI].x;
     if (S == 0) {
         acc.x = fmaf(pv, g.k[0], 0.f);  // output J, tap 0; output J+1 has not started
         acc.y = 0.f;
@@ -182,14 +199,14 @@ __device__ __forceinline__ void skew_step(v2f &acc, const v2f (&P)[NP], const Ta
         acc.y = fmaf(pv, g.k[W - 1], acc.y);  // output J+1, last tap; output J is complete
     } else {
         const v2f gp = {g.k[S - 1], g.k[S]};
-        pk_fma_skew<I & 1>(acc, P[I >> 1], gp);
+        pk_fma_skew<H>(acc, P[PI], gp);
     }
 }
 
-template <int W, int NP, int J, int... S>
+template <typename SL, int W, int NP, int J, int... S>
 __device__ __forceinline__ void skew_chain(v2f &acc, const v2f (&P)[NP], const TapsN<W> &g,
                                            std::integer_sequence<int, S...>) {
-    (skew_step<W, NP, J, S>(acc, P, g), ...);
+    (skew_step<SL, W, NP, J, S>(acc, P, g), ...);
 }
 
 // Four adjacent outputs of the row pass of the product field a*b, windows given as aligned pairs.
@@ -200,8 +217,8 @@ __device__ __forceinline__ void row_taps_skew(const v2f (&a)[C::WV * 2], const v
 #pragma unroll
     for (int i = 0; i < C::WV * 2; i++) P[i] = a[i] * b[i];  // v_pk_mul_f32, each product once
     v2f acc0, acc1;
-    skew_chain<C::W, C::WV * 2, 0>(acc0, P, g, std::make_integer_sequence<int, C::W + 1>{});
-    skew_chain<C::W, C::WV * 2, 2>(acc1, P, g, std::make_integer_sequence<int, C::W + 1>{});
+    skew_chain<SlotAdjacent, C::W, C::WV * 2, 0>(acc0, P, g, std::make_integer_sequence<int, C::W + 1>{});
+    skew_chain<SlotAdjacent, C::W, C::WV * 2, 2>(acc1, P, g, std::make_integer_sequence<int, C::W + 1>{});
     *reinterpret_cast<float4 *>(out) = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
 }
 
@@ -223,11 +240,11 @@ __device__ __forceinline__ void load_window_pairs(const float *__restrict__ A, i
 // FMA of the pass is one lane of a v_pk_fma_f32 and each output still runs its own chain over taps
 // 0..2R in order -- the bits of the scalar loop it replaces (4 x 15 v_fma_f32 -> 2 x 16 packed).
 template <typename C, int... PJ>
-__device__ __forceinline__ void col_pairs(const v2f (&V)[(C::RPT + 2 * C::R + 1) / 2], float (&S)[C::RPT],
+__device__ __forceinline__ void col_pairs(const v2f (&V)[((C::RPT + 2 * C::R + 7) / 8) * 4], float (&S)[C::RPT],
                                           const TapsN<C::W> &g, std::integer_sequence<int, PJ...>) {
-    constexpr int NP = (C::RPT + 2 * C::R + 1) / 2;
+    constexpr int NP = ((C::RPT + 2 * C::R + 7) / 8) * 4;
     v2f acc[C::RPT / 2];
-    (skew_chain<C::W, NP, 2 * PJ>(acc[PJ], V, g, std::make_integer_sequence<int, C::W + 1>{}), ...);
+    (skew_chain<SlotStride4, C::W, NP, 2 * PJ>(acc[PJ], V, g, std::make_integer_sequence<int, C::W + 1>{}), ...);
 #pragma unroll
     for (int i = 0; i < C::RPT / 2; i++) {
         S[2 * i] = acc[i].x;
@@ -235,17 +252,68 @@ __device__ __forceinline__ void col_pairs(const v2f (&V)[(C::RPT + 2 * C::R + 1)
     }
 }
 
+// The staged values of one column pass, read with hand-placed ds_read2st64_b32: pair p = (row I0, row I0 + 4)
+// of field F's row buffer, I0 = 8 (p / 4) + p % 4.  Rows of one swizzle class (q mod 4) share the lane part of
+// their address, and a row is exactly one 64-dword unit of the instruction's offsets, so FOUR address
+// registers (cls[k], computed once per tile for all five fields) and two immediates reach every cell of all
+// three row buffers -- 9 loads per field, no address arithmetic, no v_mov.  (Left to the compiler the loads
+// of consecutive fields get merged across row buffers -- same cell, 46 rows apart -- and every chain value
+// then costs a v_mov to reach its pair: 33 of a pass's 219 instructions, r03.)  The loads are asm the
+// compiler does not count: the wait statement names every destination, so nothing reads them early, and
+// the "memory" clobber keeps them behind the barrier and the row-pass stores they depend on.
+template <typename C, int F, int P>
+__device__ __forceinline__ void col_load_pair(v2f &dst, const int (&cls)[4]) {
+    constexpr int NV = C::RPT + 2 * C::R;
+    constexpr int I0 = 8 * (P / 4) + (P & 3), I1 = I0 + 4, O0 = I0 + F * C::GH, O1 = I1 + F * C::GH;
+    static_assert(C::RBS == 64 && O1 < 256, "one row = one 64-dword unit; offsets are 8 bits");
+    // A pair whose second row lies past the window (I1 >= NV) is loaded whole all the same: its upper half is
+    // never used by a chain, the address stays inside the kernel's LDS (at most 2 GH + TH + 2R + 4 rows from
+    // rb0), and the alternative -- a single ds_read_b32 into a float that is then packed into the pair -- would
+    // make the compiler copy the asm's destination BEFORE the wait below (hipcc counts an asm output as written
+    // at the end of the statement): stale data, timing-dependent.
+    if constexpr (I0 >= NV) {
+        dst = (v2f){0.f, 0.f};
+    } else {
+        static_assert((2 * C::GH + C::TH + 2 * C::R + 8) * C::RBS <= C::LDS_FLOATS, "the spare half-pair reads stay inside LDS");
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(cls[P & 3]), "i"(O0), "i"(O1) : "memory");
+    }
+}
+
+template <typename C, int F, int... PS>
+__device__ __forceinline__ void col_load_all(v2f (&V)[sizeof...(PS)], const int (&cls)[4], std::integer_sequence<int, PS...>) {
+    (col_load_pair<C, F, PS>(V[PS], cls), ...);
+}
+
+// s_waitcnt for hand-placed LDS loads, naming their destinations (four per statement; a wait on a drained
+// counter costs nothing), so the compiler places every use -- and every copy -- of them behind it.
+template <int N>
+__device__ __forceinline__ void lds_wait_all(v2f (&V)[N]) {
+    static_assert(N % 4 == 0, "pairs come in fours");
+#pragma unroll
+    for (int i = 0; i < N; i += 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[i]), "+v"(V[i + 1]), "+v"(V[i + 2]), "+v"(V[i + 3]));
+}
+
+// cls[k] = LDS byte address, in row buffer 0, of column c's cell in row r0 -- with the chunk swizzle of the
+// rows r0 + I, I = k (mod 4): rb_off() swizzles by the row's own index mod 4, and r0 is a multiple of RPT
+// only (RPT = 2: 64x16 tiles and the 1024-thread window-21 tiles), so the class of staged row I is
+// (r0 + k) & 3, not k.  Row r0 + I is then cls[I & 3] + I rows, the rows being the immediates of the loads.
 template <typename C>
-__device__ __forceinline__ void col_pass(const float *__restrict__ rb, float (&S)[C::RPT],
-                                         const TapsN<C::W> &g, int c, int r0) {
-    constexpr int R = C::R, NV = C::RPT + 2 * R, NP = (NV + 1) / 2;
+__device__ __forceinline__ void col_bases(const float *rb0, int c, int r0, int (&cls)[4]) {
+    typedef const __attribute__((address_space(3))) float lds_cfloat;
+    const int base = (int)(size_t)(lds_cfloat *)rb0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        cls[k] = base + 4 * (r0 * C::RBS + 4 * ((c >> 2) ^ (2 * ((r0 + k) & 3))) + (c & 3));
+}
+
+template <typename C, int F>
+__device__ __forceinline__ void col_pass(const int (&cls)[4], float (&S)[C::RPT], const TapsN<C::W> &g) {
+    constexpr int NV = C::RPT + 2 * C::R, NP = ((NV + 7) / 8) * 4;
     static_assert(C::RPT % 2 == 0, "column outputs in pairs");
     v2f V[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-        V[i].x = rb[rb_off(r0 + 2 * i, c >> 2) + (c & 3)];
-        V[i].y = 2 * i + 1 < NV ? rb[rb_off(r0 + 2 * i + 1, c >> 2) + (c & 3)] : 0.f;
-    }
+    col_load_all<C, F>(V, cls, std::make_integer_sequence<int, NP>{});
+    lds_wait_all(V);
     col_pairs<C>(V, S, g, std::make_integer_sequence<int, C::RPT / 2>{});
 }
 
@@ -977,9 +1045,11 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         if (STREAM && tid == 0) *link->slot = ticket;
         __syncthreads();
         MICV_STOP(41)
-        col_pass<C>(rb0, Sxx, g, c, r0);
-        col_pass<C>(rb1, Sxy, g, c, r0);
-        col_pass<C>(rb2, Syy, g, c, r0);
+        int cls[4];  // the column pass's four address registers (all five fields)
+        col_bases<C>(rb0, c, r0, cls);
+        col_pass<C, 0>(cls, Sxx, g);
+        col_pass<C, 1>(cls, Sxy, g);
+        col_pass<C, 2>(cls, Syy, g);
         // 64x16 tiles: finish the three column chains here instead of letting them sink below the
         // barrier into sweep B (their 48 loaded values would be spilled there)
         if (TH == 16) __builtin_amdgcn_sched_barrier(0);
@@ -1025,8 +1095,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             v4f *dst = reinterpret_cast<v4f *>(X);
             for (int i = tid; i < C::CARRY_F / 4; i += NT) dst[i] = src[i];
         }
-        col_pass<C>(rb0, Sxt, g, c, r0);
-        col_pass<C>(rb1, Syt, g, c, r0);
+        col_pass<C, 0>(cls, Sxt, g);
+        col_pass<C, 1>(cls, Syt, g);
     }
     MICV_STAMP(4)
 

@@ -177,3 +177,37 @@ def test_cmake_build_exports_the_same_abi(tmp_path):
     deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
     assert "amdhip64" in deps and "torch" not in deps and "oracle" not in deps
     assert os.path.exists(os.path.join(b, "liboracle.so"))
+
+
+def test_hand_placed_lds_loads_are_not_touched_before_their_wait():
+    """The column pass of the LK level kernel reads LDS with inline-asm ds_read2st64_b32 (the compiler's own
+    load merging costs a v_mov per value there).  hipcc does not count asm loads: a copy, spill or reuse of a
+    destination register between the load and the asm `s_waitcnt lgkmcnt(0)` would read stale data, depending
+    on timing.  tools/audit_asm_loads.py compiles lk_fused.hip and checks the ISA of every kernel; its
+    detector is checked first on a doctored listing."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("audit", os.path.join(ROOT, "tools", "audit_asm_loads.py"))
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    good = """_Zk:
+\t;;#ASMSTART
+\tds_read2st64_b32 v[4:5], v9 offset0:1 offset1:5
+\t;;#ASMEND
+\tv_add_u32_e32 v1, v2, v3
+\t;;#ASMSTART
+\ts_waitcnt lgkmcnt(0)
+\t;;#ASMEND
+\tv_pk_fma_f32 v[6:7], v[4:5], s[0:1], v[6:7]
+"""
+    assert audit.audit(good) == ([], 1, 1)
+    for bad_line in ("\tv_mov_b32_e32 v8, v5", "\tv_pk_fma_f32 v[6:7], v[4:5], s[0:1], v[6:7]", "\ts_barrier"):
+        bad = good.replace("\tv_add_u32_e32 v1, v2, v3", bad_line)
+        problems, loads, kernels = audit.audit(bad)
+        assert len(problems) == 1 and loads == 1, bad_line
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ", 0 problems" in r.stdout and " 0 hand-placed" not in r.stdout
