@@ -288,10 +288,46 @@ __device__ __forceinline__ void col_load_all(v2f (&V)[sizeof...(PS)], const int 
 // counter costs nothing), so the compiler places every use -- and every copy -- of them behind it.
 template <int N>
 __device__ __forceinline__ void lds_wait_all(v2f (&V)[N]) {
-    static_assert(N % 4 == 0, "pairs come in fours");
 #pragma unroll
-    for (int i = 0; i < N; i += 4)
+    for (int i = 0; i + 4 <= N; i += 4)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[i]), "+v"(V[i + 1]), "+v"(V[i + 2]), "+v"(V[i + 3]));
+    constexpr int T = N & ~3;
+    if constexpr (N % 4 == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[T]), "+v"(V[T + 1]), "+v"(V[T + 2]));
+    if constexpr (N % 4 == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[T]), "+v"(V[T + 1]));
+    if constexpr (N % 4 == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[T]));
+}
+
+// The march's coarse block (dma_coarse layout: rows of u and v interleaved, CWP floats each): the (u, v) pair
+// of coarse column k is ds_read2_b32 offset0:k offset1:k + CWP.  Left to itself the compiler pairs ADJACENT
+// columns instead -- (u[0], u[1]) and (v[0], v[1]) -- and transposes with three v_mov per coarse row.  Same
+// discipline as the column pass: whole pairs, "memory" clobber, one wait naming every destination.  Rows come
+// three to a base register (offsets are 8 bits: 2 * 2 CWP + CWP + 2 < 256).
+template <typename C, int I>
+__device__ __forceinline__ void coarse_row_load(v2f *cc, const int (&a)[2], const int (&b)[2]) {
+    constexpr int CWP = C::CWP, O = (I % 3) * 2 * CWP;
+    static_assert(O + CWP + 2 < 256 && I < 6, "offsets are 8 bits, two base registers");
+#define MICV_RD2(dst, addr, o0, o1) \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "i"(o0), "i"(o1) : "memory")
+    MICV_RD2(cc[5 * I + 0], a[I / 3], O, O + CWP);
+    MICV_RD2(cc[5 * I + 1], a[I / 3], O + 1, O + CWP + 1);
+    MICV_RD2(cc[5 * I + 2], a[I / 3], O + 2, O + CWP + 2);
+    MICV_RD2(cc[5 * I + 3], b[I / 3], O, O + CWP);
+    MICV_RD2(cc[5 * I + 4], b[I / 3], O + 1, O + CWP + 1);
+#undef MICV_RD2
+}
+
+template <typename C, int... IS>
+__device__ __forceinline__ void coarse_block_load(v2f (&cc)[5 * sizeof...(IS)], const float *c, int odd,
+                                                  std::integer_sequence<int, IS...>) {
+    typedef const __attribute__((address_space(3))) float lds_cfloat;
+    constexpr int NR = sizeof...(IS);
+    int a[2], b[2];
+    a[0] = (int)(size_t)(lds_cfloat *)c;
+    b[0] = a[0] + 4 * odd;
+    a[1] = NR > 3 ? a[0] + 4 * 3 * 2 * C::CWP : a[0];
+    b[1] = NR > 3 ? b[0] + 4 * 3 * 2 * C::CWP : b[0];
+    (coarse_row_load<C, IS>(cc, a, b), ...);
+    lds_wait_all(cc);
 }
 
 // cls[k] = LDS byte address, in row buffer 0, of column c's cell in row r0 -- with the chunk swizzle of the
@@ -695,18 +731,15 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     // tap 0 of column 0 (coarse 1, not 0) and tap 4 of column cols-1 (coarse fc-2, not fc-1);
                     // the same holds for rows.  Those are c2 / c0 of this job's own three columns.
                     const bool first_col = !INT && gx == 0, last_col = !INT && gx == cols - 1;
+                    constexpr int NR = RPT / 2 + 2;
+                    v2f cc[CDMA ? 5 * NR : 1];
+                    if constexpr (CDMA)  // rows of u and v interleaved (dma_coarse): a pair = one ds_read2_b32
+                        coarse_block_load<C>(cc, Xs + cyb * (2 * C::CWP) + ccb, odd, std::make_integer_sequence<int, NR>{});
 #pragma unroll
-                    for (int i = 0; i < RPT / 2 + 2; i++) {
+                    for (int i = 0; i < NR; i++) {
                         v2f c0, c1, c2, ca, cb;
-                        if (CDMA) {
-                            // rows of u and v interleaved (dma_coarse): a pair = one ds_read2_b32
-                            constexpr int CWP = C::CWP;
-                            const float *c = Xs + (cyb + i) * (2 * CWP) + ccb;
-                            c0 = (v2f){c[0], c[CWP]};
-                            c1 = (v2f){c[1], c[CWP + 1]};
-                            c2 = (v2f){c[2], c[CWP + 2]};
-                            ca = (v2f){c[odd], c[CWP + odd]};
-                            cb = (v2f){c[1 + odd], c[CWP + 1 + odd]};
+                        if constexpr (CDMA) {
+                            c0 = cc[5 * i], c1 = cc[5 * i + 1], c2 = cc[5 * i + 2], ca = cc[5 * i + 3], cb = cc[5 * i + 4];
                         } else {
                             const v2f *c = Cuv + (cyb + i) * CW + ccb;
                             c0 = c[0];
