@@ -56,86 +56,130 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float *__res
 // lane -> (row = lane & 3, group = lane >> 2) mapping make them conflict-free); the weight table
 // w[wy][wx] = g[wy]*g[wx] (float product, as above) arrives in SGPRs.  Every accumulator is still
 // the (wy, wx)-raster fmaf chain of Harris.cu:36-43, so the bits do not change.
+//
+// Outputs (0, 1) and (2, 3) share every weight, so each field's four chains are two v_pk_fma_f32
+// chains: tap wx multiplies the window's cells (wx, wx + 1) / (wx + 2, wx + 3), which for even wx
+// are the register pairs the b128 reads delivered and for odd wx one v_pk_mov_b32 apart (three
+// odd pairs per field and window row): 39 VALU instructions per window row instead of 60.
+// Interior tiles stage with aligned 16-byte loads (columns x0 - 4 .. x0 + 67, the four left of
+// the halo dropped) and store float4; tiles touching the left / right edge, or unaligned images,
+// take the clamped scalar loads.
 template <int R>
 struct HarrisW {
     float w[(2 * R + 1) * (2 * R + 1)];
 };
 typedef float hv4f __attribute__((ext_vector_type(4)));
+typedef float hv2f __attribute__((ext_vector_type(2)));
 
-template <int R>
-__global__ __launch_bounds__(256) void harris_response_tiled_kernel(
+template <int R, int TH>
+__global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
     const float *__restrict__ gx, const float *__restrict__ gy, int gstride, int rows, int cols,
-    HarrisW<R> hw, float alpha, float *__restrict__ resp, int rstride) {
-    constexpr int W = 2 * R + 1, TW = 64, TH = 16, RW = TW + 2 * R, RH = TH + 2 * R, PS = 80;
-    constexpr int NV = (4 + 2 * R + 3) / 4;
-    static_assert(60 + 4 * NV <= PS, "window reads stay inside a plane row");
+    HarrisW<R> hw, float alpha, float *__restrict__ resp, int rstride, int vec_ok) {
+    // LDS column = global column - (x0 - 4): the 72 columns x0 - 4 .. x0 + 67 are 18 aligned float4 of the
+    // image, written whole (the window of output column c starts at LDS column c + 4 - R)
+    constexpr int W = 2 * R + 1, TW = 64, NT = 16 * TH, RH = TH + 2 * R, PS = 80, SH = 4 - R, V4 = (TW + 8) / 4;
+    constexpr int NV = (SH + 4 + 2 * R + 3) / 4;  // float4 per window row, from the thread's own column group
+    static_assert(R >= 1 && R <= 4 && 60 + 4 * NV <= PS, "window reads stay inside a plane row");
     __shared__ __attribute__((aligned(16))) float XX[RH * PS], XY[RH * PS], YY[RH * PS];
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    {
-        constexpr int NB = (RH * RW + 255) / 256;
-        float vx[NB], vy[NB];
+    constexpr int NB = (RH * V4 + NT - 1) / NT;
+    hv4f vx[NB], vy[NB];
+    if (vec_ok && x0 >= 4 && x0 + TW + 4 <= cols) {
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const int i = threadIdx.x + k * 256 < RH * RW ? threadIdx.x + k * 256 : RH * RW - 1;
-            const int ly = i / RW, lx = i - ly * RW;
-            const int yy = clampi(y0 - R + ly, 0, rows - 1), xx = clampi(x0 - R + lx, 0, cols - 1);
-            vx[k] = gx[(size_t)yy * gstride + xx];
-            vy[k] = gy[(size_t)yy * gstride + xx];
+            const int i = threadIdx.x + k * NT < RH * V4 ? threadIdx.x + k * NT : RH * V4 - 1;
+            const int ly = i / V4, m = i - ly * V4;
+            const int yy = clampi(y0 - R + ly, 0, rows - 1);
+            const size_t o = (size_t)yy * gstride + (x0 - 4 + 4 * m);
+            vx[k] = *reinterpret_cast<const hv4f *>(gx + o);
+            vy[k] = *reinterpret_cast<const hv4f *>(gy + o);
         }
+    } else {
+        // tiles at the left / right edge (and unaligned images): clamped scalar loads, same slots
 #pragma unroll
         for (int k = 0; k < NB; k++) {
-            const int i = threadIdx.x + k * 256;
-            if (i < RH * RW) {
-                const int ly = i / RW, lx = i - ly * RW;
-                XX[ly * PS + lx] = vx[k] * vx[k];
-                XY[ly * PS + lx] = vx[k] * vy[k];
-                YY[ly * PS + lx] = vy[k] * vy[k];
+            const int i = threadIdx.x + k * NT < RH * V4 ? threadIdx.x + k * NT : RH * V4 - 1;
+            const int ly = i / V4, m = i - ly * V4;
+            const int yy = clampi(y0 - R + ly, 0, rows - 1);
+            const float *rx = gx + (size_t)yy * gstride, *ry_ = gy + (size_t)yy * gstride;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int xx = clampi(x0 - 4 + 4 * m + e, 0, cols - 1);
+                vx[k][e] = rx[xx];
+                vy[k][e] = ry_[xx];
             }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int i = threadIdx.x + k * NT;
+        if (i < RH * V4) {
+            const int ly = i / V4, m = i - ly * V4;
+            *reinterpret_cast<hv4f *>(XX + ly * PS + 4 * m) = vx[k] * vx[k];
+            *reinterpret_cast<hv4f *>(XY + ly * PS + 4 * m) = vx[k] * vy[k];
+            *reinterpret_cast<hv4f *>(YY + ly * PS + 4 * m) = vy[k] * vy[k];
         }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ry = 4 * wave + (lane & 3), c0 = 4 * (lane >> 2);
-    float mxx[4] = {0.f, 0.f, 0.f, 0.f}, mxy[4] = {0.f, 0.f, 0.f, 0.f}, myy[4] = {0.f, 0.f, 0.f, 0.f};
+    // [field][output pair]
+    hv2f acc[3][2];
+#pragma unroll
+    for (int f = 0; f < 3; f++) acc[f][0] = acc[f][1] = (hv2f){0.f, 0.f};
+    const float *planes[3] = {XX, XY, YY};
 #pragma unroll
     for (int wy = 0; wy < W; wy++) {
-        float a[4 * NV], b[4 * NV], c[4 * NV];
         const int o = (ry + wy) * PS + c0;
 #pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const hv4f va = *reinterpret_cast<const hv4f *>(XX + o + 4 * i);
-            const hv4f vb = *reinterpret_cast<const hv4f *>(XY + o + 4 * i);
-            const hv4f vc = *reinterpret_cast<const hv4f *>(YY + o + 4 * i);
-            a[4 * i] = va.x; a[4 * i + 1] = va.y; a[4 * i + 2] = va.z; a[4 * i + 3] = va.w;
-            b[4 * i] = vb.x; b[4 * i + 1] = vb.y; b[4 * i + 2] = vb.z; b[4 * i + 3] = vb.w;
-            c[4 * i] = vc.x; c[4 * i + 1] = vc.y; c[4 * i + 2] = vc.z; c[4 * i + 3] = vc.w;
-        }
+        for (int f = 0; f < 3; f++) {
+            // LDS cells c0 .. c0 + 4 NV - 1 of the window row: even pairs E[k] = (2k, 2k + 1) as read, odd pairs
+            // O[k] = (2k + 1, 2k + 2) one v_pk_mov_b32 away (the unused ones are dropped by the compiler)
+            hv2f E[2 * NV], O[2 * NV - 1];
 #pragma unroll
-        for (int wx = 0; wx < W; wx++) {
-            const float w = hw.w[wy * W + wx];
+            for (int i = 0; i < NV; i++) {
+                const hv4f v = *reinterpret_cast<const hv4f *>(planes[f] + o + 4 * i);
+                E[2 * i] = (hv2f){v.x, v.y};
+                E[2 * i + 1] = (hv2f){v.z, v.w};
+            }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                mxx[j] = fmaf(w, a[j + wx], mxx[j]);
-                mxy[j] = fmaf(w, b[j + wx], mxy[j]);
-                myy[j] = fmaf(w, c[j + wx], myy[j]);
+            for (int k = 0; k + 1 < 2 * NV; k++)  // dst.lo = E[k].hi, dst.hi = E[k + 1].lo
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O[k]) : "v"(E[k]), "v"(E[k + 1]));
+#pragma unroll
+            for (int wx = 0; wx < W; wx++) {
+                const float w = hw.w[wy * W + wx];
+                const hv2f w2 = (hv2f){w, w};
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int cell = SH + 2 * j + wx;
+                    const hv2f d = (cell & 1) ? O[cell >> 1] : E[cell >> 1];
+                    acc[f][j] = __builtin_elementwise_fma(w2, d, acc[f][j]);
+                }
             }
         }
         // pin the accumulators here: the row's FMAs must finish before the next row's reads are
-        // issued (the compiler otherwise hoists all 30 reads and holds 120 window registers)
-        asm volatile("" : "+v"(mxx[0]), "+v"(mxx[1]), "+v"(mxx[2]), "+v"(mxx[3]), "+v"(mxy[0]), "+v"(mxy[1]),
-                          "+v"(mxy[2]), "+v"(mxy[3]), "+v"(myy[0]), "+v"(myy[1]), "+v"(myy[2]), "+v"(myy[3])
+        // issued (the compiler otherwise hoists all the reads and holds every window register)
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
+                          "+v"(acc[2][1])
                      :: "memory");
     }
     const int y = y0 + ry;
     if (y >= rows) return;
+    float out[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int x = x0 + c0 + j;
-        if (x < cols) {
-            const float trace = mxx[j] + myy[j];
-            const float det = mxx[j] * myy[j] - mxy[j] * mxy[j];
-            resp[(size_t)y * rstride + x] = det - alpha * trace * trace;
-        }
+        const float mxx = acc[0][j >> 1][j & 1], mxy = acc[1][j >> 1][j & 1], myy = acc[2][j >> 1][j & 1];
+        const float trace = mxx + myy;
+        const float det = mxx * myy - mxy * mxy;
+        out[j] = det - alpha * trace * trace;
+    }
+    const int x = x0 + c0;
+    if (vec_ok && x + 3 < cols) {
+        *reinterpret_cast<hv4f *>(resp + (size_t)y * rstride + x) = (hv4f){out[0], out[1], out[2], out[3]};
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (x + j < cols) resp[(size_t)y * rstride + x + j] = out[j];
     }
 }
 
@@ -145,8 +189,15 @@ static void launch_harris_tiled(hipStream_t s, const float *gx, const float *gy,
     HarrisW<R> hw;
     for (int wy = 0; wy <= 2 * R; wy++)
         for (int wx = 0; wx <= 2 * R; wx++) hw.w[wy * (2 * R + 1) + wx] = g.k[wy] * g.k[wx];
-    harris_response_tiled_kernel<R><<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, 0, s>>>(
-        gx, gy, gstride, rows, cols, hw, alpha, resp, rstride);
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(resp)) & 15) == 0 &&
+                       (gstride & 3) == 0 && (rstride & 3) == 0;
+    // 64x32 tiles (512 threads) carry a sixth less halo per output; small images keep 64x16 for more blocks
+    if ((size_t)cdiv(cols, 64) * cdiv(rows, 32) >= 1024)
+        harris_response_tiled_kernel<R, 32><<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 512, 0, s>>>(
+            gx, gy, gstride, rows, cols, hw, alpha, resp, rstride, vec_ok);
+    else
+        harris_response_tiled_kernel<R, 16><<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, 0, s>>>(
+            gx, gy, gstride, rows, cols, hw, alpha, resp, rstride, vec_ok);
 }
 
 // ---- a10: threshold + non-maximum suppression ----------------------------------------------

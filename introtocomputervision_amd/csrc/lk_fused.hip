@@ -286,8 +286,9 @@ __device__ __forceinline__ void col_load_all(v2f (&V)[sizeof...(PS)], const int 
 
 // s_waitcnt for hand-placed LDS loads, naming their destinations (four per statement; a wait on a drained
 // counter costs nothing), so the compiler places every use -- and every copy -- of them behind it.
-template <int N>
-__device__ __forceinline__ void lds_wait_all(v2f (&V)[N]) {
+template <int N, int M>
+__device__ __forceinline__ void lds_wait_n(v2f (&V)[M]) {
+    static_assert(N <= M);
 #pragma unroll
     for (int i = 0; i + 4 <= N; i += 4)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[i]), "+v"(V[i + 1]), "+v"(V[i + 2]), "+v"(V[i + 3]));
@@ -327,7 +328,7 @@ __device__ __forceinline__ void coarse_block_load(v2f (&cc)[5 * sizeof...(IS)], 
     a[1] = NR > 3 ? a[0] + 4 * 3 * 2 * C::CWP : a[0];
     b[1] = NR > 3 ? b[0] + 4 * 3 * 2 * C::CWP : b[0];
     (coarse_row_load<C, IS>(cc, a, b), ...);
-    lds_wait_all(cc);
+    lds_wait_n<5 * NR>(cc);
 }
 
 // cls[k] = LDS byte address, in row buffer 0, of column c's cell in row r0 -- with the chunk swizzle of the
@@ -347,9 +348,13 @@ template <typename C, int F>
 __device__ __forceinline__ void col_pass(const int (&cls)[4], float (&S)[C::RPT], const TapsN<C::W> &g) {
     constexpr int NV = C::RPT + 2 * C::R, NP = ((NV + 7) / 8) * 4;
     static_assert(C::RPT % 2 == 0, "column outputs in pairs");
+    // pairs wholly past the window (a suffix of V) are constants: keep them out of the wait, which would make
+    // the compiler materialise them in registers
+    constexpr int NPL = NP - (8 * ((NP - 1) / 4) + ((NP - 1) & 3) >= NV) - (8 * ((NP - 2) / 4) + ((NP - 2) & 3) >= NV) -
+                        (8 * ((NP - 3) / 4) + ((NP - 3) & 3) >= NV);
     v2f V[NP];
     col_load_all<C, F>(V, cls, std::make_integer_sequence<int, NP>{});
-    lds_wait_all(V);
+    lds_wait_n<NPL>(V);
     col_pairs<C>(V, S, g, std::make_integer_sequence<int, C::RPT / 2>{});
 }
 

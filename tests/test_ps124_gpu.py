@@ -101,6 +101,27 @@ def test_harris_response_tiled_and_generic(M, rows, cols, win, sigma):
     assert np.array_equal(host(harris.getCornerResponse(dev(gx), dev(gy), win, sigma, 0.04)), exp)
 
 
+@pytest.mark.parametrize("win,sigma", [(3, 0.8), (5, 1.5), (7, 2.0)])
+@pytest.mark.parametrize("xoff,cols", [(0, 448), (0, 331), (1, 330), (4, 260), (2, 200)])
+def test_harris_response_interior_tiles_and_views(M, win, sigma, xoff, cols):
+    """Interior tiles stage with aligned float4 loads and store float4; column-offset views of a wider
+    device image (base not 16-byte aligned) and odd widths must take the scalar path and agree."""
+    import torch
+    harris, stereo, hough, synth = M
+    rows = 75
+    rng = np.random.default_rng(win * 100 + cols + xoff)
+    bx = (rng.standard_normal((rows, 456)) * 300).astype(np.float32)
+    by = (rng.standard_normal((rows, 456)) * 300).astype(np.float32)
+    bx[7, 130] = np.inf
+    by[40, 70] = np.nan
+    dx, dy = dev(bx), dev(by)
+    gx, gy = dx[:, xoff:xoff + cols], dy[:, xoff:xoff + cols]
+    exp = orc.harris_response(np.ascontiguousarray(bx[:, xoff:xoff + cols]), np.ascontiguousarray(by[:, xoff:xoff + cols]),
+                              win, sigma, 0.04)
+    got = host(harris.getCornerResponse(gx, gy, win, sigma, 0.04))
+    assert got.tobytes() == exp.tobytes()
+
+
 @pytest.mark.parametrize("dist", [0, 1, 3, 5, 16, 17])
 def test_harris_refine_ties_nan_inf(M, dist):
     """Quantised responses (many exact ties), -0/+0, infinities and NaNs: the tiled (max,
