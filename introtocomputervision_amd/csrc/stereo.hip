@@ -17,9 +17,15 @@
 // which is exactly the left -> right association.  Running best cost / disparity live in
 // registers; only the int8 disparity is written (9 B/px algorithmic).  VALU-bound: ~220 VALU
 // instructions per wave per disparity at r = 5 (C3: 0.27 ms measured vs 0.24 ms issue bound).
+//
+// NCC adds fl(acc / fl(sqrt(AT * E))) per (row, disparity): 28 instructions through the compiler's sqrtf and
+// division, 14 through the short exact sequences of ncc_arith.hpp, which a wave takes (per chunk of disparities)
+// when every pixel it staged is 0 or of magnitude in [2^-8, 2^16] -- tracked while staging, four integer
+// instructions per staged value.  C3 size: 0.62 -> 0.40 ms (2.24x -> 1.59x SSD).
 #include <type_traits>
 
 #include "kernels.hpp"
+#include "ncc_arith.hpp"
 
 namespace micv {
 
@@ -118,6 +124,13 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
         Lv[s] = a.left[(size_t)yy * a.stride + xl];
     }
 
+    // NCC: operands in the checked range take the short exact sqrt / division (ncc_arith.hpp)
+    NccRange pix_l;
+    if (MODE == ST_NCC) {
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) pix_l.add(Lv[s]);
+    }
+
     using acc_t = typename std::conditional<MODE == ST_SSD_SERIAL, int, float>::type;
     acc_t best[RPW];
     int bestd[RPW];
@@ -150,6 +163,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
         // is image column clamp(x_base + d0 + i) (clamp-to-edge), rows as for Lv.  Every later
         // read is an LDS read at lane + (d - d0): consecutive lanes, conflict-free.
         __builtin_amdgcn_wave_barrier();  // the previous chunk's reads are done (in-order LDS)
+        NccRange pix = pix_l, en;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
             const int yy = clampi(ys - R + s, 0, a.rows - 1);
@@ -157,8 +171,11 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
 #pragma unroll
             for (int h = 0; h < (ST_SPAN + 63) / 64; h++) {
                 const int i = lane + 64 * h;
-                if (ST_SPAN % 64 == 0 || i < ST_SPAN)
-                    Rs[s * ST_SPAN + i] = rr[clampi(x_base + d0 + i, 0, a.cols - 1)];
+                if (ST_SPAN % 64 == 0 || i < ST_SPAN) {
+                    const float v = rr[clampi(x_base + d0 + i, 0, a.cols - 1)];
+                    Rs[s * ST_SPAN + i] = v;
+                    if (MODE == ST_NCC) pix.add(v);
+                }
             }
         }
         if (MODE == ST_NCC) {
@@ -168,14 +185,21 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
 #pragma unroll
                 for (int h = 0; h < (ST_SPAN + 63) / 64; h++) {
                     const int i = lane + 64 * h;
-                    if (ST_SPAN % 64 == 0 || i < ST_SPAN)
-                        Es[j * ST_SPAN + i] = er[clampi(x_base + d0 + i - a.s_lo, 0, a.e_width - 1)];
+                    if (ST_SPAN % 64 == 0 || i < ST_SPAN) {
+                        const float v = er[clampi(x_base + d0 + i - a.s_lo, 0, a.e_width - 1)];
+                        Es[j * ST_SPAN + i] = v;
+                        en.add(v);
+                    }
                 }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int d1 = d0 + ST_DCH - 1 < a.max_d ? d0 + ST_DCH - 1 : a.max_d;
+        // (both switches are wave-uniform and loop-invariant; as template arguments the loop body has no branch,
+        // so the rows' DPP chains interleave instead of running one after the other behind wait states)
+        auto search = [&](auto short_arith, auto full_window) {
+        constexpr bool SHORT = decltype(short_arith)::value, FULLW = decltype(full_window)::value;
         for (int d = d0; d <= d1; d++) {
             const float *rcol = Rs + lane + (d - d0);
             const bool d_ok = MODE != ST_SSD_SERIAL || (d >= d_lo && d <= d_hi);
@@ -192,14 +216,19 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
                 }
                 if (s >= 2 * R) {
                     const int j = s - 2 * R;
-                    // 0 + x == x bit for bit when x is never -0 (x = diff^2, or an int): skip that add
-                    acc_t cs = MODE == ST_NCC ? (acc_t)0 : ring[(s - 2 * R) % W];
+                    // 0 + x == x bit for bit when x is never -0 (x = diff^2, or an int): skip that add.  A product
+                    // of NCC can be -0, but the column sum then differs (as -0 for +0) only when every term is -0,
+                    // the window sum only when every column sum is: a correlation of -0 for +0 (or NaN both
+                    // ways), and `nc > best` is false for either since best starts at 0 and only grows.
+                    acc_t cs = ring[(s - 2 * R) % W];
 #pragma unroll
-                    for (int k = MODE == ST_NCC ? 0 : 1; k < W; k++) cs += ring[(s - 2 * R + k) % W];
-                    const acc_t acc = systolic_sum<W>(cs, full);
+                    for (int k = 1; k < W; k++) cs += ring[(s - 2 * R + k) % W];
+                    const acc_t acc = systolic_sum<W>(cs, MODE == ST_NCC ? FULLW : full);
                     if (MODE == ST_NCC) {
                         const float accb = Es[j * ST_SPAN + lane + (d - d0)];  // window energy of `right`
-                        const float nc = (float)acc / sqrtf(AT[j] * accb);  // DisparityNCorr.cu:106
+                        const float pr = AT[j] * accb;
+                        // DisparityNCorr.cu:106
+                        const float nc = SHORT ? ncc_div((float)acc, ncc_sqrt(pr)) : (float)acc / sqrtf(pr);
                         if (nc > (float)best[j]) {                          // :108
                             best[j] = (acc_t)nc;
                             bestd[j] = d;
@@ -210,6 +239,22 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
                     }
                 }
             }
+        }
+        };
+        auto search_w = [&](auto short_arith) {
+            if (full)
+                search(short_arith, std::true_type{});
+            else
+                search(short_arith, std::false_type{});
+        };
+        if constexpr (MODE == ST_NCC) {
+            // wave-uniform: every staged operand of this chunk is in the checked range
+            if (__builtin_amdgcn_ballot_w64(!(pix.inside(NCC_PIX_LO, NCC_PIX_HI) && en.inside(NCC_EN_LO, NCC_EN_HI))) == 0)
+                search_w(std::true_type{});
+            else
+                search_w(std::false_type{});
+        } else {
+            search(std::false_type{}, std::true_type{});  // (SSD keeps `full` as a select: 57 VGPRs, 8 waves / SIMD)
         }
     }
     if (lane_ok) {

@@ -290,12 +290,14 @@ def test_rolling_at_the_reference_geometry(mods):
     assert np.array_equal(got, exp), (got != exp).sum()
 
 
-@pytest.mark.parametrize("kind", ["flat_noise", "constant", "zeros", "periodic", "huge", "tiny", "mixed_sign"])
+@pytest.mark.parametrize("kind", ["flat_noise", "constant", "zeros", "periodic", "huge", "tiny", "mixed_sign", "u8", "unit",
+                                  "edge_lo", "edge_hi", "below_lo", "above_hi", "one_outlier", "one_nan", "negative_u8"])
 def test_ncc_near_ties_and_degenerate_windows(mods, kind):
-    """disparityNCorr decides `nc > best` on a v_rsq_f32 estimate and forms the correctly rounded scores only
-    when the estimate is too close to call (r03).  Inputs made of ties and near-ties (every candidate within
-    2^-19 of the best), degenerate windows (zero energy: 0 / 0), and magnitudes outside v_rsq_f32's range drive
-    that exact path; the disparities must equal the oracle's, which always forms the exact score."""
+    """disparityNCorr forms fl(acc / fl(sqrt(AT * E))) with a short exact sequence (csrc/ncc_arith.hpp) when every
+    operand a wave stages is 0 or of magnitude in [2^-8, 2^16], and with the compiler's full-range sqrtf / division
+    otherwise (chosen per wave and chunk of disparities).  Inputs made of ties and near-ties, degenerate windows
+    (zero energy: 0 / 0), magnitudes at, just inside and just outside the range limits, and single out-of-range
+    pixels (so neighbouring waves take different paths) must all give the oracle's disparities."""
     lk, pyr, stereo, synth = mods
     rng = np.random.default_rng(4)
     rows, cols = 60, 150
@@ -314,8 +316,35 @@ def test_ncc_near_ties_and_degenerate_windows(mods, kind):
         left = (rng.random((rows, cols)) * 1e17 + 1e16).astype(np.float32); right = np.roll(left, 3, axis=1) * np.float32(1.5)
     elif kind == "tiny":
         left = (rng.random((rows, cols)) * 1e-17 + 1e-18).astype(np.float32); right = np.roll(left, 3, axis=1) * np.float32(1.5)
-    else:
+    elif kind == "mixed_sign":
         left = rng.standard_normal((rows, cols)).astype(np.float32); right = rng.standard_normal((rows, cols)).astype(np.float32)
+    elif kind in ("u8", "negative_u8"):
+        left = rng.integers(0, 256, (rows, cols)).astype(np.float32); right = np.roll(left, 4, axis=1).copy()
+        right[rng.random((rows, cols)) < 0.3] = 0
+        left[10:30, 20:60] = 0  # whole windows of zeros: 0 / 0
+        if kind == "negative_u8":
+            left -= 128; right -= 128
+    elif kind == "unit":
+        left = (rng.integers(0, 256, (rows, cols)) / 255.0).astype(np.float32); right = np.roll(left, 2, axis=1).copy()
+    elif kind in ("edge_lo", "below_lo"):
+        lo = np.float32(2.0 ** -8)
+        if kind == "below_lo":
+            lo = np.nextafter(lo, np.float32(0))
+        left = (lo * (1 + rng.integers(0, 3, (rows, cols)))).astype(np.float32); right = np.roll(left, 5, axis=1).copy()
+        left[5, 7] = lo; right[40, 100] = lo
+    elif kind in ("edge_hi", "above_hi"):
+        hi = np.float32(2.0 ** 16)
+        if kind == "above_hi":
+            hi = np.nextafter(hi, np.float32(np.inf))
+        left = (hi * rng.random((rows, cols))).astype(np.float32) ; right = np.roll(left, 5, axis=1).copy()
+        left[left < 2.0 ** -8] = 0
+        right[right < 2.0 ** -8] = 0
+        left[5, 7] = hi; right[40, 100] = hi
+    else:
+        left = rng.integers(1, 256, (rows, cols)).astype(np.float32); right = np.roll(left, 4, axis=1).copy()
+        bad = np.float32(np.nan) if kind == "one_nan" else np.float32(1e-30)
+        left[30, 75] = bad
+        right[12, 20] = bad
     for rad, flags in ((3, 0), (5, 1), (12, 0)):
         exp = orc.disparity_ncorr(left, right, rad, -20, 6, flags)
         got = host(stereo.disparityNCorr(dev(left), dev(right), rad, -20, 6, flags))
