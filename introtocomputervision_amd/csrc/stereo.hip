@@ -15,8 +15,12 @@
 // systolic chain of v_add_f32 with a DPP wave_shr:1 operand:
 //   acc <- shift_right_one_lane(acc) + colsum     (2r steps, unrolled, rows interleaved)
 // which is exactly the left -> right association.  Running best cost / disparity live in
-// registers; only the int8 disparity is written (9 B/px algorithmic).  VALU-bound: ~220 VALU
-// instructions per wave per disparity at r = 5 (C3: 0.27 ms measured vs 0.24 ms issue bound).
+// registers; only the int8 disparity is written (9 B/px algorithmic).  VALU-bound.  Per wave and
+// disparity at r = 5, 8 rows: the terms and column sums of two rows per v_pk_* instruction (67 instead of
+// 116 for the scalar form), 80 DPP adds, 24 compare / selects: ~171 instructions, C3 0.225 ms measured vs
+// 0.173 ms at one VALU instruction per cycle and CU (54 of a wave's 64 lanes produce outputs).  Whether the
+// window has 2r + 1 or 2r columns is a template argument of the search loop: as a run-time flag it was a
+// branch per row, and the rows' DPP chains then ran one after the other behind s_nop wait states.
 //
 // NCC adds fl(acc / fl(sqrt(AT * E))) per (row, disparity): 28 instructions through the compiler's sqrtf and
 // division, 14 through the short exact sequences of ncc_arith.hpp, which a wave takes (per chunk of disparities)
@@ -30,6 +34,8 @@
 namespace micv {
 
 enum { ST_SSD = 0, ST_SSD_SERIAL = 1, ST_NCC = 2 };
+
+typedef float st_v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float dpp_shr1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, false));
@@ -203,6 +209,50 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
         for (int d = d0; d <= d1; d++) {
             const float *rcol = Rs + lane + (d - d0);
             const bool d_ok = MODE != ST_SSD_SERIAL || (d >= d_lo && d <= d_hi);
+            if constexpr (MODE != ST_SSD_SERIAL) {
+                // Two output rows (j, j + 1), j even, per v_pk_add_f32: their column sums add the terms of rows
+                // j + k and j + 1 + k at step k, i.e. the pair X[m] = (term[m], term[m + 1]), m = j + k.  Even m is
+                // the pair the packed subtract / multiply produced (E), odd m one v_pk_mov_b32 away (O).  Each
+                // half is the same top -> bottom chain as before; the horizontal chains stay scalar (DPP).
+                static_assert(STEPS % 2 == 0 && RPW % 2 == 0, "rows in pairs");
+                st_v2f E[STEPS / 2], O[STEPS / 2];
+#pragma unroll
+                for (int t = 0; t < STEPS / 2; t++) {
+                    const st_v2f rv = (st_v2f){rcol[(2 * t) * ST_SPAN], rcol[(2 * t + 1) * ST_SPAN]};
+                    const st_v2f lv = (st_v2f){Lv[2 * t], Lv[2 * t + 1]};
+                    if (MODE == ST_NCC) {
+                        E[t] = lv * rv;
+                    } else {
+                        const st_v2f diff = lv - rv;
+                        E[t] = diff * diff;
+                    }
+                    if (t > 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O[t - 1]) : "v"(E[t - 1]), "v"(E[t]));
+                    if (2 * t >= 2 * R) {
+                        const int j = 2 * t - 2 * R;
+                        st_v2f cs2 = E[j / 2];  // (no 0 + x: see the scalar loop below)
+#pragma unroll
+                        for (int k = 1; k < W; k++) cs2 += ((j + k) & 1) ? O[(j + k) / 2] : E[(j + k) / 2];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const float acc = systolic_sum<W>(cs2[h], FULLW);
+                            if (MODE == ST_NCC) {
+                                const float accb = Es[(j + h) * ST_SPAN + lane + (d - d0)];  // window energy of `right`
+                                const float pr = AT[j + h] * accb;
+                                // DisparityNCorr.cu:106
+                                const float nc = SHORT ? ncc_div(acc, ncc_sqrt(pr)) : acc / sqrtf(pr);
+                                if (nc > (float)best[j + h]) {  // :108
+                                    best[j + h] = (acc_t)nc;
+                                    bestd[j + h] = d;
+                                }
+                            } else if (acc < (float)best[j + h]) {  // DisparitySSD.cu:88
+                                best[j + h] = (acc_t)acc;
+                                bestd[j + h] = d;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
             acc_t ring[W];
 #pragma unroll
             for (int s = 0; s < STEPS; s++) {
@@ -223,7 +273,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
                     acc_t cs = ring[(s - 2 * R) % W];
 #pragma unroll
                     for (int k = 1; k < W; k++) cs += ring[(s - 2 * R + k) % W];
-                    const acc_t acc = systolic_sum<W>(cs, MODE == ST_NCC ? FULLW : full);
+                    const acc_t acc = systolic_sum<W>(cs, FULLW);
                     if (MODE == ST_NCC) {
                         const float accb = Es[j * ST_SPAN + lane + (d - d0)];  // window energy of `right`
                         const float pr = AT[j] * accb;
@@ -254,7 +304,7 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
             else
                 search_w(std::false_type{});
         } else {
-            search(std::false_type{}, std::true_type{});  // (SSD keeps `full` as a select: 57 VGPRs, 8 waves / SIMD)
+            search_w(std::false_type{});
         }
     }
     if (lane_ok) {
