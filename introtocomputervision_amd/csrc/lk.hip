@@ -67,6 +67,391 @@ __global__ __launch_bounds__(256) void lk_solve_kernel(const float *__restrict__
     v[(size_t)y * ostride + x] = vv;
 }
 
+// ---- generic level in two launches (any odd window 5 .. 63; config/ps5.yaml runs 43) ----------------------
+// The four-launch form above moves the five product fields through HBM three times (write, row pass, column
+// pass) and reads them a fourth time to solve.  Here the row pass starts from the images and the column pass
+// ends in the solve: one intermediate (the five row-filtered fields), 57 + 57 MB instead of 58 + 83 + 83 + 58
+// at 1080p.  Every value is produced by the same expressions in the same order (sobel3 / avg2 / the products
+// of lk_products_kernel, the fmaf chains of filter_rows / filter_cols from +0, lk_solve): identical bits.
+//
+// Pass A: 256 x 8 outputs per workgroup.  Ix, Iy, It of the tile's cells (+ n/2 columns either side, columns
+// BORDER_REFLECT_101 as the row filter would address the product fields) go to LDS, a thread producing the 8
+// cells of one column from a 10 x 3 neighbourhood of each image held in registers (7.5 loads per cell instead
+// of 18).  The row pass is filter_rows_lds_kernel's: four adjacent outputs per thread, taps four at a time, one
+// ds_read_b128 per plane and chunk; the five products of the four new cells are formed from them in registers.
+__global__ __launch_bounds__(256) void lk_products_rows_kernel(const float *__restrict__ prev, int pstride,
+                                                                const float *__restrict__ next, int nstride, int rows,
+                                                                int cols, float *__restrict__ T, size_t field, Taps t) {
+    constexpr int TW = 256, TR = 8;
+    extern __shared__ float lkg_lds[];
+    const int a = t.n / 2, rw = TW + t.n - 1, pw = ((rw + 3) & ~3) + 4;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    float *LX = lkg_lds, *LY = LX + TR * pw, *LT = LY + TR * pw;
+    const float s1 = 1.f / 9.f, s2 = 2.f * s1;  // OpticalFlow.cpp:19
+    int ry[TR + 2];
+#pragma unroll
+    for (int j = 0; j < TR + 2; j++) ry[j] = reflect101(y0 - 1 + j, rows);
+#pragma unroll 1
+    for (int c = threadIdx.x; c < rw; c += 256) {
+        const int xx = reflect101(x0 - a + c, cols);
+        const int rx0 = reflect101(xx - 1, cols), rx2 = reflect101(xx + 1, cols);
+        float P[TR + 2][3], N[TR + 2][3];
+#pragma unroll
+        for (int j = 0; j < TR + 2; j++) {
+            const float *pr = prev + (size_t)ry[j] * pstride, *nr = next + (size_t)ry[j] * nstride;
+            P[j][0] = pr[rx0]; P[j][1] = pr[xx]; P[j][2] = pr[rx2];
+            N[j][0] = nr[rx0]; N[j][1] = nr[xx]; N[j][2] = nr[rx2];
+        }
+#pragma unroll
+        for (int k = 0; k < TR; k++) {
+            float pgx, pgy, ngx, ngy;
+            sobel3(&P[k], s1, s2, pgx, pgy);
+            sobel3(&N[k], s1, s2, ngx, ngy);
+            LX[k * pw + c] = avg2(ngx, pgx);
+            LY[k * pw + c] = avg2(ngy, pgy);
+            LT[k * pw + c] = N[k + 1][1] - P[k + 1][1];
+        }
+    }
+    __syncthreads();
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int q = threadIdx.x & 63;
+#pragma unroll 1
+    for (int r = threadIdx.x >> 6; r < TR; r += 4) {
+        const f4 *px = reinterpret_cast<const f4 *>(LX + r * pw) + q;
+        const f4 *py = reinterpret_cast<const f4 *>(LY + r * pw) + q;
+        const f4 *pt = reinterpret_cast<const f4 *>(LT + r * pw) + q;
+        float acc[5][4];
+#pragma unroll
+        for (int f = 0; f < 5; f++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[f][j] = 0.f;
+        // w[f][0..3]: products of the four cells the chunk starts at, w[f][4..7]: of the next four
+        float w[5][8];
+        auto products = [&](const f4 ix, const f4 iy, const f4 it, int o) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                w[0][o + e] = ix[e] * ix[e];
+                w[1][o + e] = ix[e] * iy[e];
+                w[2][o + e] = iy[e] * iy[e];
+                w[3][o + e] = ix[e] * it[e];
+                w[4][o + e] = iy[e] * it[e];
+            }
+        };
+        products(px[0], py[0], pt[0], 0);
+        int c = 0;
+        for (; c + 4 <= t.n; c += 4) {
+            const int i = (c >> 2) + 1;
+            products(px[i], py[i], pt[i], 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const float tap = t.k[c + kk];
+#pragma unroll
+                for (int f = 0; f < 5; f++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[f][j] = fmaf(w[f][kk + j], tap, acc[f][j]);
+            }
+#pragma unroll
+            for (int f = 0; f < 5; f++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[f][e] = w[f][4 + e];
+        }
+        if (c < t.n) {  // 1-3 left-over taps
+            const int i = (c >> 2) + 1;
+            products(px[i], py[i], pt[i], 4);
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                if (c + kk < t.n) {
+                    const float tap = t.k[c + kk];
+#pragma unroll
+                    for (int f = 0; f < 5; f++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[f][j] = fmaf(w[f][kk + j], tap, acc[f][j]);
+                }
+            }
+        }
+        if (y0 + r < rows) {
+            const int x = x0 + 4 * q;
+#pragma unroll
+            for (int f = 0; f < 5; f++) {
+                float *o = T + f * field + (size_t)(y0 + r) * cols + x;
+                if (x + 3 < cols && (cols & 3) == 0) {
+                    *reinterpret_cast<f4 *>(o) = (f4){acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (x + j < cols) o[j] = acc[f][j];
+                }
+            }
+        }
+    }
+}
+
+// Pass B: 64 x 32 outputs per workgroup, eight vertically adjacent outputs per thread (filter_cols_lds_kernel's
+// job), the five fields one after the other through one LDS buffer -- the next field's rows are in flight while
+// a field is summed -- then lk_solve (+ base flow) on the 40 sums in registers: u, v are the only stores.
+__global__ __launch_bounds__(256) void lk_cols_solve_kernel(const float *__restrict__ T, size_t field, int rows, int cols,
+                                                             Taps t, const float *__restrict__ base_u,
+                                                             const float *__restrict__ base_v, int bstride,
+                                                             float *__restrict__ u, float *__restrict__ v, int ostride) {
+    constexpr int TW = 64, TH = 32, RP = TH / 4, NB = (32 + 62 + 3) / 4;  // n <= 63
+    extern __shared__ float lkg_lds[];
+    const int a = t.n / 2, ph = TH + t.n - 1;  // staged rows
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int c = threadIdx.x & 63, x = x0 + c < cols ? x0 + c : cols - 1;
+    int roff[NB];  // (a field is below 2^31 elements: the callers' size checks)
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int r = 4 * k + (threadIdx.x >> 6);
+        roff[k] = reflect101(y0 - a + (r < ph ? r : ph - 1), rows) * cols + x;
+    }
+    float st[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) st[k] = T[roff[k]];
+    const int rb = (threadIdx.x >> 6) * RP;
+    const float *lp = lkg_lds + rb * TW + c;
+    float acc[5][RP];
+#pragma unroll
+    for (int f = 0; f < 5; f++) {
+        if (f > 0) __syncthreads();  // field f - 1 has been summed by every wave
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int r = 4 * k + (threadIdx.x >> 6);
+            if (r < ph) lkg_lds[r * TW + c] = st[k];
+        }
+        __syncthreads();
+        if (f < 4) {
+#pragma unroll
+            for (int k = 0; k < NB; k++) st[k] = T[(f + 1) * field + roff[k]];
+        }
+#pragma unroll
+        for (int j = 0; j < RP; j++) acc[f][j] = 0.f;
+        float w[12];
+#pragma unroll
+        for (int i = 0; i < 7; i++) w[i] = lp[i * TW];
+        int k0 = 0;
+        for (; k0 + 4 <= t.n; k0 += 4) {
+#pragma unroll
+            for (int i = 7; i < 11; i++) w[i] = lp[(k0 + i) * TW];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const float tap = t.k[k0 + kk];
+#pragma unroll
+                for (int j = 0; j < RP; j++) acc[f][j] = fmaf(w[kk + j], tap, acc[f][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 7; i++) w[i] = w[i + 4];
+        }
+        if (k0 < t.n) {  // 1-3 left-over taps: rows up to k0 + 2 + 7
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                if (k0 + kk < t.n) {
+                    w[7 + kk] = lp[(k0 + 7 + kk) * TW];
+                    const float tap = t.k[k0 + kk];
+#pragma unroll
+                    for (int j = 0; j < RP; j++) acc[f][j] = fmaf(w[kk + j], tap, acc[f][j]);
+                }
+            }
+        }
+    }
+    if (x0 + c >= cols) return;
+#pragma unroll
+    for (int j = 0; j < RP; j++) {
+        const int y = y0 + rb + j;
+        if (y < rows) {
+            float uu, vv;
+            lk_solve(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], uu, vv);
+            if (base_u) {
+                uu = base_u[(size_t)y * bstride + x] + uu;
+                vv = base_v[(size_t)y * bstride + x] + vv;
+            }
+            u[(size_t)y * ostride + x] = uu;
+            v[(size_t)y * ostride + x] = vv;
+        }
+    }
+}
+
+// The same two passes with the tap count a template argument (instantiated for config/ps5.yaml's 43): fully
+// unrolled, taps in SGPRs, and two outputs per v_pk_fma_f32.  Outputs (j, j + 1) share every tap and read the
+// window values (k + j, k + j + 1) at tap k: the pair of values starting at an EVEN index is what a packed
+// multiply (pass A) or a two-row ds_read2st64_b32 (pass B) delivers, the pair starting at an ODD index is one
+// v_pk_mov_b32 (A) or one more two-row read (B) away.  Each half is still its output's own fmaf chain from +0.
+typedef float lk_v2f __attribute__((ext_vector_type(2)));
+
+template <int N>
+__global__ __launch_bounds__(256) void lk_products_rows_pk_kernel(const float *__restrict__ prev, int pstride,
+                                                                   const float *__restrict__ next, int nstride, int rows,
+                                                                   int cols, float *__restrict__ T, size_t field, Taps t) {
+    constexpr int TW = 256, TR = 8, A = N / 2, RW = TW + N - 1, PW = ((RW + 3) & ~3) + 4;
+    constexpr int NV4 = (N + 3 + 3) / 4;  // float4 of a thread's window: values 0 .. N + 2
+    static_assert(4 * 63 + 4 * NV4 <= PW, "window reads stay inside a staged row");
+    extern __shared__ float lkg_lds[];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    float *LX = lkg_lds, *LY = LX + TR * PW, *LT = LY + TR * PW;
+    const float s1 = 1.f / 9.f, s2 = 2.f * s1;  // OpticalFlow.cpp:19
+    int ry[TR + 2];
+#pragma unroll
+    for (int j = 0; j < TR + 2; j++) ry[j] = reflect101(y0 - 1 + j, rows);
+#pragma unroll 1
+    for (int c = threadIdx.x; c < RW; c += 256) {
+        const int xx = reflect101(x0 - A + c, cols);
+        const int rx0 = reflect101(xx - 1, cols), rx2 = reflect101(xx + 1, cols);
+        float P[TR + 2][3], Nx[TR + 2][3];
+#pragma unroll
+        for (int j = 0; j < TR + 2; j++) {
+            const float *pr = prev + (size_t)ry[j] * pstride, *nr = next + (size_t)ry[j] * nstride;
+            P[j][0] = pr[rx0]; P[j][1] = pr[xx]; P[j][2] = pr[rx2];
+            Nx[j][0] = nr[rx0]; Nx[j][1] = nr[xx]; Nx[j][2] = nr[rx2];
+        }
+#pragma unroll
+        for (int k = 0; k < TR; k++) {
+            float pgx, pgy, ngx, ngy;
+            sobel3(&P[k], s1, s2, pgx, pgy);
+            sobel3(&Nx[k], s1, s2, ngx, ngy);
+            LX[k * PW + c] = avg2(ngx, pgx);
+            LY[k * PW + c] = avg2(ngy, pgy);
+            LT[k * PW + c] = Nx[k + 1][1] - P[k + 1][1];
+        }
+    }
+    __syncthreads();
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int q = threadIdx.x & 63;
+#pragma unroll 1
+    for (int r = threadIdx.x >> 6; r < TR; r += 4) {
+        const f4 *px = reinterpret_cast<const f4 *>(LX + r * PW) + q;
+        const f4 *py = reinterpret_cast<const f4 *>(LY + r * PW) + q;
+        const f4 *pt = reinterpret_cast<const f4 *>(LT + r * PW) + q;
+        lk_v2f acc[5][2];
+#pragma unroll
+        for (int f = 0; f < 5; f++) acc[f][0] = acc[f][1] = (lk_v2f){0.f, 0.f};
+        // E[f][m] = products of window values (2m, 2m + 1), O[f][m] = of (2m + 1, 2m + 2)
+        lk_v2f E[5][2 * NV4], O[5][2 * NV4];
+#pragma unroll
+        for (int i = 0; i < NV4; i++) {
+            const f4 ix = px[i], iy = py[i], it = pt[i];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const lk_v2f x2 = h ? (lk_v2f){ix.z, ix.w} : (lk_v2f){ix.x, ix.y};
+                const lk_v2f y2 = h ? (lk_v2f){iy.z, iy.w} : (lk_v2f){iy.x, iy.y};
+                const lk_v2f t2 = h ? (lk_v2f){it.z, it.w} : (lk_v2f){it.x, it.y};
+                E[0][2 * i + h] = x2 * x2;
+                E[1][2 * i + h] = x2 * y2;
+                E[2][2 * i + h] = y2 * y2;
+                E[3][2 * i + h] = x2 * t2;
+                E[4][2 * i + h] = y2 * t2;
+            }
+#pragma unroll
+            for (int f = 0; f < 5; f++) {
+                if (i > 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O[f][2 * i - 1]) : "v"(E[f][2 * i - 1]), "v"(E[f][2 * i]));
+                asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(O[f][2 * i]) : "v"(E[f][2 * i]), "v"(E[f][2 * i + 1]));
+            }
+            // the taps whose last window value (k + 3) arrived with this float4
+#pragma unroll
+            for (int k = 4 * i - 3; k <= 4 * i; k++) {
+                if (k >= 0 && k < N) {
+                    const float tap = t.k[k];
+                    const lk_v2f tap2 = (lk_v2f){tap, tap};
+#pragma unroll
+                    for (int f = 0; f < 5; f++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int cell = k + 2 * h;
+                            const lk_v2f d = (cell & 1) ? O[f][cell >> 1] : E[f][cell >> 1];
+                            acc[f][h] = __builtin_elementwise_fma(d, tap2, acc[f][h]);
+                        }
+                }
+            }
+            // pin the accumulators: this float4's FMAs finish before the next one's reads are issued (the compiler
+            // otherwise hoists every read of the unrolled window and runs out of registers)
+            asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]),
+                              "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[4][0]), "+v"(acc[4][1])
+                         :: "memory");
+        }
+        if (y0 + r < rows) {
+            const int x = x0 + 4 * q;
+#pragma unroll
+            for (int f = 0; f < 5; f++) {
+                float *o = T + f * field + (size_t)(y0 + r) * cols + x;
+                const float out[4] = {acc[f][0].x, acc[f][0].y, acc[f][1].x, acc[f][1].y};
+                if (x + 3 < cols && (cols & 3) == 0) {
+                    *reinterpret_cast<f4 *>(o) = (f4){out[0], out[1], out[2], out[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (x + j < cols) o[j] = out[j];
+                }
+            }
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void lk_cols_solve_pk_kernel(const float *__restrict__ T, size_t field, int rows, int cols,
+                                                                Taps t, const float *__restrict__ base_u,
+                                                                const float *__restrict__ base_v, int bstride,
+                                                                float *__restrict__ u, float *__restrict__ v, int ostride) {
+    constexpr int TW = 64, TH = 32, RP = TH / 4, A = N / 2, PH = TH + N - 1, NB = (PH + 3) / 4;
+    extern __shared__ float lkg_lds[];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int c = threadIdx.x & 63, x = x0 + c < cols ? x0 + c : cols - 1;
+    int roff[NB];  // (a field is below 2^31 elements: the callers' size checks)
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int r = 4 * k + (threadIdx.x >> 6);
+        roff[k] = reflect101(y0 - A + (r < PH ? r : PH - 1), rows) * cols + x;
+    }
+    float st[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) st[k] = T[roff[k]];
+    const int rb = (threadIdx.x >> 6) * RP;
+    const float *lp = lkg_lds + rb * TW + c;
+    lk_v2f acc[5][RP / 2];
+#pragma unroll
+    for (int f = 0; f < 5; f++) {
+        if (f > 0) __syncthreads();  // field f - 1 has been summed by every wave
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int r = 4 * k + (threadIdx.x >> 6);
+            if (r < PH) lkg_lds[r * TW + c] = st[k];
+        }
+        __syncthreads();
+        if (f < 4) {
+#pragma unroll
+            for (int k = 0; k < NB; k++) st[k] = T[(f + 1) * field + roff[k]];
+        }
+#pragma unroll
+        for (int j = 0; j < RP / 2; j++) acc[f][j] = (lk_v2f){0.f, 0.f};
+        // tap k, outputs (2h, 2h + 1): window rows (k + 2h, k + 2h + 1) -- one two-row LDS read per pair start
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const float tap = t.k[k];
+            const lk_v2f tap2 = (lk_v2f){tap, tap};
+#pragma unroll
+            for (int h = 0; h < RP / 2; h++) {
+                const lk_v2f d = (lk_v2f){lp[(k + 2 * h) * TW], lp[(k + 2 * h + 1) * TW]};
+                acc[f][h] = __builtin_elementwise_fma(d, tap2, acc[f][h]);
+            }
+            if ((k & 3) == 3)  // (as in pass A: keeps the unrolled window's reads from all being hoisted)
+                asm volatile("" : "+v"(acc[f][0]), "+v"(acc[f][1]), "+v"(acc[f][2]), "+v"(acc[f][3]) :: "memory");
+        }
+    }
+    if (x0 + c >= cols) return;
+#pragma unroll
+    for (int j = 0; j < RP; j++) {
+        const int y = y0 + rb + j;
+        if (y < rows) {
+            float uu, vv;
+            lk_solve(acc[0][j >> 1][j & 1], acc[1][j >> 1][j & 1], acc[2][j >> 1][j & 1], acc[3][j >> 1][j & 1],
+                     acc[4][j >> 1][j & 1], uu, vv);
+            if (base_u) {
+                uu = base_u[(size_t)y * bstride + x] + uu;
+                vv = base_v[(size_t)y * bstride + x] + vv;
+            }
+            u[(size_t)y * ostride + x] = uu;
+            v[(size_t)y * ostride + x] = vv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void lk_warp_kernel(const float *__restrict__ src, int sstride,
                                                        const float *__restrict__ du,
                                                        const float *__restrict__ dv, int fstride,
@@ -115,6 +500,27 @@ static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const
     float *S = scratch, *T = scratch + 5 * n;
     Taps g;
     gaussian_taps(win, (double)((float)win / 3.f), &g);  // OpticalFlow.cpp:73
+    if (g.n == 43) {  // config/ps5.yaml:11
+        constexpr int N = 43;
+        const size_t lds_a = (size_t)3 * 8 * ((((256 + N - 1) + 3) & ~3) + 4) * sizeof(float);
+        lk_products_rows_pk_kernel<N><<<dim3(cdiv(cols, 256), cdiv(rows, 8)), 256, lds_a, s>>>(prev, pstride, next, nstride,
+                                                                                               rows, cols, T, n, g);
+        MICV_LAUNCH_CHECK();
+        lk_cols_solve_pk_kernel<N><<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 256, (size_t)64 * (32 + N - 1) * sizeof(float), s>>>(
+            T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
+    if (g.n >= 5) {  // two launches: images -> row sums -> flow
+        const size_t lds_a = (size_t)3 * 8 * ((((256 + g.n - 1) + 3) & ~3) + 4) * sizeof(float);
+        lk_products_rows_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 8)), 256, lds_a, s>>>(prev, pstride, next, nstride, rows,
+                                                                                         cols, T, n, g);
+        MICV_LAUNCH_CHECK();
+        lk_cols_solve_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 256, (size_t)64 * (32 + g.n - 1) * sizeof(float), s>>>(
+            T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     const dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
     lk_products_kernel<<<grid, 256, 0, s>>>(prev, pstride, next, nstride, rows, cols, S, n);
     MICV_LAUNCH_CHECK();
