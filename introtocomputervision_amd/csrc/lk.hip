@@ -384,71 +384,132 @@ __global__ __launch_bounds__(256) void lk_products_rows_pk_kernel(const float *_
     }
 }
 
+// Pass B, packed: a thread owns two adjacent columns x 8 rows (64 x 32 outputs per wave-row of the 128 x 32
+// tile), so a pair is simply the 8 staged bytes of its two columns -- one ds_read_b64 per window row, no pair
+// assembly -- and every window row is read once into a register window that slides with the taps.  Tiles that
+// lie inside the image (16-byte aligned rows) stage by LDS-DMA, field f + 1 into the second buffer while field f
+// is summed: no staging registers, no ds_write.  Edge tiles load element by element, columns clamped.
 template <int N>
 __global__ __launch_bounds__(256) void lk_cols_solve_pk_kernel(const float *__restrict__ T, size_t field, int rows, int cols,
                                                                 Taps t, const float *__restrict__ base_u,
                                                                 const float *__restrict__ base_v, int bstride,
                                                                 float *__restrict__ u, float *__restrict__ v, int ostride) {
-    constexpr int TW = 64, TH = 32, RP = TH / 4, A = N / 2, PH = TH + N - 1, NB = (PH + 3) / 4;
+    constexpr int TW = 128, TH = 32, RP = 8, A = N / 2, PH = TH + N - 1, V4 = TW / 4, NB = (PH * V4 + 255) / 256;
+    static_assert((PH * V4) % 64 == 0, "whole waves of staging slots");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_cvoid;
     extern __shared__ float lkg_lds[];
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int c = threadIdx.x & 63, x = x0 + c < cols ? x0 + c : cols - 1;
-    int roff[NB];  // (a field is below 2^31 elements: the callers' size checks)
+    const int lane = threadIdx.x & 63, rb = (threadIdx.x >> 6) * RP;
+    const bool dma = (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(T) & 15) == 0 && x0 + TW <= cols;  // uniform
+    // staging slot i = float4 (i % V4) of staged row i / V4; its first element's offset inside a field (a field is
+    // below 2^31 elements: the callers' size checks)
+    int roff[NB];
 #pragma unroll
     for (int k = 0; k < NB; k++) {
-        const int r = 4 * k + (threadIdx.x >> 6);
-        roff[k] = reflect101(y0 - A + (r < PH ? r : PH - 1), rows) * cols + x;
+        const int i = threadIdx.x + 256 * k < PH * V4 ? threadIdx.x + 256 * k : PH * V4 - 1;
+        const int ly = i / V4, m = i - ly * V4;
+        roff[k] = reflect101(y0 - A + ly, rows) * cols + x0 + 4 * m;
     }
-    float st[NB];
+    const int slot0 = __builtin_amdgcn_readfirstlane(threadIdx.x - lane);
+    auto stage = [&](const float *F, float *buf) {
+        if (dma) {
 #pragma unroll
-    for (int k = 0; k < NB; k++) st[k] = T[roff[k]];
-    const int rb = (threadIdx.x >> 6) * RP;
-    const float *lp = lkg_lds + rb * TW + c;
-    lk_v2f acc[5][RP / 2];
+            for (int k = 0; k < NB; k++)
+                if (slot0 + 256 * k < PH * V4)
+                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(F + roff[k]), (lds_void *)(buf + 4 * (slot0 + 256 * k)), 16, 0, 0);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < NB; k++) {
+                const int i = threadIdx.x + 256 * k;
+                if (i < PH * V4) {
+                    const int xb = x0 + 4 * (i % V4), rowo = roff[k] - xb;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) buf[4 * i + e] = F[rowo + (xb + e < cols ? xb + e : cols - 1)];
+                }
+            }
+        }
+    };
+    stage(T, lkg_lds);
+    lk_v2f acc[5][RP];
 #pragma unroll
     for (int f = 0; f < 5; f++) {
-        if (f > 0) __syncthreads();  // field f - 1 has been summed by every wave
+        float *cur = lkg_lds + (f & 1) * (PH * TW), *nxt = lkg_lds + ((f + 1) & 1) * (PH * TW);
+        __syncthreads();  // field f is staged (and field f - 1, in the other buffer, has been summed by every wave)
+        if (f < 4) stage(T + (f + 1) * field, nxt);
+        const float *lp = cur + rb * TW + 2 * lane;
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const int r = 4 * k + (threadIdx.x >> 6);
-            if (r < PH) lkg_lds[r * TW + c] = st[k];
-        }
-        __syncthreads();
-        if (f < 4) {
+        for (int j = 0; j < RP; j++) acc[f][j] = (lk_v2f){0.f, 0.f};
+        lk_v2f W[N + RP - 1];
 #pragma unroll
-            for (int k = 0; k < NB; k++) st[k] = T[(f + 1) * field + roff[k]];
-        }
-#pragma unroll
-        for (int j = 0; j < RP / 2; j++) acc[f][j] = (lk_v2f){0.f, 0.f};
-        // tap k, outputs (2h, 2h + 1): window rows (k + 2h, k + 2h + 1) -- one two-row LDS read per pair start
+        for (int sidx = 0; sidx < RP - 1; sidx++) W[sidx] = *reinterpret_cast<const lk_v2f *>(lp + sidx * TW);
 #pragma unroll
         for (int k = 0; k < N; k++) {
+            W[k + RP - 1] = *reinterpret_cast<const lk_v2f *>(lp + (k + RP - 1) * TW);
             const float tap = t.k[k];
             const lk_v2f tap2 = (lk_v2f){tap, tap};
 #pragma unroll
-            for (int h = 0; h < RP / 2; h++) {
-                const lk_v2f d = (lk_v2f){lp[(k + 2 * h) * TW], lp[(k + 2 * h + 1) * TW]};
-                acc[f][h] = __builtin_elementwise_fma(d, tap2, acc[f][h]);
-            }
+            for (int j = 0; j < RP; j++) acc[f][j] = __builtin_elementwise_fma(W[k + j], tap2, acc[f][j]);
             if ((k & 3) == 3)  // (as in pass A: keeps the unrolled window's reads from all being hoisted)
-                asm volatile("" : "+v"(acc[f][0]), "+v"(acc[f][1]), "+v"(acc[f][2]), "+v"(acc[f][3]) :: "memory");
+                asm volatile("" : "+v"(acc[f][0]), "+v"(acc[f][1]), "+v"(acc[f][2]), "+v"(acc[f][3]), "+v"(acc[f][4]),
+                                  "+v"(acc[f][5]), "+v"(acc[f][6]), "+v"(acc[f][7])
+                             :: "memory");
         }
     }
-    if (x0 + c >= cols) return;
+    // every sum in its register before any solve starts (the scheduler otherwise interleaves the double-precision
+    // solves with the last field's chains)
+#pragma unroll
+    for (int f = 0; f < 5; f++)
+        asm volatile("" : "+v"(acc[f][0]), "+v"(acc[f][1]), "+v"(acc[f][2]), "+v"(acc[f][3]), "+v"(acc[f][4]), "+v"(acc[f][5]),
+                          "+v"(acc[f][6]), "+v"(acc[f][7])
+                     :: "memory");
+    const int x = x0 + 2 * lane;
+    if (x >= cols) return;
+    const bool pair_ok = x + 1 < cols && (ostride & 1) == 0 && (bstride & 1) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(base_u) |
+                           reinterpret_cast<uintptr_t>(base_v)) & 7) == 0;
 #pragma unroll
     for (int j = 0; j < RP; j++) {
-        const int y = y0 + rb + j;
+        // (opaque, and behind the previous row's fence: the addresses and base-flow loads of all eight rows would
+        // otherwise be formed ahead of the last field's sums -- 100+ registers)
+        int y = y0 + rb + j;
+        asm volatile("" : "+v"(y));
         if (y < rows) {
-            float uu, vv;
-            lk_solve(acc[0][j >> 1][j & 1], acc[1][j >> 1][j & 1], acc[2][j >> 1][j & 1], acc[3][j >> 1][j & 1],
-                     acc[4][j >> 1][j & 1], uu, vv);
-            if (base_u) {
-                uu = base_u[(size_t)y * bstride + x] + uu;
-                vv = base_v[(size_t)y * bstride + x] + vv;
+            lk_v2f uu, vv;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                float a_, b_;
+                lk_solve(acc[0][j][e], acc[1][j][e], acc[2][j][e], acc[3][j][e], acc[4][j][e], a_, b_);
+                uu[e] = a_;
+                vv[e] = b_;
             }
-            u[(size_t)y * ostride + x] = uu;
-            v[(size_t)y * ostride + x] = vv;
+            if (pair_ok) {
+                if (base_u) {
+                    uu = *reinterpret_cast<const lk_v2f *>(base_u + (size_t)y * bstride + x) + uu;
+                    vv = *reinterpret_cast<const lk_v2f *>(base_v + (size_t)y * bstride + x) + vv;
+                }
+                *reinterpret_cast<lk_v2f *>(u + (size_t)y * ostride + x) = uu;
+                *reinterpret_cast<lk_v2f *>(v + (size_t)y * ostride + x) = vv;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (x + e < cols) {
+                        float a_ = uu[e], b_ = vv[e];
+                        if (base_u) {
+                            a_ = base_u[(size_t)y * bstride + x + e] + a_;
+                            b_ = base_v[(size_t)y * bstride + x + e] + b_;
+                        }
+                        u[(size_t)y * ostride + x + e] = a_;
+                        v[(size_t)y * ostride + x + e] = b_;
+                    }
+                }
+            }
         }
+        // one row's solves at a time (unfenced, the 16 double-precision solves interleave and need 200+ registers)
+        if (j + 1 < RP)
+            asm volatile("" : "+v"(acc[0][j + 1]), "+v"(acc[1][j + 1]), "+v"(acc[2][j + 1]), "+v"(acc[3][j + 1]), "+v"(acc[4][j + 1])
+                         :: "memory");
     }
 }
 
@@ -506,7 +567,15 @@ static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const
         lk_products_rows_pk_kernel<N><<<dim3(cdiv(cols, 256), cdiv(rows, 8)), 256, lds_a, s>>>(prev, pstride, next, nstride,
                                                                                                rows, cols, T, n, g);
         MICV_LAUNCH_CHECK();
-        lk_cols_solve_pk_kernel<N><<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 256, (size_t)64 * (32 + N - 1) * sizeof(float), s>>>(
+        static thread_local int attr_dev = -1;
+        int dev = 0;
+        MICV_HIP(hipGetDevice(&dev));
+        if (attr_dev != dev) {  // two staging buffers: 74 KB of dynamic LDS
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_cols_solve_pk_kernel<N>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_dev = dev;
+        }
+        lk_cols_solve_pk_kernel<N><<<dim3(cdiv(cols, 128), cdiv(rows, 32)), 256, (size_t)2 * 128 * (32 + N - 1) * sizeof(float), s>>>(
             T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride);
         MICV_LAUNCH_CHECK();
         return MICV_OK;

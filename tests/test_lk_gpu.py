@@ -103,6 +103,26 @@ def test_lk_single_level(mods, rows, cols, win):
     assert np.array_equal(host(gv), ev)
 
 
+@pytest.mark.parametrize("win", [43, 9, 27])
+@pytest.mark.parametrize("rows,cols,pad", [(150, 520, 0), (131, 388, 4), (75, 516, 3), (33, 256, 0), (40, 131, 0)])
+def test_lk_generic_two_launch_tiles(mods, rows, cols, pad, win):
+    """The two-launch generic level (window 43 packed and unrolled, the others with run-time taps): images wide
+    enough for interior 128-column tiles (staged by LDS-DMA) next to edge tiles, widths that are / are not
+    multiples of 4 and 128, row pitches that differ from the width, rows that are not multiples of 8 / 32."""
+    import torch
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(77 + win + cols, rows, cols, dx=2, dy=-1)
+    eu, ev = orc.lk_flow(prev, nxt, win)
+    dp = torch.zeros((rows, cols + pad), dtype=torch.float32, device="cuda")
+    dn = torch.zeros((rows, cols + pad), dtype=torch.float32, device="cuda")
+    dp[:, :cols] = torch.from_numpy(prev)
+    dn[:, :cols] = torch.from_numpy(nxt)
+    gu, gv = lk.calcOpticalFlow(dp[:, :cols], dn[:, :cols], win)
+    assert host(gu).tobytes() == eu.tobytes()
+    assert host(gv).tobytes() == ev.tobytes()
+
+
 def test_lk_single_level_generic_vs_fused(mods):
     lk, pyr = mods
     from introtocomputervision_amd import synth, _capi

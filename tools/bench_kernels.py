@@ -89,7 +89,7 @@ P, N = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
 ms = timeit(lambda: lk.calcOpticalFlow(P, N, 15, ctx=ctx))
 line("lk::calcOpticalFlow 1080p win 15 (fused)", ms, 1080 * 1920, 16)
 ms = timeit(lambda: lk.calcOpticalFlow(P, N, 43, ctx=ctx), iters=5)
-line("lk::calcOpticalFlow 1080p win 43 (generic path)", ms, 1080 * 1920, 16)
+line("lk::calcOpticalFlow 1080p win 43 (two-launch generic path)", ms, 1080 * 1920, 16)
 ms = timeit(lambda: pyr.makeGaussianPyramid(P, 5, ctx=ctx))
 line("makeGaussianPyramid 1080p 5 levels", ms, 1080 * 1920, 4 + 4 * 0.333 + 4)
 
