@@ -62,7 +62,8 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 #define MICV_OPT_LK_SHORT_TILES    9 /* win-15 level kernel, 64x16 tiles: 0 = up to 512 tiles (one round), n = up to n, -1 = never */
 #define MICV_OPT_LK_STREAM         10 /* level kernel as a persistent grid that stages the next tile ahead: 1 = on, 0 = off (default; measured slower) */
 #define MICV_OPT_LK_TALL_TILES     11 /* 1024-thread tiles, one workgroup per CU, for big launches: window 15 on 64x64 tiles only with 1 (measured slower); window 21 on 64x32 tiles by default (0 or 1; measured faster); -1 = never */
-#define MICV_OPT_COUNT            12
+#define MICV_OPT_COMPACT_3PASS     12 /* ordered lists (corners, edge points, peak candidates, matches): 0 = one-launch chained scan up to 1 M elements, count / scan / emit launches beyond; 1 = always three launches; -1 = always one */
+#define MICV_OPT_COUNT            13
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
 int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value);
 

@@ -33,7 +33,8 @@ OK, EINVAL, EHIP, ENOMEM, EUNSUPPORTED = 0, -1, -2, -3, -4
 STEREO_COLS_2R, STEREO_MIN_SSD_5E6, STEREO_SERIAL, STEREO_ROLLING = 1, 2, 4, 8
 # micv_ctx_set_option (include/mi_cv.h): none of these changes a result
 (OPT_LK_STREAM_GROUPS, OPT_LK_FORCE_GENERIC, OPT_LK_NARROW_TILES, OPT_SOBEL_GENERIC, OPT_HARRIS_GENERIC,
- OPT_NMS_SCAN, OPT_STEREO_ROWS, OPT_LK_CHAIN, OPT_LK_SHORT_TILES, OPT_LK_STREAM, OPT_LK_TALL_TILES) = range(1, 12)
+ OPT_NMS_SCAN, OPT_STEREO_ROWS, OPT_LK_CHAIN, OPT_LK_SHORT_TILES, OPT_LK_STREAM, OPT_LK_TALL_TILES,
+ OPT_COMPACT_3PASS) = range(1, 13)
 
 
 class MicvError(RuntimeError):

@@ -124,6 +124,15 @@ struct micv_ctx {
     hipStream_t lk_ticket_stream[kLkTicketSlots] = {};
     int lk_ticket_used = 0;
     int lk_ticket_slot(hipStream_t stream, unsigned **out);
+    // State of the one-launch ordered compaction (compact.hpp): per stream, all zero between launches
+    struct CompactSlot {
+        hipStream_t stream = nullptr;
+        void *buf = nullptr;  // 16 B of counters, then one status word per chunk
+        int chunks = 0;
+    };
+    CompactSlot compact_slots[kLkTicketSlots];
+    int compact_used = 0;
+    int compact_state(hipStream_t stream, int nchunks, unsigned long long **status, unsigned **counters);
     // Hough trig tables (hough.hip), uploaded once per context: [0] theta = -90.., [1] theta = 0..
     void *trig_tables[2] = {nullptr, nullptr};
     void *io_acquire(size_t bytes);

@@ -3,7 +3,13 @@
 // i in [0, n) for which pred(i) holds -- row-major order for images, which is the order the
 // reference's corner lists and point lists have.
 //
-// Three launches, no host synchronisation:
+// One launch (compact_onepass_kernel), no host synchronisation: a chained scan with decoupled look-back.  Every
+// 4096-element chunk takes a ticket (its position in index order = the order workgroups started, so all its
+// predecessors are running or done), counts its hits, publishes the count, finds its offset by looking back over
+// its predecessors' published counts / running totals (the whole workgroup, 256 chunks per step), publishes its own
+// running total and writes its hits.  pred is evaluated once per element.  The status words live in a per-stream,
+// context-owned buffer that is all zero between launches: the last chunk to finish zeroes it again.
+// Without such a buffer (more than 16 streams on one context) the three-launch form runs instead:
 //   count : every 1024-element chunk counts its hits (wave ballots)          -> chunk_count[]
 //   scan  : one workgroup scans the chunk counts                              -> chunk_off[], total
 //   emit  : every chunk recomputes pred, ranks its hits and writes them at chunk_off + rank
@@ -66,6 +72,119 @@ __global__ __launch_bounds__(256) void compact_emit_kernel(Pred pred, int64_t n,
     }
 }
 
+// What a hit becomes in the output: its linear index (default) ...
+struct IndexEmit {
+    int32_t *out;
+    __device__ void operator()(int64_t pos, int64_t i) const { out[pos] = (int32_t)i; }
+};
+// ... or its (row, column), Harris.cu:314-318 (Conv1Dto2D)
+struct YxEmit {
+    int32_t *locs;
+    int cols;
+    __device__ void operator()(int64_t pos, int64_t i) const {
+        const int y = (int)(i / cols);
+        locs[2 * pos] = y;
+        locs[2 * pos + 1] = (int)(i - (int64_t)y * cols);
+    }
+};
+
+constexpr unsigned long long kCompactAgg = 1ull << 32, kCompactInc = 2ull << 32;  // status = flag | 32-bit count
+constexpr int kChunk1 = 4096;  // elements per workgroup of the one-launch form (256 threads x 16)
+
+// 4096 elements per workgroup and a look-back by the whole workgroup (256 predecessors per step).
+template <typename Pred, typename Emit>
+__global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit emit, int64_t n, int nchunks,
+                                                               unsigned long long *__restrict__ status,
+                                                               unsigned *__restrict__ counters, int64_t cap,
+                                                               int64_t *__restrict__ count) {
+    constexpr int J = kChunk1 / 256;
+    static_assert(J * 4 == 64, "one (j, wave) slot per lane of the scanning wave");
+    __shared__ int wcount[J * 4];  // hits of slot (j, wave), then their exclusive prefix: slot order == index order
+    __shared__ unsigned s_chunk, s_last;
+    __shared__ int s_total, s_first[4];
+    __shared__ long long s_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_chunk = atomicAdd(&counters[0], 1u);
+    __syncthreads();
+    const int chunk = (int)s_chunk;
+    const int64_t base = (int64_t)chunk * kChunk1;
+    unsigned hits = 0;
+    int before[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const bool hit = i < n && pred(i);
+        const unsigned long long m = __ballot(hit);
+        before[j] = __popcll(m & ((1ull << lane) - 1ull));
+        hits |= (unsigned)hit << j;
+        if (lane == 0) wcount[j * 4 + wave] = __popcll(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int c = wcount[lane];
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        wcount[lane] = incl - c;
+        if (lane == 63) {
+            s_total = incl;
+            __hip_atomic_store(&status[chunk], (chunk == 0 ? kCompactInc : kCompactAgg) | (unsigned)incl, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    long long excl = 0;
+    for (int p = chunk - 1; p >= 0; p -= 256) {  // (uniform: every thread sees the same shared flags)
+        const int q = p - (int)threadIdx.x;      // thread t looks at predecessor p - t
+        unsigned long long st = kCompactInc;     // before chunk 0: a running total of 0
+        if (q >= 0) {
+            do {
+                st = __hip_atomic_load(&status[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((st >> 32) == 0);
+        }
+        const unsigned long long inc = __ballot((st & kCompactInc) != 0);
+        if (lane == 0) s_first[wave] = inc ? __ffsll((long long)inc) - 1 : 64;  // nearest running total in this wave
+        __syncthreads();
+        int fw = 4;  // first wave (nearest 64 predecessors first) that saw a running total
+#pragma unroll
+        for (int w = 3; w >= 0; w--)
+            if (s_first[w] < 64) fw = w;
+        long long v = (wave < fw || (wave == fw && lane <= s_first[wave])) ? (long long)(unsigned)st : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0) s_part[wave] = v;
+        __syncthreads();
+        excl += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();  // s_first / s_part are rewritten by the next step
+        if (fw < 4) break;
+    }
+    __syncthreads();  // wcount's prefix and s_total (chunk 0 takes no step above)
+    if (threadIdx.x == 0) {
+        if (chunk > 0)
+            __hip_atomic_store(&status[chunk], kCompactInc | (unsigned long long)(excl + s_total), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (chunk == nchunks - 1) *count = excl + s_total;
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        if (!((hits >> j) & 1)) continue;
+        const int64_t pos = excl + wcount[j * 4 + wave] + before[j];
+        if (pos < cap) emit(pos, base + j * 256 + threadIdx.x);
+    }
+    // the last chunk out leaves the state as it found it: all zero
+    if (threadIdx.x == 0) s_last = atomicAdd(&counters[1], 1u) == (unsigned)(nchunks - 1);
+    __syncthreads();
+    if (s_last) {
+        for (int i = threadIdx.x; i < nchunks; i += 256) status[i] = 0;
+        if (threadIdx.x == 0) {
+            counters[0] = 0;
+            counters[1] = 0;
+        }
+    }
+}
+
 inline size_t compact_scratch_bytes(int64_t n) {
     const int64_t nchunks = (n + kChunk - 1) / kChunk;
     return Carver::need(nchunks, 4) + Carver::need(nchunks, 8);
@@ -96,6 +215,35 @@ int ordered_compact(hipStream_t s, Pred pred, int64_t n, int32_t *out, int64_t c
     compact_emit_kernel<<<nchunks, 256, 0, s>>>(pred, n, chunk_off, out, cap);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
+}
+
+// The one-launch form when the context has a state buffer for this stream (MICV_OPT_COMPACT_3PASS forces the
+// other).  `emit` decides what is written; `idx` (int32[cap], may be null when emit does not need it) is only
+// used by the three-launch fallback, which reports through *used_fallback that the caller has to convert idx.
+template <typename Pred, typename Emit>
+int ordered_compact(micv_ctx *ctx, hipStream_t s, Pred pred, Emit emit, int64_t n, int32_t *idx, int64_t cap,
+                    int64_t *count, void *scratch, bool *used_fallback) {
+    if (n >= (int64_t)1 << 31) {
+        set_error("ordered_compact: %lld elements exceed int32 indices", (long long)n);
+        return MICV_EINVAL;
+    }
+    const int nchunks = (int)((n + kChunk1 - 1) / kChunk1);
+    unsigned long long *status = nullptr;
+    unsigned *counters = nullptr;
+    *used_fallback = false;
+    // Up to 256 chunks (1 M elements) every chunk reaches chunk 0 in ONE look-back step -- it just adds up its
+    // predecessors' counts -- and the launch costs less than three (VGA corner list 36 -> 27 us).  Beyond that the
+    // walk back to the spreading running totals takes several dependent steps for the first round of workgroups and
+    // measured slower than the three launches (4K: 0.146 vs 0.104 ms; 1080p edge points: 46 vs 34 us), unless forced
+    // (MICV_OPT_COMPACT_3PASS = -1, tests).
+    const int opt = ctx->opt[MICV_OPT_COMPACT_3PASS];
+    if (nchunks > 0 && opt <= 0 && (nchunks <= 256 || opt < 0) && ctx->compact_state(s, nchunks, &status, &counters) == MICV_OK) {
+        compact_onepass_kernel<<<nchunks, 256, 0, s>>>(pred, emit, n, nchunks, status, counters, cap, count);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
+    *used_fallback = true;
+    return ordered_compact(s, pred, n, idx, cap, count, scratch);
 }
 
 }  // namespace micv

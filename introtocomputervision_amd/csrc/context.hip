@@ -211,6 +211,8 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     for (auto &b : ctx->io_cache) (void)hipFree(b.p);
     for (auto &e : ctx->lk_sched) (void)hipFree(e.dev);
     if (ctx->lk_tickets) (void)hipFree(ctx->lk_tickets);
+    for (auto &c : ctx->compact_slots)
+        if (c.buf) (void)hipFree(c.buf);
     for (void *t : ctx->trig_tables)
         if (t) (void)hipFree(t);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -229,6 +231,9 @@ int micv_ctx::lk_ticket_slot(hipStream_t stream, unsigned **out) {
         void *p = nullptr;
         MICV_HIP(hipMalloc(&p, kLkTicketSlots * kWords * sizeof(unsigned)));
         hipError_t e = hipMemset(p, 0, kLkTicketSlots * kWords * sizeof(unsigned));
+        // (the fill runs on the null stream, which non-blocking streams do not wait for: finish it before any
+        // slot is handed out)
+        if (e == hipSuccess) e = hipDeviceSynchronize();
         if (e != hipSuccess) {
             (void)hipFree(p);
             MICV_HIP(e);
@@ -244,6 +249,38 @@ int micv_ctx::lk_ticket_slot(hipStream_t stream, unsigned **out) {
         lk_ticket_stream[slot] = stream;
     }
     *out = lk_tickets + (size_t)slot * kWords;
+    return MICV_OK;
+}
+
+// One slot per stream, as for the tickets above: launches on one stream are ordered and each leaves the state
+// zeroed.  Growing a slot frees the old buffer, which waits for the device (hipFree), so no launch still uses it.
+int micv_ctx::compact_state(hipStream_t stream, int nchunks, unsigned long long **status, unsigned **counters) {
+    int slot = -1;
+    for (int i = 0; i < compact_used; i++)
+        if (compact_slots[i].stream == stream) slot = i;
+    if (slot < 0) {
+        if (compact_used >= kLkTicketSlots) return MICV_EUNSUPPORTED;
+        slot = compact_used++;
+        compact_slots[slot].stream = stream;
+    }
+    CompactSlot &c = compact_slots[slot];
+    if (c.chunks < nchunks) {
+        const int want = nchunks < 1024 ? 1024 : nchunks + nchunks / 2;
+        void *p = nullptr;
+        MICV_HIP(hipMalloc(&p, 16 + (size_t)want * 8));
+        // on the caller's stream: hipMemset runs on the null stream, which a non-blocking stream does not wait for --
+        // the launch that follows could start first and have its state wiped under it
+        hipError_t e = hipMemsetAsync(p, 0, 16 + (size_t)want * 8, stream);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            MICV_HIP(e);
+        }
+        if (c.buf) (void)hipFree(c.buf);
+        c.buf = p;
+        c.chunks = want;
+    }
+    *counters = static_cast<unsigned *>(c.buf);
+    *status = reinterpret_cast<unsigned long long *>(static_cast<char *>(c.buf) + 16);
     return MICV_OK;
 }
 
@@ -292,6 +329,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= 0 && value <= 1, "micv_ctx_set_option: streamed launch must be 0 or 1");
     if (option == MICV_OPT_LK_TALL_TILES)
         MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: tall tiles must be -1, 0 or 1");
+    if (option == MICV_OPT_COMPACT_3PASS)
+        MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: compaction form must be -1, 0 or 1");
     ctx->opt[option] = value;
     return MICV_OK;
 }

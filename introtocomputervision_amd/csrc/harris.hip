@@ -444,8 +444,10 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
             resp, (int)(rstride / 4), rows, cols, threshold, min_distance, corners,
             (int)(cstride / 4), flag);
     MICV_LAUNCH_CHECK();
-    MICV_TRY(ordered_compact(s, FlagPred{flag}, n, idx, cap, count, c.base + c.off));
-    if (cap > 0) {
+    // one launch writes the (y, x) list; the three-launch fallback leaves linear indices to convert
+    bool fallback = false;
+    MICV_TRY(ordered_compact(ctx, s, FlagPred{flag}, YxEmit{locs_yx, cols}, n, idx, cap, count, c.base + c.off, &fallback));
+    if (fallback && cap > 0) {
         idx_to_yx_kernel<<<64, 256, 0, s>>>(locs_yx, idx, count, cap, cols);
         MICV_LAUNCH_CHECK();
     }

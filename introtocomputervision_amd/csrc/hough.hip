@@ -357,7 +357,8 @@ static int hough_points(micv_ctx *ctx, hipStream_t s, const uint8_t *mask, int r
     *pts = c.take<int32_t>(n);
     *npts = c.take<int64_t>(1);
     *extra = c.take<char>(extra_bytes);
-    return ordered_compact(s, MaskPred{mask, cols, mstride}, n, *pts, n, *npts, c.base + c.off);
+    bool fallback = false;
+    return ordered_compact(ctx, s, MaskPred{mask, cols, mstride}, IndexEmit{*pts}, n, *pts, n, *npts, c.base + c.off, &fallback);
 }
 
 int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
@@ -449,8 +450,9 @@ int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
     int32_t *cand = c.take<int32_t>(n);
     int64_t *ncand = c.take<int64_t>(1);
     unsigned long long *sel = c.take<unsigned long long>((size_t)num_peaks + 1);
-    MICV_TRY(ordered_compact(s, PeakPred{acc, rows, cols, threshold}, n, cand, n, ncand,
-                             c.base + c.off));
+    bool fallback = false;
+    MICV_TRY(ordered_compact(ctx, s, PeakPred{acc, rows, cols, threshold}, IndexEmit{cand}, n, cand, n, ncand, c.base + c.off,
+                             &fallback));
     if (num_peaks <= 64) {
         peak_select_all_kernel<<<1, 1024, 0, s>>>(acc, cand, ncand, n, num_peaks, cols, peaks_rc, count);
         MICV_LAUNCH_CHECK();

@@ -396,7 +396,6 @@ __global__ __launch_bounds__(256) void lk_cols_solve_pk_kernel(const float *__re
                                                                 float *__restrict__ u, float *__restrict__ v, int ostride) {
     constexpr int TW = 128, TH = 32, RP = 8, A = N / 2, PH = TH + N - 1, V4 = TW / 4, NB = (PH * V4 + 255) / 256;
     static_assert((PH * V4) % 64 == 0, "whole waves of staging slots");
-    typedef float f4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void glb_cvoid;
     extern __shared__ float lkg_lds[];

@@ -161,6 +161,46 @@ def test_harris_refine_random(M, thr, dist):
     assert np.array_equal(host(l3), el[:5])
 
 
+@pytest.mark.parametrize("rows,cols,density", [(2160, 3840, 0.02), (2160, 3840, 0.9), (480, 640, 0.3), (33, 31, 0.5), (1, 5000, 0.5),
+                                               (300, 1100, 0.0), (300, 1100, 1.0)])
+def test_ordered_list_one_launch_vs_three(M, rows, cols, density):
+    """The ordered corner list comes from one launch (chained scan with look-back) and, with
+    MICV_OPT_COMPACT_3PASS, from count / scan / emit: both must give numpy's row-major list -- at sizes where
+    the look-back spans several 64-chunk steps (4K = 8100 chunks), with nearly empty and nearly full chunks,
+    for repeated calls on one context (the state is left zeroed) and from two streams of one context."""
+    import torch
+    from introtocomputervision_amd import _capi
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(rows + cols)
+    # minDistance 0: every pixel >= threshold is kept (Harris.cpp:119-135 with an empty neighbourhood)
+    R = rng.random((rows, cols)).astype(np.float32)
+    thr = 1.0 - density if 0.0 < density < 1.0 else (2.0 if density == 0.0 else -1.0)
+    ys, xs = np.nonzero(R.astype(np.float64) >= thr)
+    exp = np.stack([ys, xs], axis=1).astype(np.int32)
+    dR = dev(R)
+    c1 = _capi.Context(0)
+    c1.set_option(_capi.OPT_COMPACT_3PASS, -1)  # one launch at every size (the default switches at 1 M elements)
+    c3 = _capi.Context(0)
+    c3.set_option(_capi.OPT_COMPACT_3PASS, 1)
+    c0 = _capi.Context(0)
+    for ctx in (c1, c3, c1, c0, c1):
+        _, locs = harris.refineCorners(dR, thr, 0, ctx=ctx)
+        assert np.array_equal(host(locs), exp)
+    _, locs = harris.refineCorners(dR, thr, 0, capacity=7, ctx=c1)
+    assert np.array_equal(host(locs), exp[:7])
+    # a second (non-blocking) stream gets its own state, zeroed on THAT stream before its first launch; a context's
+    # scratch is shared, so calls on different streams are not overlapped (mi_cv.h)
+    s2 = torch.cuda.Stream()
+    for _ in range(2):
+        with torch.cuda.stream(s2):
+            dR2 = dR.clone()
+            _, l2 = harris.refineCorners(dR2, thr, 0, ctx=c1)
+        torch.cuda.synchronize()
+        _, l1 = harris.refineCorners(dR, thr, 0, ctx=c1)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(l1), exp) and np.array_equal(host(l2), exp)
+
+
 def test_reference_check_bmp(M):
     """The only real image in the reference (Resources/ProblemSet4/check.bmp, 160x120 8-bit)."""
     harris, stereo, hough, synth = M
