@@ -52,7 +52,7 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
  * that produce identical bits (tests compare the alternatives) or how a batch is scheduled.
  * The library reads NO environment variables. */
 #define MICV_OPT_LK_STREAM_GROUPS  1 /* stream groups a batch is split into: 0 = default (1), 1..4 */
-#define MICV_OPT_LK_FORCE_GENERIC  2 /* LK through the generic multi-launch kernels */
+#define MICV_OPT_LK_FORCE_GENERIC  2 /* LK through the generic kernels: 1 = two or four launches per level by size (as for windows the fused kernels do not cover), 2 = always four, 3 = always two */
 #define MICV_OPT_LK_NARROW_TILES   3 /* win-15 level kernel: 256-thread tiles instead of 512 */
 #define MICV_OPT_SOBEL_GENERIC     4 /* Sobel through the generic row / column passes */
 #define MICV_OPT_HARRIS_GENERIC    5 /* Harris response: one-thread-per-pixel kernel */

@@ -548,19 +548,32 @@ int launch_warp(hipStream_t s, const float *src, int sstride, const float *du, c
     return MICV_OK;
 }
 
+// Level sizes from which the two-launch forms win (tools/probes/generic_form_bench.py, one level per call, us):
+//   window 43, unrolled:  540 x 960: 38 vs 32 (four launches)   1080 x 1920: 51 vs 79
+//   window 9, run-time taps:  68 x 120: 31 vs 30   135 x 240: 23 vs 35   1080 x 1920: 37 vs 64
+constexpr size_t kTwoLaunchMinPixels = 16 * 1024, kTwoLaunchMinPixelsUnrolled = 1024 * 1024;
 // Scratch floats the generic level needs: 10 planar fields.
 static size_t lk_generic_scratch(int rows, int cols) { return (size_t)rows * cols * 10; }
+
+// MICV_OPT_LK_FORCE_GENERIC: 1 = generic kernels, form by size; 2 = always four launches; 3 = always two
+static int lk_generic_form(const micv_ctx *ctx) {
+    const int o = ctx->opt[MICV_OPT_LK_FORCE_GENERIC];
+    return o == 2 ? 2 : (o == 3 ? 1 : 0);
+}
 
 // lk::calcOpticalFlow on (prev, next); output = base + flow when base_u != nullptr.
 static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const float *next,
                             int nstride, int rows, int cols, int win, const float *base_u,
                             const float *base_v, int bstride, float *u, float *v, int ostride,
-                            float *scratch) {
+                            float *scratch, int form = 0) {
     const size_t n = (size_t)rows * cols;
     float *S = scratch, *T = scratch + 5 * n;
     Taps g;
     gaussian_taps(win, (double)((float)win / 3.f), &g);  // OpticalFlow.cpp:73
-    if (g.n == 43) {  // config/ps5.yaml:11
+    // form: 0 = by size, 2 = always the four launches, 1 = always two (MICV_OPT_LK_FORCE_GENERIC 2 / 1 on a window
+    // the fused kernels do not cover).  Small levels are latency-bound and the two long kernels lose there.
+    const bool two = form == 1 || (form == 0 && (size_t)rows * cols >= kTwoLaunchMinPixels);
+    if (g.n == 43 && (form == 1 || (form == 0 && (size_t)rows * cols >= kTwoLaunchMinPixelsUnrolled))) {  // config/ps5.yaml:11
         constexpr int N = 43;
         const size_t lds_a = (size_t)3 * 8 * ((((256 + N - 1) + 3) & ~3) + 4) * sizeof(float);
         lk_products_rows_pk_kernel<N><<<dim3(cdiv(cols, 256), cdiv(rows, 8)), 256, lds_a, s>>>(prev, pstride, next, nstride,
@@ -579,7 +592,7 @@ static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const
         MICV_LAUNCH_CHECK();
         return MICV_OK;
     }
-    if (g.n >= 5) {  // two launches: images -> row sums -> flow
+    if (two && g.n >= 5) {  // two launches: images -> row sums -> flow
         const size_t lds_a = (size_t)3 * 8 * ((((256 + g.n - 1) + 3) & ~3) + 4) * sizeof(float);
         lk_products_rows_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 8)), 256, lds_a, s>>>(prev, pstride, next, nstride, rows,
                                                                                          cols, T, n, g);
@@ -736,7 +749,7 @@ static int lk_chain_generic(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c
             float *ou = last ? c.u + b * c.opair_elems : bu;
             float *ov = last ? c.v + b * c.opair_elems : bv;
             MICV_TRY(lk_level_generic(s, pk, ist, warped, C, R, C, win, bu, bv, C, ou, ov,
-                                      last ? c.ostride : C, gen));  // :159-162
+                                      last ? c.ostride : C, gen, lk_generic_form(ctx)));  // :159-162
         }
         if (c.profile) MICV_TRY(ctx->prof_end(k, s));
         cur ^= 1;
@@ -911,7 +924,7 @@ int micv_lk_flow_dev(micv_ctx *ctx, const float *prev, const float *next, int ro
     MICV_TRY(ctx->reserve(Carver::need(lk_generic_scratch(rows, cols), 4), &scratch));
     return lk_level_generic(s, prev, (int)(stride / 4), next, (int)(stride / 4), rows, cols, win,
                             nullptr, nullptr, 0, u, v, (int)(ostride / 4),
-                            static_cast<float *>(scratch));
+                            static_cast<float *>(scratch), lk_generic_form(ctx));
 }
 
 int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next, int batch,
@@ -995,7 +1008,7 @@ int micv_lk_level_batch_dev(micv_ctx *ctx, const float *prev, const float *next,
         }
         MICV_TRY(launch_warp(s, nb, (int)(stride / 4), bu, bv, cols, rows, cols, warped, cols));
         MICV_TRY(lk_level_generic(s, pb, (int)(stride / 4), warped, cols, rows, cols, win, bu, bv, cols,
-                                  u + b * ope, v + b * ope, (int)(ostride / 4), gen));
+                                  u + b * ope, v + b * ope, (int)(ostride / 4), gen, lk_generic_form(ctx)));
     }
     return MICV_OK;
 }

@@ -118,9 +118,15 @@ def test_lk_generic_two_launch_tiles(mods, rows, cols, pad, win):
     dn = torch.zeros((rows, cols + pad), dtype=torch.float32, device="cuda")
     dp[:, :cols] = torch.from_numpy(prev)
     dn[:, :cols] = torch.from_numpy(nxt)
-    gu, gv = lk.calcOpticalFlow(dp[:, :cols], dn[:, :cols], win)
-    assert host(gu).tobytes() == eu.tobytes()
-    assert host(gv).tobytes() == ev.tobytes()
+    from introtocomputervision_amd import _capi
+    # 3 = always two launches (window 43: the unrolled kernels, which the default takes from 1 M pixels on),
+    # 2 = always four, 0 = by size
+    for form in (3, 2, 0):
+        ctx = _capi.Context(0)
+        ctx.set_option(_capi.OPT_LK_FORCE_GENERIC, form)
+        gu, gv = lk.calcOpticalFlow(dp[:, :cols], dn[:, :cols], win, ctx=ctx)
+        assert host(gu).tobytes() == eu.tobytes(), form
+        assert host(gv).tobytes() == ev.tobytes(), form
 
 
 def test_lk_single_level_generic_vs_fused(mods):
