@@ -86,6 +86,24 @@ def test_fuzz_lk(shape, pad, seed, kind, win, levels, shift):
         assert same(host(su), e1u) and same(host(sv), e1v)
 
 
+@settings(max_examples=120, **COMMON)
+@given(st.tuples(st.integers(1, 70), st.integers(1, 420)), pad, seed, kind, st.sampled_from([5, 9, 13, 23, 27, 43, 63]),
+       st.sampled_from([3, 3, 2, 0]), st.booleans())
+def test_fuzz_lk_generic_forms(shape, pad, seed, kind, win, form, shift):
+    """The generic level in its two-launch (3; window 43: unrolled, LDS-DMA on interior 128-column tiles) and
+    four-launch (2) forms and with the size-dependent default (0): widths past 256 give the row pass more than one
+    tile and the column pass interior tiles."""
+    from introtocomputervision_amd import lk, _capi
+    rows, cols = shape
+    prev = image(seed, rows, cols, kind)
+    nxt = np.roll(prev, (1, -2), (0, 1)) if shift else image(seed + 1, rows, cols, kind)
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_FORCE_GENERIC, form)
+    su, sv = lk.calcOpticalFlow(dev(prev, pad), dev(nxt, pad), winSize=win, ctx=ctx)
+    eu, ev = orc.lk_flow(prev, nxt, win)
+    assert same(host(su), eu) and same(host(sv), ev), (rows, cols, pad, win, form)
+
+
 @settings(max_examples=200, **COMMON)
 @given(shape, pad, seed, st.floats(0.0, 40.0), st.booleans())
 def test_fuzz_warp_pyr_resize(shape, pad, seed, amp, wild):
