@@ -129,6 +129,18 @@ def test_lk_generic_two_launch_tiles(mods, rows, cols, pad, win):
         assert host(gv).tobytes() == ev.tobytes(), form
 
 
+def test_lk_window43_1080p_default_path(mods):
+    """config/ps5.yaml's window 43 at the C2 frame size: from 1 M pixels on the default is the unrolled two-launch
+    form (interior 128-column tiles by LDS-DMA, 1080 = 33 x 32 + 24 rows); every pixel against the oracle."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    prev, nxt = synth.lk_pair(0x5EED0005, 1080, 1920, 3, -2)
+    eu, ev = orc.lk_flow(prev, nxt, 43)
+    gu, gv = lk.calcOpticalFlow(dev(prev), dev(nxt), 43)
+    assert host(gu).tobytes() == eu.tobytes()
+    assert host(gv).tobytes() == ev.tobytes()
+
+
 def test_lk_single_level_generic_vs_fused(mods):
     lk, pyr = mods
     from introtocomputervision_amd import synth, _capi
