@@ -42,10 +42,9 @@ __global__ void compact_scan_kernel(const int *__restrict__ chunk_count,
                                     int64_t *__restrict__ chunk_off, int nchunks,
                                     int64_t *__restrict__ count);
 
-template <typename Pred>
-__global__ __launch_bounds__(256) void compact_emit_kernel(Pred pred, int64_t n,
+template <typename Pred, typename Emit>
+__global__ __launch_bounds__(256) void compact_emit_kernel(Pred pred, Emit emit, int64_t n,
                                                             const int64_t *__restrict__ chunk_off,
-                                                            int32_t *__restrict__ out,
                                                             int64_t cap) {
     __shared__ int wcount[16];
     const int64_t base = (int64_t)blockIdx.x * kChunk;
@@ -68,7 +67,7 @@ __global__ __launch_bounds__(256) void compact_emit_kernel(Pred pred, int64_t n,
         int prior = 0;  // hits in earlier (j', wave') slots: slot order == index order
         for (int s = 0; s < j * 4 + wave; s++) prior += wcount[s];
         const int64_t pos = off + prior + before[j];
-        if (pos < cap) out[pos] = (int32_t)(base + j * 256 + threadIdx.x);
+        if (pos < cap) emit(pos, base + j * 256 + threadIdx.x);
     }
 }
 
@@ -193,14 +192,9 @@ inline size_t compact_scratch_bytes(int64_t n) {
 int launch_compact_scan(hipStream_t s, const int *chunk_count, int64_t *chunk_off, int nchunks,
                         int64_t *count);
 
-// out: device int32[cap]; count: device int64 (total hits, may exceed cap).
-template <typename Pred>
-int ordered_compact(hipStream_t s, Pred pred, int64_t n, int32_t *out, int64_t cap, int64_t *count,
-                    void *scratch) {
-    if (n >= (int64_t)1 << 31) {
-        set_error("ordered_compact: %lld elements exceed int32 indices", (long long)n);
-        return MICV_EINVAL;
-    }
+// count: device int64 (total hits, may exceed cap: only the first cap are written).
+template <typename Pred, typename Emit>
+int ordered_compact3(hipStream_t s, Pred pred, Emit emit, int64_t n, int64_t cap, int64_t *count, void *scratch) {
     const int nchunks = (int)((n + kChunk - 1) / kChunk);
     Carver c(scratch);
     int *chunk_count = c.take<int>(nchunks);
@@ -212,17 +206,16 @@ int ordered_compact(hipStream_t s, Pred pred, int64_t n, int32_t *out, int64_t c
     compact_count_kernel<<<nchunks, 256, 0, s>>>(pred, n, chunk_count);
     MICV_LAUNCH_CHECK();
     MICV_TRY(launch_compact_scan(s, chunk_count, chunk_off, nchunks, count));
-    compact_emit_kernel<<<nchunks, 256, 0, s>>>(pred, n, chunk_off, out, cap);
+    compact_emit_kernel<<<nchunks, 256, 0, s>>>(pred, emit, n, chunk_off, cap);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
 
-// The one-launch form when the context has a state buffer for this stream (MICV_OPT_COMPACT_3PASS forces the
-// other).  `emit` decides what is written; `idx` (int32[cap], may be null when emit does not need it) is only
-// used by the three-launch fallback, which reports through *used_fallback that the caller has to convert idx.
+// The one-launch form when the context has a state buffer for this stream and the list is short enough (below;
+// MICV_OPT_COMPACT_3PASS forces either form), the three launches otherwise.  `emit` decides what a hit becomes.
 template <typename Pred, typename Emit>
-int ordered_compact(micv_ctx *ctx, hipStream_t s, Pred pred, Emit emit, int64_t n, int32_t *idx, int64_t cap,
-                    int64_t *count, void *scratch, bool *used_fallback) {
+int ordered_compact(micv_ctx *ctx, hipStream_t s, Pred pred, Emit emit, int64_t n, int64_t cap, int64_t *count,
+                    void *scratch) {
     if (n >= (int64_t)1 << 31) {
         set_error("ordered_compact: %lld elements exceed int32 indices", (long long)n);
         return MICV_EINVAL;
@@ -230,7 +223,6 @@ int ordered_compact(micv_ctx *ctx, hipStream_t s, Pred pred, Emit emit, int64_t 
     const int nchunks = (int)((n + kChunk1 - 1) / kChunk1);
     unsigned long long *status = nullptr;
     unsigned *counters = nullptr;
-    *used_fallback = false;
     // Up to 256 chunks (1 M elements) every chunk reaches chunk 0 in ONE look-back step -- it just adds up its
     // predecessors' counts -- and the launch costs less than three (VGA corner list 36 -> 27 us).  Beyond that the
     // walk back to the spreading running totals takes several dependent steps for the first round of workgroups and
@@ -242,8 +234,7 @@ int ordered_compact(micv_ctx *ctx, hipStream_t s, Pred pred, Emit emit, int64_t 
         MICV_LAUNCH_CHECK();
         return MICV_OK;
     }
-    *used_fallback = true;
-    return ordered_compact(s, pred, n, idx, cap, count, scratch);
+    return ordered_compact3(s, pred, emit, n, cap, count, scratch);
 }
 
 }  // namespace micv

@@ -242,6 +242,34 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float *__restrict
 // in the scan above too).
 // DT > 0: minDistance known at compile time (loops unroll, the LDS reads of a window are all in
 // flight); DT == 0: any d <= 16 with rolled loops.
+// (maximum, how often it occurs) of the four windows [j, j + 2D], j = 0..3, of 4 + 2D values; w = nullptr: every
+// value counts once, else value k counts w[k] times (the column pass adds up the row pass's counts).  The windows
+// share the values [3, 2D]: their maximum and its count are formed once; a window's own maximum is that one or one
+// of its three other values, and when it is larger than the common maximum nothing of the common part equals it.
+// fmaxf skips NaN and `==` is false for it, as in the plain scans; max and integer sums do not depend on the order.
+template <int D>
+__device__ __forceinline__ void nms_window4(const float (&v)[4 + 2 * D], const int *w, float (&m)[4], int (&n)[4]) {
+    float mc = -INFINITY;
+#pragma unroll
+    for (int k = 3; k <= 2 * D; k++) mc = fmaxf(mc, v[k]);
+    int nc = 0;
+#pragma unroll
+    for (int k = 3; k <= 2 * D; k++) nc += v[k] == mc ? (w ? w[k] : 1) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float mj = mc;
+#pragma unroll
+        for (int k = j; k <= j + 2 * D; k++)
+            if (k < 3 || k > 2 * D) mj = fmaxf(mj, v[k]);
+        int nj = mj == mc ? nc : 0;
+#pragma unroll
+        for (int k = j; k <= j + 2 * D; k++)
+            if (k < 3 || k > 2 * D) nj += v[k] == mj ? (w ? w[k] : 1) : 0;
+        m[j] = mj;
+        n[j] = nj;
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__restrict__ resp,
                                                                 int rstride, int rows, int cols,
@@ -252,8 +280,8 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
     constexpr int TW = 64, TH = DT > 0 ? 32 : 16, DMAX = DT > 0 ? DT : 16;  // taller tiles re-fetch less halo
     const int d = DT > 0 ? DT : d_rt;
     __shared__ float T[(TH + 2 * DMAX) * (TW + 2 * DMAX + 1)];
-    __shared__ float RM[(TH + 2 * DMAX) * TW];
-    __shared__ int RN[(TH + 2 * DMAX) * TW];
+    __shared__ __attribute__((aligned(16))) float RM[(TH + 2 * DMAX) * TW];
+    __shared__ __attribute__((aligned(16))) int RN[(TH + 2 * DMAX) * TW];
     const int RW = TW + 2 * d, RH = TH + 2 * d, TS = RW | 1;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     // Staging: 128 lanes per region row (RW <= 96), two rows per pass of the workgroup, four
@@ -277,18 +305,60 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         }
     }
     __syncthreads();
+    if constexpr (DT > 0) {
+        // Four adjacent windows at a time (nms_window4): 4 + 2d staged values serve four cells, and their common
+        // part is scanned once -- 14 LDS reads and ~70 instructions per four cells at d = 5 instead of 44 and 132.
+        // Row pass: job = (region row, group of four columns); lanes = 16 groups x 4 rows, conflict-free at the odd pitch.
+        for (int i = threadIdx.x; i < RH * (TW / 4); i += 256) {
+            const int r = i / (TW / 4), c4 = 4 * (i - r * (TW / 4));
+            const float *tp = T + r * TS + c4;
+            float v[4 + 2 * DT];
+#pragma unroll
+            for (int k = 0; k < 4 + 2 * DT; k++) v[k] = tp[k];
+            float m[4];
+            int n[4];
+            nms_window4<DT>(v, nullptr, m, n);
+            *reinterpret_cast<hv4f *>(RM + r * TW + c4) = (hv4f){m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<int4 *>(RN + r * TW + c4) = make_int4(n[0], n[1], n[2], n[3]);
+        }
+        __syncthreads();
+        // column pass: job = (column, group of four rows)
+        const int c = threadIdx.x & 63, x = x0 + c;
+        if (x >= cols) return;
+        for (int rg = threadIdx.x >> 6; rg < TH / 4; rg += 4) {
+            const int ry0 = 4 * rg;
+            if (y0 + ry0 >= rows) break;
+            float v[4 + 2 * DT];
+            int w[4 + 2 * DT];
+#pragma unroll
+            for (int k = 0; k < 4 + 2 * DT; k++) {
+                v[k] = RM[(ry0 + k) * TW + c];
+                w[k] = RN[(ry0 + k) * TW + c];
+            }
+            float M[4];
+            int N[4];
+            nms_window4<DT>(v, w, M, N);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int y = y0 + ry0 + j;
+                if (y < rows) {
+                    const float pv = T[(ry0 + j + DT) * TS + c + DT];
+                    const bool keep = (double)pv >= threshold && pv == M[j] && N[j] == 1;
+                    corners[(size_t)y * cstride + x] = keep ? pv : 0.f;
+                    flag[(size_t)y * cols + x] = keep ? 1 : 0;
+                }
+            }
+        }
+        return;
+    }
     // row pass: window maximum (fmaxf skips NaN), then how many cells equal it
     for (int i = threadIdx.x; i < RH * TW; i += 256) {
         const int r = i / TW, c = i - r * TW;
         const float *tp = T + r * TS + c;
         float m = -INFINITY;
-#pragma unroll
-        for (int k = 0; k <= 2 * DMAX; k++)
-            if (DT > 0 || k <= 2 * d) m = fmaxf(m, tp[k]);
+        for (int k = 0; k <= 2 * d; k++) m = fmaxf(m, tp[k]);
         int n = 0;
-#pragma unroll
-        for (int k = 0; k <= 2 * DMAX; k++)
-            if (DT > 0 || k <= 2 * d) n += tp[k] == m ? 1 : 0;
+        for (int k = 0; k <= 2 * d; k++) n += tp[k] == m ? 1 : 0;
         RM[i] = m;
         RN[i] = n;
     }
@@ -299,13 +369,9 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         const int y = y0 + ry;
         if (y >= rows) break;
         float M = -INFINITY;
-#pragma unroll
-        for (int k = 0; k <= 2 * DMAX; k++)
-            if (DT > 0 || k <= 2 * d) M = fmaxf(M, RM[(ry + k) * TW + c]);
+        for (int k = 0; k <= 2 * d; k++) M = fmaxf(M, RM[(ry + k) * TW + c]);
         int N = 0;
-#pragma unroll
-        for (int k = 0; k <= 2 * DMAX; k++)
-            if (DT > 0 || k <= 2 * d) N += RM[(ry + k) * TW + c] == M ? RN[(ry + k) * TW + c] : 0;
+        for (int k = 0; k <= 2 * d; k++) N += RM[(ry + k) * TW + c] == M ? RN[(ry + k) * TW + c] : 0;
         const float v = T[(ry + d) * TS + c + d];
         const bool keep = (double)v >= threshold && v == M && N == 1;
         corners[(size_t)y * cstride + x] = keep ? v : 0.f;
@@ -317,18 +383,6 @@ struct FlagPred {
     const uint8_t *flag;
     __device__ bool operator()(int64_t i) const { return flag[i] != 0; }
 };
-
-// linear index -> (y, x) pairs, Harris.cu:314-318 (Conv1Dto2D).
-__global__ void idx_to_yx_kernel(int32_t *__restrict__ locs, const int32_t *__restrict__ idx,
-                                 const int64_t *__restrict__ count, int64_t cap, int cols) {
-    const int64_t n = *count < cap ? *count : cap;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t v = idx[i];
-        locs[2 * i] = v / cols;
-        locs[2 * i + 1] = v % cols;
-    }
-}
 
 // ---- a11 ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sift_angles_kernel(const float *__restrict__ gx,
@@ -414,11 +468,9 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)rows * cols;
     void *scratch;
-    MICV_TRY(ctx->reserve(Carver::need(n, 1) + Carver::need(cap, 4) + compact_scratch_bytes(n),
-                          &scratch));
+    MICV_TRY(ctx->reserve(Carver::need(n, 1) + compact_scratch_bytes(n), &scratch));
     Carver c(scratch);
     uint8_t *flag = c.take<uint8_t>(n);
-    int32_t *idx = c.take<int32_t>(cap);
     const bool force_scan = ctx->opt[MICV_OPT_NMS_SCAN] != 0;
     if (min_distance <= 16 && !force_scan) {
 #define MICV_NMS(DT)                                                                             \
@@ -444,14 +496,8 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
             resp, (int)(rstride / 4), rows, cols, threshold, min_distance, corners,
             (int)(cstride / 4), flag);
     MICV_LAUNCH_CHECK();
-    // one launch writes the (y, x) list; the three-launch fallback leaves linear indices to convert
-    bool fallback = false;
-    MICV_TRY(ordered_compact(ctx, s, FlagPred{flag}, YxEmit{locs_yx, cols}, n, idx, cap, count, c.base + c.off, &fallback));
-    if (fallback && cap > 0) {
-        idx_to_yx_kernel<<<64, 256, 0, s>>>(locs_yx, idx, count, cap, cols);
-        MICV_LAUNCH_CHECK();
-    }
-    return MICV_OK;
+    // (y, x) written directly, Harris.cu:314-318 (Conv1Dto2D)
+    return ordered_compact(ctx, s, FlagPred{flag}, YxEmit{locs_yx, cols}, n, cap, count, c.base + c.off);
 }
 
 int micv_sift_angles_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,

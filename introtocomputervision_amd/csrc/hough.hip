@@ -357,8 +357,7 @@ static int hough_points(micv_ctx *ctx, hipStream_t s, const uint8_t *mask, int r
     *pts = c.take<int32_t>(n);
     *npts = c.take<int64_t>(1);
     *extra = c.take<char>(extra_bytes);
-    bool fallback = false;
-    return ordered_compact(ctx, s, MaskPred{mask, cols, mstride}, IndexEmit{*pts}, n, *pts, n, *npts, c.base + c.off, &fallback);
+    return ordered_compact(ctx, s, MaskPred{mask, cols, mstride}, IndexEmit{*pts}, n, n, *npts, c.base + c.off);
 }
 
 int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
@@ -450,9 +449,7 @@ int micv_hough_peaks_dev(micv_ctx *ctx, const int32_t *acc, int rows, int cols,
     int32_t *cand = c.take<int32_t>(n);
     int64_t *ncand = c.take<int64_t>(1);
     unsigned long long *sel = c.take<unsigned long long>((size_t)num_peaks + 1);
-    bool fallback = false;
-    MICV_TRY(ordered_compact(ctx, s, PeakPred{acc, rows, cols, threshold}, IndexEmit{cand}, n, cand, n, ncand, c.base + c.off,
-                             &fallback));
+    MICV_TRY(ordered_compact(ctx, s, PeakPred{acc, rows, cols, threshold}, IndexEmit{cand}, n, n, ncand, c.base + c.off));
     if (num_peaks <= 64) {
         peak_select_all_kernel<<<1, 1024, 0, s>>>(acc, cand, ncand, n, num_peaks, cols, peaks_rc, count);
         MICV_LAUNCH_CHECK();

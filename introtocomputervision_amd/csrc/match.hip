@@ -212,8 +212,7 @@ int micv_bf_ratio_filter_dev(micv_ctx *ctx, const int32_t *idx2, const float *di
     MICV_TRY(ctx->reserve(Carver::need((size_t)cap + 1, 4) + compact_scratch_bytes(nq), &scratch));
     Carver c(scratch);
     int32_t *sel = c.take<int32_t>((size_t)cap + 1);
-    bool fallback = false;
-    MICV_TRY(ordered_compact(ctx, s, RatioPred{dist2, ratio}, IndexEmit{sel}, nq, sel, cap, count, c.base + c.off, &fallback));
+    MICV_TRY(ordered_compact(ctx, s, RatioPred{dist2, ratio}, IndexEmit{sel}, nq, cap, count, c.base + c.off));
     if (cap > 0) {
         bf_emit_kernel<<<64, 256, 0, s>>>(sel, count, cap, idx2, dist2, matches_qt, distances);
         MICV_LAUNCH_CHECK();
