@@ -171,7 +171,7 @@ def parse_args(argv=None):
                     help="stream groups the library splits a batch into (0 = its default, 1); the PMC "
                          "passes of tools/profile.sh use 1 so a level-0 dispatch covers the whole batch")
     ap.add_argument("--lk-chain", type=int, default=0,
-                    help="MICV_OPT_LK_CHAIN of every context: 0 = the library's rule, 1 = no tile chains, n = longest chain")
+                    help="MICV_OPT_LK_CHAIN of every context: 0 = the library's rule (pairs of tiles only for launches just over whole rounds), 1 = no tile chains, n = longest chain")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="micv_ctx_set_option on every context, e.g. --opt OPT_LK_TALL_TILES=1 (A/B and PMC runs)")
     ap.add_argument("--no-pmc", action="store_true",

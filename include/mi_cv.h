@@ -58,7 +58,7 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 #define MICV_OPT_HARRIS_GENERIC    5 /* Harris response: one-thread-per-pixel kernel */
 #define MICV_OPT_NMS_SCAN          6 /* Harris NMS: scanning kernel instead of the separable one */
 #define MICV_OPT_STEREO_ROWS       7 /* rows per stereo strip: 0 = automatic, 8 or 10 */
-#define MICV_OPT_LK_CHAIN          8 /* fused LK tile chains: 0 / 1 = off (default), n = longest chain (<= 32), -1 = schedule only */
+#define MICV_OPT_LK_CHAIN          8 /* fused LK tile chains: 0 = pairs of tiles only for launches a little over one or two rounds of workgroups (default), 1 = never, n = longest chain (<= 32), -1 = schedule only */
 #define MICV_OPT_LK_SHORT_TILES    9 /* win-15 level kernel, 64x16 tiles: 0 = up to 512 tiles (one round), n = up to n, -1 = never */
 #define MICV_OPT_LK_STREAM         10 /* level kernel as a persistent grid that stages the next tile ahead: 1 = on, 0 = off (default; measured slower) */
 #define MICV_OPT_LK_TALL_TILES     11 /* 1024-thread tiles, one workgroup per CU, for big launches: window 15 on 64x64 tiles only with 1 (measured slower); window 21 on 64x32 tiles by default (0 or 1; measured faster); -1 = never */

@@ -1541,8 +1541,26 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             // With the shuffle-free packed row pass (r02) the chain kernel no longer beats the plain one
             // (A/B on one box, bench.py: 41.6 vs 41.6 Gpix/s, sustained 0.372 vs 0.368 ms): chains are
             // an option (MICV_OPT_LK_CHAIN > 1), not the default.
-            (void)tiles;
+            // r03b, on the kernel as it is now (tools/level_bench.py, 8 / 16 pairs): chains of two still lose on
+            // level 0 and level 1 (0.203 vs 0.199, 0.059 vs 0.058 ms) but win where the tile count is a little over
+            // a whole number of rounds -- level 2 of 8 pairs, 576 tiles on 512 slots: 0.0286 -> 0.0251 ms (288
+            // two-tile workgroups in one round instead of two rounds of single tiles); 16 pairs, 1152 tiles:
+            // 0.0421 -> 0.0382.  MICV_OPT_LK_CHAIN = 0 takes them exactly there; 1 = never.
             int max_chain = a.max_chain > 1 ? a.max_chain : 1;
+            if (a.max_chain == 0) {
+                static thread_local int slots_dev = -1;
+                static thread_local long slots = 512;
+                int dev = 0;
+                MICV_HIP(hipGetDevice(&dev));
+                if (slots_dev != dev) {
+                    int n_cu = 256;
+                    MICV_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+                    slots = 2L * n_cu;  // two 512-thread workgroups per CU
+                    slots_dev = dev;
+                }
+                const long rounds = tiles / slots, rem = tiles % slots;
+                if (rounds >= 1 && rounds <= 2 && rem > 0 && rem <= slots / 4) max_chain = 2;
+            }
             if (max_chain > 32) max_chain = 32;
             const bool sched_only = a.max_chain < 0;
             if (sched_only) max_chain = 1;  // the schedule kernel with single tiles only

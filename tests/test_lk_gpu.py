@@ -436,6 +436,28 @@ def test_tile_chains_are_bit_exact(mods, rows, cols, levels, batch, max_chain):
     assert torch.equal(su, u) and torch.equal(sv, v)
 
 
+@pytest.mark.parametrize("rows,cols,batch", [(270, 480, 8), (270, 480, 16), (270, 480, 7)])
+def test_automatic_chain_rule_is_bit_exact(mods, rows, cols, batch):
+    """MICV_OPT_LK_CHAIN = 0 (default) runs pairs of tiles where a launch is a little over one or two rounds of
+    workgroups: 8 (16) pairs of 270x480 are 576 (1152) 64x32 tiles on 512 slots -- level 2 of the bench's step.
+    Same bits as chains off (1) and as the oracle; 7 pairs (504 tiles) stay on the plain grid."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(5100 + i, rows, cols, 2, -1) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    out = {}
+    for opt in (0, 1):
+        ctx = _capi.Context(0)
+        ctx.set_option(_capi.OPT_LK_CHAIN, opt)
+        ctx.set_lk_groups(1)
+        for rep in range(2):
+            out[opt] = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, 2, ctx=ctx)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    for i in (0, batch - 1):
+        eu, ev = orc.lk_flow_pyr(prev[i], nxt[i], 15, 2)
+        assert np.array_equal(host(out[0][0][i]), eu) and np.array_equal(host(out[0][1][i]), ev), i
+
+
 @pytest.mark.parametrize("rows,cols,levels,batch,win", [(270, 480, 2, 1, 15), (540, 960, 3, 2, 15), (1080, 1920, 5, 1, 15),
                                                         (330, 700, 3, 3, 15), (200, 210, 2, 1, 15), (97, 400, 2, 2, 15),
                                                         (540, 960, 3, 9, 15), (300, 520, 3, 2, 7), (300, 520, 2, 3, 11)])
