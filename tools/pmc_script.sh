@@ -1,12 +1,12 @@
 #!/usr/bin/env bash
 # Issue / stall counters (one rocprofv3 --pmc pass, 8 SQ counters) of every kernel a python script launches:
-#   bash tools/pmc_script.sh tools/probes/win43_trace.py [kernel-name-substring]
+#   bash tools/pmc_script.sh tools/probes/win43_trace.py [kernel-name-substring [script args ...]]
 repo="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
-script="$(realpath "$1")"; filt="${2:-}"
+script="$(realpath "$1")"; filt="${2:-}"; shift; [ $# -gt 0 ] && shift
 out="$repo/gpurun_out/pmcs"; rm -rf "$out"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES \
-    --output-format csv -d "$out" -- python3 "$script" > /dev/null 2>&1
+    --output-format csv -d "$out" -- python3 "$script" "$@" > "$out.log" 2>&1
 python3 - "$out" "$filt" <<'PY'
 import csv, glob, sys, collections, json
 d = collections.defaultdict(lambda: collections.defaultdict(list))
