@@ -280,9 +280,22 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
                 const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
                 const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
                 // NaN samples (a NaN gradient) have no defined bin: o0 is clamped so the adds stay inside
-                // the histogram; what they add is llrint(NaN), as on the host
+                // the histogram; what they add is llrintf(NaN) as the host's cvtss2si returns it, INT64_MIN, for
+                // each of the eight shares (every share of a NaN magnitude is NaN)
                 o0 = o0 < 0 ? 0 : (o0 > SN - 1 ? SN - 1 : o0);
                 const int idx = ((r0 + 1) * (SD + 2) + c0 + 1) * (SN + 2) + o0 + (lane & (COPIES - 1)) * SHIST;
+                if (mag != mag) {
+                    const unsigned long long ind = 0x8000000000000000ull;
+                    atomicAdd(&hist[idx], ind);
+                    atomicAdd(&hist[idx + 1], ind);
+                    atomicAdd(&hist[idx + (SN + 2)], ind);
+                    atomicAdd(&hist[idx + (SN + 3)], ind);
+                    atomicAdd(&hist[idx + (SD + 2) * (SN + 2)], ind);
+                    atomicAdd(&hist[idx + (SD + 2) * (SN + 2) + 1], ind);
+                    atomicAdd(&hist[idx + (SD + 3) * (SN + 2)], ind);
+                    atomicAdd(&hist[idx + (SD + 3) * (SN + 2) + 1], ind);
+                    continue;
+                }
                 // llrintf(ldexpf(v, sh)) for 0 <= v * 2^sh < 2^41: one double fma onto 2^52 rounds to the
                 // nearest-even integer and leaves it in the low mantissa bits
 #define MICV_FX(v) ((unsigned long long)__double_as_longlong(fma((double)(v), fx_scale, 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull)

@@ -133,6 +133,20 @@ def test_descriptors_many_keypoints_one_wave_each():
     assert np.array_equal(got, exp)
     few = harris.computeDescriptors(dgx, dgy, torch.from_numpy(kps[:300]).cuda()).cpu().numpy()
     assert np.array_equal(few, exp[:300])
+    # non-finite and flat gradients, pitched planes: a NaN gradient adds llrintf(NaN) = INT64_MIN per share, as the
+    # host's conversion returns it (r03: the kernel added the NaN's mantissa bits instead -- 62 descriptors differed)
+    gx2, gy2 = gx.copy(), gy.copy()
+    gx2[40, 50] = np.nan
+    gy2[90, 120] = np.inf
+    gx2[100:110, 30:60] = 0
+    gy2[100:110, 30:60] = 0
+    exp2 = orc.sift_descriptors(gx2, gy2, kps)
+    px = torch.zeros((rows, cols + 6), device="cuda"); py = torch.zeros((rows, cols + 6), device="cuda")
+    px[:, :cols] = torch.from_numpy(gx2); py[:, :cols] = torch.from_numpy(gy2)
+    g3 = harris.computeDescriptors(px[:, :cols], py[:, :cols], torch.from_numpy(kps).cuda()).cpu().numpy()
+    assert g3.tobytes() == exp2.tobytes()
+    g4 = harris.computeDescriptors(px[:, :cols], py[:, :cols], torch.from_numpy(kps[:200]).cuda()).cpu().numpy()  # four waves per keypoint
+    assert g4.tobytes() == exp2[:200].tobytes()
 
 
 @pytest.mark.gpu
