@@ -192,3 +192,31 @@ def test_fuzz_hough(shape, pad, seed, density, rho_bin, theta_bin, radius, num_p
     thr = int(max(1, eacc.max() // 2))
     assert np.array_equal(host(hough.findLocalMaxima(acc, num_peaks, thr)).astype(np.uint32),
                           orc.hough_peaks(eacc, num_peaks, thr))
+
+
+@settings(max_examples=60, **COMMON)
+@given(st.tuples(st.integers(3, 90), st.integers(3, 120)), pad, seed, st.integers(1, 40), st.sampled_from([0, 0, 1, 2, 3]),
+       st.floats(-8.0, 8.0))
+def test_fuzz_sift_descriptors(shape, pad, seed, nkp, poison, log_scale):
+    """Descriptor windows over random gradient fields of any magnitude (2^-8 .. 2^8 of 8-bit gradients), keypoints in
+    and out of the image with sizes from a pixel to more than the image, and poisoned fields: a NaN, an infinity, a
+    flat block -- the corner the NaN-share fix of r03 came from."""
+    import torch
+    from introtocomputervision_amd import harris
+    rows, cols = shape
+    rng = np.random.default_rng(seed)
+    scale = np.float32(2.0 ** log_scale)
+    gx = (rng.standard_normal((rows, cols)) * 60).astype(np.float32) * scale
+    gy = (rng.standard_normal((rows, cols)) * 60).astype(np.float32) * scale
+    if poison == 1:
+        gx[rng.integers(0, rows), rng.integers(0, cols)] = np.nan
+    elif poison == 2:
+        gy[rng.integers(0, rows), rng.integers(0, cols)] = np.float32(np.inf) * (1 if seed & 1 else -1)
+    elif poison == 3:
+        gx[: rows // 2, : cols // 2] = 0
+        gy[: rows // 2, : cols // 2] = 0
+    kps = np.stack([rng.uniform(-10, cols + 10, nkp), rng.uniform(-10, rows + 10, nkp),
+                    rng.choice([0.5, 1.5, 8 / 3, 4, 10, 40], nkp), rng.uniform(-400, 800, nkp)], 1).astype(np.float32)
+    exp = orc.sift_descriptors(gx, gy, kps)
+    got = harris.computeDescriptors(dev(gx, pad), dev(gy, pad), torch.from_numpy(kps).cuda())
+    assert same(host(got), exp), (rows, cols, pad, nkp, poison)
