@@ -436,11 +436,31 @@ def test_tile_chains_are_bit_exact(mods, rows, cols, levels, batch, max_chain):
     assert torch.equal(su, u) and torch.equal(sv, v)
 
 
+@pytest.mark.parametrize("rows,cols,levels,batch", [(540, 960, 3, 2), (330, 700, 3, 3), (97, 400, 2, 2)])
+@pytest.mark.parametrize("max_chain", [2, 4, 32])
+def test_tile_chains_window_11(mods, rows, cols, levels, batch, max_chain):
+    """The chain kernel's other instantiation (window 11, halo 8): forced chains against chains off and the oracle."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(4400 + i + rows, rows, cols, 2, -3) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_CHAIN, max_chain)
+    u, v = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 11, levels, ctx=ctx)
+    ctx.set_option(_capi.OPT_LK_CHAIN, 1)
+    su, sv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 11, levels, ctx=ctx)
+    assert torch.equal(su, u) and torch.equal(sv, v)
+    eu, ev = orc.lk_flow_pyr(prev[0], nxt[0], 11, levels)
+    assert np.array_equal(host(u[0]), eu) and np.array_equal(host(v[0]), ev)
+
+
+@pytest.mark.parametrize("win", [15, 11, 7])
 @pytest.mark.parametrize("rows,cols,batch", [(270, 480, 8), (270, 480, 16), (270, 480, 7)])
-def test_automatic_chain_rule_is_bit_exact(mods, rows, cols, batch):
+def test_automatic_chain_rule_is_bit_exact(mods, rows, cols, batch, win):
     """MICV_OPT_LK_CHAIN = 0 (default) runs pairs of tiles where a launch is a little over one or two rounds of
     workgroups: 8 (16) pairs of 270x480 are 576 (1152) 64x32 tiles on 512 slots -- level 2 of the bench's step.
-    Same bits as chains off (1) and as the oracle; 7 pairs (504 tiles) stay on the plain grid."""
+    Same bits as chains off (1) and as the oracle; 7 pairs (504 tiles) stay on the plain grid.  Window 11 has a chain
+    kernel too (window 7's region does not split into whole LDS-DMA waves: always the plain grid)."""
     lk, pyr = mods
     from introtocomputervision_amd import synth, _capi
     pairs = [synth.lk_pair(5100 + i, rows, cols, 2, -1) for i in range(batch)]
@@ -451,10 +471,10 @@ def test_automatic_chain_rule_is_bit_exact(mods, rows, cols, batch):
         ctx.set_option(_capi.OPT_LK_CHAIN, opt)
         ctx.set_lk_groups(1)
         for rep in range(2):
-            out[opt] = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, 2, ctx=ctx)
+            out[opt] = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), win, 2, ctx=ctx)
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     for i in (0, batch - 1):
-        eu, ev = orc.lk_flow_pyr(prev[i], nxt[i], 15, 2)
+        eu, ev = orc.lk_flow_pyr(prev[i], nxt[i], win, 2)
         assert np.array_equal(host(out[0][0][i]), eu) and np.array_equal(host(out[0][1][i]), ev), i
 
 
