@@ -15,7 +15,11 @@ hyp = pytest.importorskip("hypothesis")
 from hypothesis import HealthCheck, given, settings  # noqa: E402
 from hypothesis import strategies as st  # noqa: E402
 
-COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck), print_blob=True)
+import os  # noqa: E402
+
+# MICV_FUZZ_SCALE=n: n times the examples, drawn at random instead of the fixed sequence (a soak run by hand)
+SCALE = max(1, int(os.environ.get("MICV_FUZZ_SCALE", "1")))
+COMMON = dict(deadline=None, derandomize=SCALE == 1, suppress_health_check=list(HealthCheck), print_blob=True)
 
 
 def dev(a, pad=0):
@@ -68,7 +72,7 @@ seed = st.integers(0, 2 ** 31 - 1)
 kind = st.integers(0, 3)
 
 
-@settings(max_examples=300, **COMMON)
+@settings(max_examples=300 * SCALE, **COMMON)
 @given(shape, pad, seed, kind, st.sampled_from([1, 3, 5, 7, 11, 15, 21, 23, 43]), st.integers(1, 5), st.booleans())
 def test_fuzz_lk(shape, pad, seed, kind, win, levels, shift):
     from introtocomputervision_amd import lk
@@ -86,7 +90,7 @@ def test_fuzz_lk(shape, pad, seed, kind, win, levels, shift):
         assert same(host(su), e1u) and same(host(sv), e1v)
 
 
-@settings(max_examples=120, **COMMON)
+@settings(max_examples=120 * SCALE, **COMMON)
 @given(st.tuples(st.integers(1, 70), st.integers(1, 420)), pad, seed, kind, st.sampled_from([5, 9, 13, 23, 27, 43, 63]),
        st.sampled_from([3, 3, 2, 0]), st.booleans())
 def test_fuzz_lk_generic_forms(shape, pad, seed, kind, win, form, shift):
@@ -104,7 +108,7 @@ def test_fuzz_lk_generic_forms(shape, pad, seed, kind, win, form, shift):
     assert same(host(su), eu) and same(host(sv), ev), (rows, cols, pad, win, form)
 
 
-@settings(max_examples=200, **COMMON)
+@settings(max_examples=200 * SCALE, **COMMON)
 @given(shape, pad, seed, st.floats(0.0, 40.0), st.booleans())
 def test_fuzz_warp_pyr_resize(shape, pad, seed, amp, wild):
     from introtocomputervision_amd import lk, pyr
@@ -129,7 +133,7 @@ def test_fuzz_warp_pyr_resize(shape, pad, seed, amp, wild):
         assert same(host(g), e)
 
 
-@settings(max_examples=200, **COMMON)
+@settings(max_examples=200 * SCALE, **COMMON)
 @given(shape, pad, seed, kind, st.sampled_from([1, 3, 5, 7]), st.sampled_from([3, 5, 7, 9]),
        st.floats(0.5, 3.0), st.integers(1, 9))
 def test_fuzz_harris(shape, pad, seed, kind, ksize, window, sigma, min_dist):
@@ -148,7 +152,7 @@ def test_fuzz_harris(shape, pad, seed, kind, ksize, window, sigma, min_dist):
     assert same(host(corners), ecorners) and np.array_equal(host(locs), elocs)
 
 
-@settings(max_examples=300, **COMMON)
+@settings(max_examples=300 * SCALE, **COMMON)
 @given(st.tuples(st.integers(1, 100), st.integers(1, 150)), pad, seed, st.integers(0, 12), st.integers(-40, 20),
        st.integers(0, 40), st.sampled_from([0, 1, 2, 3, 8, 9, 11]), st.booleans(), st.booleans())
 def test_fuzz_stereo(shape, pad, seed, rad, min_d, span, flags, ncc, integer):
@@ -172,7 +176,7 @@ def test_fuzz_stereo(shape, pad, seed, rad, min_d, span, flags, ncc, integer):
     assert np.array_equal(host(got), exp), (rows, cols, rad, min_d, max_d, flags, ncc, int((host(got) != exp).sum()))
 
 
-@settings(max_examples=150, **COMMON)
+@settings(max_examples=150 * SCALE, **COMMON)
 @given(st.tuples(st.integers(2, 120), st.integers(2, 160)), pad, seed, st.floats(0.0, 0.2), st.integers(1, 3),
        st.integers(1, 5), st.integers(1, 30), st.integers(1, 20))
 def test_fuzz_hough(shape, pad, seed, density, rho_bin, theta_bin, radius, num_peaks):
@@ -194,7 +198,7 @@ def test_fuzz_hough(shape, pad, seed, density, rho_bin, theta_bin, radius, num_p
                           orc.hough_peaks(eacc, num_peaks, thr))
 
 
-@settings(max_examples=60, **COMMON)
+@settings(max_examples=60 * SCALE, **COMMON)
 @given(st.tuples(st.integers(3, 90), st.integers(3, 120)), pad, seed, st.integers(1, 40), st.sampled_from([0, 0, 1, 2, 3]),
        st.floats(-8.0, 8.0))
 def test_fuzz_sift_descriptors(shape, pad, seed, nkp, poison, log_scale):
@@ -232,7 +236,7 @@ def poison(a, seed, how):
     return a
 
 
-@settings(max_examples=120, **COMMON)
+@settings(max_examples=120 * SCALE, **COMMON)
 @given(st.tuples(st.integers(2, 80), st.integers(2, 150)), pad, seed, st.sampled_from([1, 2, 3]), st.sampled_from([3, 5, 7]),
        st.sampled_from([3, 5, 7, 9]), st.integers(0, 6), st.sampled_from([7, 15, 21, 9]))
 def test_fuzz_poisoned_images(shape, pad, seed, how, ksize, window, rad, win):
