@@ -1,8 +1,8 @@
 """Reader for the reference's run configurations (config/psN.yaml, read with yaml-cpp by each
 problem set's Config class: ps4_cpp/lib/Config.cpp:25-133, ps1_cpp/src/Config.cpp,
 ps2_cpp/lib/Config.cpp, ps5_cpp/lib/Config.cpp).  The files use a small YAML subset -- `---` / `...`
-markers, comments, `key: scalar` pairs and one level of nested maps by two-space indentation -- which
-is all this reader accepts (the C++ twin is shim/micv_config.hpp).  Scalars stay strings until asked
+markers, comments, `key: scalar` pairs, maps nested by indentation (three deep in config/ps7.yaml) and
+block sequences of scalars -- which is all this reader accepts (the C++ twin is shim/micv_config.hpp).  Scalars stay strings until asked
 for with a type, exactly as YAML::Node::as<T>() works."""
 
 
@@ -32,7 +32,8 @@ def _scalar(text):
 
 
 class Node(dict):
-    """A YAML map: values are strings (scalars) or Nodes (nested maps)."""
+    """A YAML map: values are strings (scalars), Nodes (nested maps, any depth) or lists of strings
+    (block sequences of scalars, e.g. the per-trial frame counts of config/ps7.yaml:7-40)."""
 
     def has(self, key):
         return key in self
@@ -43,12 +44,20 @@ class Node(dict):
             raise ConfigError(f"'{key}' is not a map")
         return v
 
+    def seq(self, key):
+        v = self.get(key)
+        if not isinstance(v, list):
+            raise ConfigError(f"'{key}' is not a sequence")
+        return v
+
     def _raw(self, key):
         if key not in self:
             raise ConfigError(f"key '{key}' not found")
         v = self[key]
         if isinstance(v, Node):
             raise ConfigError(f"'{key}' is a map, not a scalar")
+        if isinstance(v, list):
+            raise ConfigError(f"'{key}' is a sequence, not a scalar")
         return v
 
     def as_str(self, key):
@@ -77,43 +86,100 @@ class Node(dict):
         raise ConfigError(f"'{key}: {v}' is not a boolean")
 
 
+def _is_item(body):
+    return body == "-" or body.startswith("- ")
+
+
 def loads(text):
-    root = Node()
-    current, current_indent = None, 0
+    """Block maps nested to any depth by indentation and block sequences of scalars; a sequence may sit at
+    its parent key's own indentation, as YAML allows.  Flow collections, anchors, multi-line scalars and
+    sequences of maps are not part of the reference's files and are rejected."""
+    lines = []  # (lineno, indent, body)
     for lineno, raw in enumerate(text.splitlines(), 1):
         line = _strip_comment(raw)
         if not line.strip() or line.strip() in ("---", "..."):
             continue
         if "\t" in line[:len(line) - len(line.lstrip())]:
             raise ConfigError(f"line {lineno}: tabs are not allowed for indentation")
-        indent = len(line) - len(line.lstrip(" "))
-        body = line.strip()
-        if ":" not in body:
-            raise ConfigError(f"line {lineno}: expected 'key: value'")
-        key, _, value = body.partition(":")
-        if value and not value.startswith((" ", "\t")):
-            # a colon inside the key (e.g. a path) -- keys of the reference's files never contain one
-            raise ConfigError(f"line {lineno}: expected a space after ':'")
-        key = _scalar(key)
-        if indent == 0:
-            if value.strip() == "":
-                current = Node()
-                current_indent = None
-                root[key] = current
+        lines.append((lineno, len(line) - len(line.lstrip(" ")), line.strip()))
+    pos = 0
+
+    def parse_seq(indent):
+        nonlocal pos
+        out = []
+        while pos < len(lines) and lines[pos][1] == indent and _is_item(lines[pos][2]):
+            lineno, _, body = lines[pos]
+            item = body[1:].strip()
+            if item == "" or (":" in item and not (item[0] in "\"'")) and _split_key(item, lineno, probe=True):
+                raise ConfigError(f"line {lineno}: only sequences of scalars are supported")
+            out.append(_scalar(item))
+            pos += 1
+        if pos < len(lines) and lines[pos][1] > indent:
+            raise ConfigError(f"line {lines[pos][0]}: unexpected indentation inside a sequence")
+        return out
+
+    def parse_map(indent):
+        nonlocal pos
+        node = Node()
+        while pos < len(lines) and lines[pos][1] == indent:
+            lineno, _, body = lines[pos]
+            if _is_item(body):
+                raise ConfigError(f"line {lineno}: sequence entry inside a map")
+            key, value = _split_key(body, lineno)
+            pos += 1
+            if value != "":
+                node[key] = _scalar(value)
+                if pos < len(lines) and lines[pos][1] > indent:
+                    raise ConfigError(f"line {lines[pos][0]}: indented entry below the scalar '{key}'")
+                continue
+            if pos < len(lines) and lines[pos][1] > indent:
+                child_indent = lines[pos][1]
+                node[key] = parse_seq(child_indent) if _is_item(lines[pos][2]) else parse_map(child_indent)
+                if pos < len(lines) and lines[pos][1] > indent:
+                    raise ConfigError(f"line {lines[pos][0]}: inconsistent indentation below '{key}'")
+            elif pos < len(lines) and lines[pos][1] == indent and _is_item(lines[pos][2]):
+                node[key] = parse_seq(indent)
             else:
-                root[key] = _scalar(value)
-                current = None
-        else:
-            if current is None:
-                raise ConfigError(f"line {lineno}: indented entry without a parent map")
-            if current_indent is None:
-                current_indent = indent
-            if indent != current_indent:
-                raise ConfigError(f"line {lineno}: only one level of nesting is supported")
-            if value.strip() == "":
-                raise ConfigError(f"line {lineno}: nested maps below '{key}' are not supported")
-            current[key] = _scalar(value)
+                node[key] = Node()  # `key:` with nothing below it
+        return node
+
+    if lines and lines[0][1] != 0:
+        raise ConfigError(f"line {lines[0][0]}: indented entry without a parent map")
+    root = parse_map(0)
+    if pos < len(lines):
+        raise ConfigError(f"line {lines[pos][0]}: inconsistent indentation")
     return root
+
+
+def _split_key(body, lineno, probe=False):
+    if ":" not in body:
+        if probe:
+            return None
+        raise ConfigError(f"line {lineno}: expected 'key: value'")
+    key, _, value = body.partition(":")
+    if value and not value.startswith((" ", "\t")):
+        # a colon inside the key (e.g. a path) -- keys of the reference's files never contain one
+        if probe:
+            return None
+        raise ConfigError(f"line {lineno}: expected a space after ':'")
+    return _scalar(key), value.strip()
+
+
+def dumps(node, prefix=""):
+    """Every leaf as `path/to/key=value` (sequence entries `key[i]=value`), keys in byte order: the form
+    tests compare across the two readers (Node::dump in shim/micv_config.hpp)."""
+    out = []
+    for k in sorted(node, key=lambda s: s.encode()):
+        v = node[k]
+        if isinstance(v, Node):
+            if not v:
+                out.append(f"{prefix}{k}={{}}\n")
+            out.append(dumps(v, prefix + k + "/"))
+        elif isinstance(v, list):
+            out.extend(f"{prefix}{k}[{i}]={x}\n" for i, x in enumerate(v))
+        else:
+            out.append(f"{prefix}{k}={v}\n")
+    return "".join(out)
 
 
 def load(path):
@@ -151,3 +217,39 @@ def disparity_params(cfg, section):
     """Config::DisparitySSD / NCorr (ps2): window_radius, disparity_range."""
     n = cfg.child(section)
     return {k: n.as_int(k) for k in ("window_radius", "disparity_range")}
+
+
+def mhi_params(cfg, section):
+    """Config::MHI (ps7_cpp/lib/Config.cpp:35-47): diff_threshold, pre_blur_size (a square cv::Size),
+    pre_blur_sigma, tau; `last_frame` is in the file (config/ps7.yaml:47) but the reference never reads it."""
+    n = cfg.child(section)
+    return {"diff_threshold": n.as_float("diff_threshold"), "pre_blur_size": n.as_int("pre_blur_size"),
+            "pre_blur_sigma": n.as_float("pre_blur_sigma"), "tau": n.as_int("tau")}
+
+
+def last_frames(cfg):
+    """Config::loadActionLengths (ps7_cpp/lib/Config.cpp:49-66): a map of maps of maps of sequences ->
+    {"PS7A<action>P<person>T<trial>": last frame}, actions / persons / trials numbered from 1."""
+    actions = cfg.child("last_frame_of_action")
+    out = {}
+    for a in range(1, len(actions) + 1):
+        persons = actions.child(f"action{a}")
+        for p in range(1, len(persons) + 1):
+            for t, frames in enumerate(persons.seq(f"person{p}"), 1):
+                try:
+                    out[f"PS7A{a}P{p}T{t}"] = int(frames, 0)
+                except ValueError:
+                    raise ConfigError(f"action{a}/person{p}: '{frames}' is not an integer") from None
+    return out
+
+
+def lk_params(cfg):
+    """ps5's flat keys (ps5_cpp/lib/Config.cpp; config/ps5.yaml:11-17)."""
+    return {k: cfg.as_int(k) for k in ("lk_window_size_1", "lk_window_size_3", "pyr_level_3-a", "pyr_level_3-b",
+                                       "lk_window_size_4")}
+
+
+def hough_circle_params(cfg, section):
+    """Config::HoughCircle (ps1): min_radius, max_radius, num_peaks, threshold."""
+    n = cfg.child(section)
+    return {k: n.as_int(k) for k in ("min_radius", "max_radius", "num_peaks", "threshold")}

@@ -2,23 +2,25 @@
 // so a psN-style main() can be rebuilt without yaml-cpp (its submodule is empty in the reference
 // tree).  Same access pattern as the reference's Config classes use on YAML::Node
 // (ps4_cpp/lib/Config.cpp:25-133: config["harris_trans"], node["window_size"].as<size_t>() ...).
-// Accepts the YAML subset those files use: `---` / `...`, comments, `key: scalar`, one level of
-// nested maps by indentation.  The Python twin is introtocomputervision_amd/config.py.
+// Accepts the YAML subset those files use: `---` / `...`, comments, `key: scalar`, maps nested by
+// indentation to any depth, block sequences of scalars.  The Python twin is introtocomputervision_amd/config.py.
 #pragma once
 #include <cctype>
 #include <cstdlib>
 #include <fstream>
 #include <map>
 #include <memory>
+#include <ostream>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace micv_config {
 
 class Node {
 public:
-    bool has(const std::string &key) const { return scalars_.count(key) || maps_.count(key); }
+    bool has(const std::string &key) const { return scalars_.count(key) || maps_.count(key) || seqs_.count(key); }
     const Node &child(const std::string &key) const {
         auto it = maps_.find(key);
         if (it == maps_.end()) throw std::runtime_error("config: '" + key + "' is not a map");
@@ -39,47 +41,119 @@ public:
         ss << f.rdbuf();
         return parse(ss.str());
     }
+    // Block maps nested to any depth by indentation and block sequences of scalars (a sequence may sit at its
+    // parent key's own indentation, as YAML allows): config/ps7.yaml:7-40 is a map of maps of maps of
+    // sequences (ps7_cpp/lib/Config.cpp:49-66).  Flow collections, anchors, multi-line scalars and sequences
+    // of maps do not occur in the reference's files and are rejected.
     static Node parse(const std::string &text) {
-        Node root;
-        Node *current = nullptr;
-        int current_indent = -1, lineno = 0;
+        std::vector<Line> lines;
+        int lineno = 0;
         std::istringstream in(text);
         std::string raw;
         while (std::getline(in, raw)) {
             lineno++;
-            std::string line = strip_comment(raw);
+            const std::string line = strip_comment(raw);
             const size_t first = line.find_first_not_of(" ");
             if (first == std::string::npos) continue;
+            if (line[first] == '\t') fail(lineno, "tabs are not allowed for indentation");
             const std::string body = trim(line);
-            if (body == "---" || body == "...") continue;
-            const size_t colon = body.find(':');
-            if (colon == std::string::npos || (colon + 1 < body.size() && body[colon + 1] != ' ' && body[colon + 1] != '\t'))
-                throw std::runtime_error("config: line " + std::to_string(lineno) + ": expected 'key: value'");
-            const std::string key = unquote(trim(body.substr(0, colon)));
-            const std::string value = trim(body.substr(colon + 1));
-            if (first == 0) {
-                if (value.empty()) {
-                    root.maps_[key] = std::make_shared<Node>();
-                    current = root.maps_[key].get();
-                    current_indent = -1;
-                } else {
-                    root.scalars_[key] = unquote(value);
-                    current = nullptr;
-                }
-            } else {
-                if (!current) throw std::runtime_error("config: line " + std::to_string(lineno) + ": indented entry without a parent");
-                if (current_indent < 0) current_indent = (int)first;
-                if ((int)first != current_indent || value.empty())
-                    throw std::runtime_error("config: line " + std::to_string(lineno) + ": only one level of nesting is supported");
-                current->scalars_[key] = unquote(value);
-            }
+            if (body.empty() || body == "---" || body == "...") continue;
+            lines.push_back({lineno, (int)first, body});
         }
+        size_t pos = 0;
+        if (!lines.empty() && lines[0].indent != 0) fail(lines[0].no, "indented entry without a parent");
+        Node root;
+        parse_map(lines, pos, 0, root);
+        if (pos < lines.size()) fail(lines[pos].no, "inconsistent indentation");
         return root;
     }
+    const std::vector<std::string> &seq(const std::string &key) const {
+        auto it = seqs_.find(key);
+        if (it == seqs_.end()) throw std::runtime_error("config: '" + key + "' is not a sequence");
+        return it->second;
+    }
+    // every leaf as `path/to/key=value` (sequence entries as `key[i]=value`), one per line, keys in byte
+    // order: the form tests compare across the two readers (config.dumps() on the Python side)
+    void dump(std::ostream &os, const std::string &prefix = "") const {
+        std::map<std::string, int> keys;  // 0 scalar, 1 map, 2 sequence
+        for (auto &kv : scalars_) keys[kv.first] = 0;
+        for (auto &kv : maps_) keys[kv.first] = 1;
+        for (auto &kv : seqs_) keys[kv.first] = 2;
+        for (auto &kv : keys) {
+            if (kv.second == 0) os << prefix << kv.first << "=" << scalars_.at(kv.first) << "\n";
+            if (kv.second == 1) {
+                if (maps_.at(kv.first)->size() == 0) os << prefix << kv.first << "={}\n";
+                maps_.at(kv.first)->dump(os, prefix + kv.first + "/");
+            }
+            if (kv.second == 2) {
+                const auto &v = seqs_.at(kv.first);
+                for (size_t i = 0; i < v.size(); i++) os << prefix << kv.first << "[" << i << "]=" << v[i] << "\n";
+            }
+        }
+    }
+    // number of entries of this map (YAML::Node::size(), used by ps7's loadActionLengths)
+    size_t size() const { return scalars_.size() + maps_.size() + seqs_.size(); }
 
 private:
     std::map<std::string, std::string> scalars_;
     std::map<std::string, std::shared_ptr<Node>> maps_;
+    std::map<std::string, std::vector<std::string>> seqs_;
+    struct Line {
+        int no, indent;
+        std::string body;
+    };
+    [[noreturn]] static void fail(int lineno, const std::string &what) {
+        throw std::runtime_error("config: line " + std::to_string(lineno) + ": " + what);
+    }
+    static bool is_item(const std::string &body) { return body == "-" || body.compare(0, 2, "- ") == 0; }
+    // splits `key: value`; false when the text has no key separator
+    static bool split_key(const std::string &body, std::string *key, std::string *value) {
+        const size_t colon = body.find(':');
+        if (colon == std::string::npos || (colon + 1 < body.size() && body[colon + 1] != ' ' && body[colon + 1] != '\t'))
+            return false;
+        *key = unquote(trim(body.substr(0, colon)));
+        *value = trim(body.substr(colon + 1));
+        return true;
+    }
+    static void parse_seq(const std::vector<Line> &lines, size_t &pos, int indent, std::vector<std::string> *out) {
+        while (pos < lines.size() && lines[pos].indent == indent && is_item(lines[pos].body)) {
+            const std::string item = trim(lines[pos].body.substr(1));
+            std::string k, v;
+            if (item.empty() || (item[0] != '"' && item[0] != '\'' && split_key(item, &k, &v)))
+                fail(lines[pos].no, "only sequences of scalars are supported");
+            out->push_back(unquote(item));
+            pos++;
+        }
+        if (pos < lines.size() && lines[pos].indent > indent) fail(lines[pos].no, "unexpected indentation inside a sequence");
+    }
+    static void parse_map(const std::vector<Line> &lines, size_t &pos, int indent, Node &node) {
+        while (pos < lines.size() && lines[pos].indent == indent) {
+            const Line &ln = lines[pos];
+            if (is_item(ln.body)) fail(ln.no, "sequence entry inside a map");
+            std::string key, value;
+            if (!split_key(ln.body, &key, &value)) fail(ln.no, "expected 'key: value'");
+            pos++;
+            if (!value.empty()) {
+                node.scalars_[key] = unquote(value);
+                if (pos < lines.size() && lines[pos].indent > indent) fail(lines[pos].no, "indented entry below the scalar '" + key + "'");
+                continue;
+            }
+            if (pos < lines.size() && lines[pos].indent > indent) {
+                const int child = lines[pos].indent;
+                if (is_item(lines[pos].body)) {
+                    parse_seq(lines, pos, child, &node.seqs_[key]);
+                } else {
+                    node.maps_[key] = std::make_shared<Node>();
+                    parse_map(lines, pos, child, *node.maps_[key]);
+                }
+                if (pos < lines.size() && lines[pos].indent > indent) fail(lines[pos].no, "inconsistent indentation below '" + key + "'");
+            } else if (pos < lines.size() && lines[pos].indent == indent && is_item(lines[pos].body)) {
+                parse_seq(lines, pos, indent, &node.seqs_[key]);
+            } else {
+                node.maps_[key] = std::make_shared<Node>();  // `key:` with nothing below it
+            }
+        }
+    }
 
     static std::string trim(const std::string &s) {
         const size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r");
@@ -153,5 +227,35 @@ struct Harris {
           gaussian_sigma(n.as<double>("gaussian_sigma")), alpha(n.as<float>("alpha")),
           response_threshold(n.as<double>("response_threshold")), min_distance(n.as<int>("min_distance")) {}
 };
+
+// Config::MHI of ps7 (ps7_cpp/lib/Config.cpp:35-47); `last_frame` is in the file but never read there.
+struct MHI {
+    double diff_threshold = 0;
+    int pre_blur_size = 0;
+    double pre_blur_sigma = 0;
+    int tau = 0;
+    explicit MHI(const Node &n)
+        : diff_threshold(n.as<double>("diff_threshold")), pre_blur_size(n.as<int>("pre_blur_size")),
+          pre_blur_sigma(n.as<double>("pre_blur_sigma")), tau(n.as<int>("tau")) {}
+};
+
+// Config::loadActionLengths of ps7 (ps7_cpp/lib/Config.cpp:49-66): "PS7A<a>P<p>T<t>" -> last frame.
+inline std::map<std::string, int> last_frames(const Node &cfg) {
+    std::map<std::string, int> out;
+    const Node &actions = cfg.child("last_frame_of_action");
+    for (size_t a = 1; a <= actions.size(); a++) {
+        const Node &persons = actions.child("action" + std::to_string(a));
+        for (size_t p = 1; p <= persons.size(); p++) {
+            int trial = 1;
+            for (const std::string &v : persons.seq("person" + std::to_string(p))) {
+                char *end = nullptr;
+                const long n = std::strtol(v.c_str(), &end, 0);
+                if (end == v.c_str() || *end) throw std::runtime_error("config: '" + v + "' is not an integer");
+                out["PS7A" + std::to_string(a) + "P" + std::to_string(p) + "T" + std::to_string(trial++)] = (int)n;
+            }
+        }
+    }
+    return out;
+}
 
 }  // namespace micv_config

@@ -56,10 +56,95 @@ def test_typed_sections_and_errors():
         cfg.child("use_gpu")
     with pytest.raises(config.ConfigError):
         cfg.as_float("missing")
-    with pytest.raises(config.ConfigError):
-        config.loads("a:\n  b:\n    c: 1\n")
-    with pytest.raises(config.ConfigError):
-        config.loads("  orphan: 1\n")
+    assert config.loads("a:\n  b:\n    c: 1\n").child("a").child("b").as_int("c") == 1
+    assert config.loads("a:\n- 1\n- 2\nb: 3\n").seq("a") == ["1", "2"]  # a sequence at its key's own indentation
+    for bad in ("  orphan: 1\n", "a:\n  b: 1\n c: 2\n", "a: 1\n  b: 2\n", "a:\n  - x: 1\n", "a:\n  - 1\n    - 2\n",
+                "a:\n\tb: 1\n", "- 1\n", "a:\n  - 1\n  b: 2\n", "just text\n"):
+        with pytest.raises(config.ConfigError):
+            config.loads(bad)
+
+
+REF = os.path.join(CFG, "ref")  # byte copies of /root/reference/config/ps0..7.yaml (data files of the reference)
+REF_FILES = [f"ps{i}.yaml" for i in range(8)]
+
+
+def _same(mine, ref, path=""):
+    if isinstance(ref, dict):
+        assert isinstance(mine, config.Node) and set(mine) == {str(k) for k in ref}, path
+        for k, v in ref.items():
+            _same(mine[str(k)], v, f"{path}/{k}")
+    elif isinstance(ref, list):
+        assert isinstance(mine, list) and len(mine) == len(ref), path
+        for a, b in zip(mine, ref):
+            _same(a, b, path + "[]")
+    elif isinstance(ref, bool):
+        assert mine.lower() == str(ref).lower(), path
+    elif isinstance(ref, (int, float)):
+        assert float(mine) == float(ref), path
+    else:
+        assert mine == str(ref).strip(), path
+
+
+@pytest.mark.parametrize("name", REF_FILES)
+def test_reference_config_files_load_and_agree_with_pyyaml(name):
+    """Every run configuration the reference ships loads, and means what a full YAML parser says it means
+    (ps7.yaml nests lists under a three-level map, config/ps7.yaml:7-40)."""
+    yaml = pytest.importorskip("yaml")
+    path = os.path.join(REF, name)
+    _same(config.load(path), yaml.safe_load(open(path)))
+
+
+def test_reference_config_typed_sections():
+    """The typed views the reference's Config classes take of ps1 / ps2 / ps4 / ps5 / ps7, with the values
+    the files hold ("Config / flags")."""
+    c1 = config.load(os.path.join(REF, "ps1.yaml"))
+    assert config.edge_params(c1, "edge_detector_p2") == {"gaussian_size": 1, "gaussian_sigma": 0.0001, "lower_threshold": 1,
+                                                          "upper_threshold": 3, "sobel_aperture_size": 3}
+    assert config.edge_params(c1, "edge_detector_p6")["gaussian_size"] == 7
+    assert config.hough_params(c1, "hough_transform_p2") == {"rho_bin_size": 1, "theta_bin_size": 1, "num_peaks": 6, "threshold": 200}
+    assert config.hough_params(c1, "hough_transform_p6") == {"rho_bin_size": 2, "theta_bin_size": 3, "num_peaks": 10, "threshold": 80}
+    assert config.hough_circle_params(c1, "hough_circle_transform_p5") == {"min_radius": 20, "max_radius": 50, "num_peaks": 10, "threshold": 130}
+    assert c1.child("images").as_str("input0_noise") == "../Resources/ProblemSet1/ps1-input0-noise.png"
+    c2 = config.load(os.path.join(REF, "ps2.yaml"))
+    assert c2.as_bool("use_gpu_disparity") is True
+    assert config.disparity_params(c2, "problem_1_ssd") == {"window_radius": 6, "disparity_range": 3}
+    assert config.disparity_params(c2, "problem_2_ssd") == {"window_radius": 7, "disparity_range": 95}
+    assert config.disparity_params(c2, "problem_5_ncorr") == {"window_radius": 7, "disparity_range": 80}
+    c4 = config.load(os.path.join(REF, "ps4.yaml"))
+    for section in ("harris_trans", "harris_sim"):
+        assert config.harris_params(c4, section) == {"sobel_kernel_size": 3, "window_size": 5, "gaussian_sigma": 1.5, "alpha": 0.04,
+                                                     "response_threshold": 5e8, "min_distance": 5}
+    assert c4.as_bool("use_gpu") is True and len(c4.as_str("mersenne_seed").split()) == 16
+    assert c4.child("ransac_sim").as_float("consensus_ratio") == 0.6
+    c5 = config.load(os.path.join(REF, "ps5.yaml"))
+    assert config.lk_params(c5) == {"lk_window_size_1": 43, "lk_window_size_3": 7, "pyr_level_3-a": 1, "pyr_level_3-b": 2,
+                                    "lk_window_size_4": 15}
+    assert c5.child("image_sets").as_str("shift") == "../Resources/ProblemSet5/TestSeq"
+    c7 = config.load(os.path.join(REF, "ps7.yaml"))
+    frames = config.last_frames(c7)  # ps7_cpp/lib/Config.cpp:49-66
+    assert len(frames) == 27 and frames["PS7A1P1T1"] == 50 and frames["PS7A2P2T3"] == 23 and frames["PS7A3P3T3"] == 19
+    assert config.mhi_params(c7, "mhi_action1") == {"diff_threshold": 1.7, "pre_blur_size": 31, "pre_blur_sigma": 10.0, "tau": 25}
+    assert config.mhi_params(c7, "mhi_action3")["tau"] == 34
+
+
+def test_cpp_reader_agrees_on_the_reference_files(tmp_path):
+    """shim/micv_config.hpp (what a psN-style main() includes) reads the same leaves from the same files."""
+    exe = str(tmp_path / "config_dump")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", os.path.join(HERE, "cpp", "config_dump.cpp"), "-o", exe], check=True)
+    for path in [os.path.join(REF, n) for n in REF_FILES] + [os.path.join(CFG, "ps4.yaml"), os.path.join(CFG, "pipeline.yaml")]:
+        r = subprocess.run([exe, path], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == config.dumps(config.load(path)), path
+    r = subprocess.run([exe, "--ps7", os.path.join(REF, "ps7.yaml")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    frames = config.last_frames(config.load(os.path.join(REF, "ps7.yaml")))
+    assert lines[:-1] == [f"{k} {v}" for k, v in sorted(frames.items())] and lines[-1] == "mhi_action3 1.7 31 10 34"
+    for bad in ("  orphan: 1\n", "a:\n  b: 1\n c: 2\n", "a: 1\n  b: 2\n", "a:\n  - x: 1\n", "a:\n\tb: 1\n", "- 1\n"):
+        f = tmp_path / "bad.yaml"
+        f.write_text(bad)
+        r = subprocess.run([exe, str(f)], capture_output=True, text=True)
+        assert r.returncode == 1 and "config: line" in r.stderr, bad
 
 
 def build_ps4_demo(tmp):
