@@ -60,6 +60,18 @@ int orc_sobel(const float *src, int rows, int cols, size_t sstride, int ksize, f
 int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t stride,
                 int win, float *u, float *v, size_t ostride);
 
+/* Alternative accumulation orders of the five window sums, used ONLY to bound how far a real OpenCV 3.4.1
+ * run could be from the contract (tests/test_unpinned_bounds.py). */
+#define ORC_VAR_BLUR_CVCPU 1 /* OpenCV's CPU FilterEngine order: row left->right, column folded from the centre */
+#define ORC_VAR_BLUR_FUSED 2 /* ... with fused multiply-adds (an AVX2/FMA3 build) instead of mul + add */
+void orc_sep_filter_cvcpu(const float *src, int rows, int cols, size_t sstride,
+                          const float *krow, int nrow, const float *kcol, int ncol,
+                          float *dst, size_t dstride, int fused);
+int orc_lk_flow_ex(const float *prev, const float *next, int rows, int cols, size_t stride,
+                   int win, int variant, float *u, float *v, size_t ostride, double *det_out);
+int orc_lk_flow_pyr_ex(const float *prev, const float *next, int rows, int cols, size_t stride,
+                       int win, int levels, int variant, float *u, float *v, size_t ostride, double *det0_out);
+
 /* cvRound(float) of the reference's x86-64 OpenCV 3.4.1 build: round half to even into 32 bits,
  * INT_MIN ("integer indefinite") for NaN and for values that do not fit an int32. */
 int orc_cv_round(float v);
@@ -109,6 +121,17 @@ void orc_rgb8_to_gray_f32(const uint8_t *rgb, int rows, int cols, size_t sstride
  * (Harris.cu:36-43,76-91: fmaf chain in (wy,wx) raster order, all-float det/trace). */
 int orc_harris_response(const float *gx, const float *gy, int rows, int cols, size_t stride,
                         int win, double sigma, float alpha, float *resp, size_t rstride);
+
+/* The same with the arithmetic selected: ORC_HARRIS_GPU = the contract (harris::gpu, Harris.cu:36-43,85-91:
+ * fma.rn accumulation, float det - alpha tr^2, unfused); ORC_HARRIS_CPU = harris::cpu as written
+ * (Harris.cpp:78-92: unfused `secondMoment + weight * gradVals`, cv::determinant in double, the difference
+ * rounded to float once); ORC_HARRIS_GPU_FMAD = the GPU kernel's last three lines as nvcc's default
+ * contraction would compile them (a bounding variant, tests/test_unpinned_bounds.py). */
+#define ORC_HARRIS_GPU 0
+#define ORC_HARRIS_CPU 1
+#define ORC_HARRIS_GPU_FMAD 2
+int orc_harris_response_ex(const float *gx, const float *gy, int rows, int cols, size_t stride,
+                           int win, double sigma, float alpha, int mode, float *resp, size_t rstride);
 
 /* harris::{cpu,gpu}::refineCorners (Harris.cpp:99-147 / Harris.cu:173-329).  corners is
  * zero except at kept maxima; locs receives (y,x) pairs in row-major order.  Returns the

@@ -62,6 +62,42 @@ void orc_sep_filter(const float *src, int rows, int cols, size_t sstride,
     free(tmp);
 }
 
+/* ---- alternative accumulation orders, for BOUNDING the unpinned decisions (never the contract) ----
+ * cv::GaussianBlur on CV_32F (OpticalFlow.cpp:73-77) runs OpenCV 3.4.1's CPU FilterEngine
+ * (imgproc/src/filter.cpp): RowFilter<float,float,RowVec_32f> -- `s = kx[0]*S[0]; s += kx[k]*S[k]`,
+ * k ascending -- then SymmColumnFilter<Cast<float,float>,SymmColumnVec_32f> for the symmetric Gaussian
+ * taps -- `s = ky[c]*S[c]; s += ky[c+i]*(S[c+i] + S[c-i])`, i = 1..ksize/2, from the centre outwards.
+ * Whether its multiply-adds are fused depends on the build (the SSE2 baseline is not; the AVX2/FMA3
+ * dispatch of filter.avx2.cpp is): `fused` selects.  The contract (orc_sep_filter) is the left-to-right
+ * fmaf chain in BOTH passes; its row pass equals this row pass with fused = 1 bit for bit, the column
+ * pass differs in order either way.  Published algorithm restated; not verifiable here. */
+void orc_sep_filter_cvcpu(const float *src, int rows, int cols, size_t sstride,
+                          const float *krow, int nrow, const float *kcol, int ncol,
+                          float *dst, size_t dstride, int fused) {
+    float *tmp = (float *)malloc((size_t)rows * cols * sizeof(float));
+    int ar = nrow / 2, ac = ncol / 2;
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            float acc = krow[0] * AT(src, sstride, y, orc_reflect101(x - ar, cols));
+            for (int k = 1; k < nrow; k++) {
+                float s = AT(src, sstride, y, orc_reflect101(x + k - ar, cols));
+                acc = fused ? fmaf(s, krow[k], acc) : acc + krow[k] * s;
+            }
+            tmp[(size_t)y * cols + x] = acc;
+        }
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) {
+            float acc = kcol[ac] * tmp[(size_t)y * cols + x];
+            for (int i = 1; i <= ac; i++) {
+                float pair = tmp[(size_t)orc_reflect101(y + i, rows) * cols + x] +
+                             tmp[(size_t)orc_reflect101(y - i, rows) * cols + x];
+                acc = fused ? fmaf(pair, kcol[ac + i], acc) : acc + kcol[ac + i] * pair;
+            }
+            AT(dst, dstride, y, x) = acc;
+        }
+    free(tmp);
+}
+
 /* cv::getDerivKernels -> getSobelKernels (OpenCV 3.4.1 imgproc/src/deriv.cpp), integer taps. */
 static int sobel_kernel_1d(int ksize, int order, float *out) {
     int ker[40];
@@ -117,9 +153,12 @@ int orc_sobel(const float *src, int rows, int cols, size_t sstride, int ksize, f
     return 0;
 }
 
-/* lk::calcOpticalFlow, ps5_cpp/lib/OpticalFlow.cpp:41-104. */
-int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t stride,
-                int win, float *u, float *v, size_t ostride) {
+/* lk::calcOpticalFlow, ps5_cpp/lib/OpticalFlow.cpp:41-104.  variant 0 = the contract; ORC_VAR_BLUR_CVCPU
+ * (+ ORC_VAR_BLUR_FUSED) runs the five window sums in OpenCV's CPU filter order instead (above).  det_out
+ * (optional, rows x cols doubles, dense) receives det(A) of every pixel: the distance to the
+ * `det < 0.1` discontinuity (:82,95). */
+int orc_lk_flow_ex(const float *prev, const float *next, int rows, int cols, size_t stride,
+                   int win, int variant, float *u, float *v, size_t ostride, double *det_out) {
     if (win < 1 || (win & 1) == 0 || win > 255) return -1;
     size_t n = (size_t)rows * cols;
     float *buf = (float *)malloc(9 * n * sizeof(float));
@@ -148,7 +187,10 @@ int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t
     float *tmp = pIx; /* gradients are dead now */
     float *fields[5] = {Sxx, Sxy, Syy, Sxt, Syt};
     for (int f = 0; f < 5; f++) {
-        orc_sep_filter(fields[f], rows, cols, cols, g, win, g, win, tmp, cols);
+        if (variant & ORC_VAR_BLUR_CVCPU)
+            orc_sep_filter_cvcpu(fields[f], rows, cols, cols, g, win, g, win, tmp, cols, (variant & ORC_VAR_BLUR_FUSED) != 0);
+        else
+            orc_sep_filter(fields[f], rows, cols, cols, g, win, g, win, tmp, cols);
         memcpy(fields[f], tmp, n * sizeof(float));
     }
     const double tau = 0.1; /* :82 */
@@ -159,6 +201,7 @@ int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t
             float b0 = -Sxt[i], b1 = -Syt[i];
             /* cv::determinant, 2x2 CV_32F: det2() in double (OpenCV 3.4.1 core/src/lapack.cpp) */
             double det = (double)a00 * a11 - (double)a01 * a10;
+            if (det_out) det_out[i] = det;
             float uu = 0.f, vv = 0.f;
             if (!(det < tau)) {
                 /* cv::solve, DECOMP_LU, 2x2 CV_32F fast path (lapack.cpp) */
@@ -174,6 +217,11 @@ int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t
         }
     free(buf);
     return 0;
+}
+
+int orc_lk_flow(const float *prev, const float *next, int rows, int cols, size_t stride,
+                int win, float *u, float *v, size_t ostride) {
+    return orc_lk_flow_ex(prev, next, rows, cols, stride, win, 0, u, v, ostride, NULL);
 }
 
 static int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
@@ -300,6 +348,13 @@ void orc_pyr_up(const float *src, int rows, int cols, size_t sstride,
 /* lk::calcOpticalFlowPyr, OpticalFlow.cpp:122-167; `levels` replaces pyrDepth = 4 (:127). */
 int orc_lk_flow_pyr(const float *prev, const float *next, int rows, int cols, size_t stride,
                     int win, int levels, float *u, float *v, size_t ostride) {
+    return orc_lk_flow_pyr_ex(prev, next, rows, cols, stride, win, levels, 0, u, v, ostride, NULL);
+}
+
+/* The same with a `variant` of the window sums at every level (orc_lk_flow_ex); det0_out: det(A) of the
+ * finest level's solve. */
+int orc_lk_flow_pyr_ex(const float *prev, const float *next, int rows, int cols, size_t stride,
+                       int win, int levels, int variant, float *u, float *v, size_t ostride, double *det0_out) {
     if (levels < 1 || levels > 16) return -1;
     float *pp[16], *np[16];
     int pr[16], pc[16];
@@ -351,7 +406,7 @@ int orc_lk_flow_pyr(const float *prev, const float *next, int rows, int cols, si
         float *dx = (float *)malloc((size_t)R * C * sizeof(float));
         float *dy = (float *)malloc((size_t)R * C * sizeof(float));
         orc_lk_warp(np[k], du, dv, R, C, C, warped);               /* :155 */
-        rc = orc_lk_flow(pp[k], warped, R, C, C, win, dx, dy, C);  /* :159 */
+        rc = orc_lk_flow_ex(pp[k], warped, R, C, C, win, variant, dx, dy, C, k == 0 ? det0_out : NULL);  /* :159 */
         for (size_t i = 0; i < (size_t)R * C; i++) { du[i] = du[i] + dx[i]; dv[i] = dv[i] + dy[i]; } /* :161-162 */
         free(warped); free(dx); free(dy);
         if (rc) break;

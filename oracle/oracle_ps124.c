@@ -19,9 +19,10 @@ static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
  * coordinates, weights = outer product of getGaussianKernel(win, sigma, CV_32F) -- the float
  * product g[wy]*g[wx]), accumulation as harris::gpu (Harris.cu:36-43,85: M = fma(w, I, M) per
  * tap in (wy, wx) raster order; :87-91: trace, det, response in float, left to right). */
-int orc_harris_response(const float *gx, const float *gy, int rows, int cols, size_t stride,
-                        int win, double sigma, float alpha, float *resp, size_t rstride) {
+int orc_harris_response_ex(const float *gx, const float *gy, int rows, int cols, size_t stride,
+                           int win, double sigma, float alpha, int mode, float *resp, size_t rstride) {
     if (win < 1 || (win & 1) == 0 || win > 63 || !(sigma > 0)) return -1;
+    if (mode < 0 || mode > ORC_HARRIS_GPU_FMAD) return -1;
     float g[64];
     orc_gaussian_kernel(win, sigma, g);
     int r = win / 2;
@@ -33,15 +34,42 @@ int orc_harris_response(const float *gx, const float *gy, int rows, int cols, si
                     int yy = clampi(y + wy, 0, rows - 1), xx = clampi(x + wx, 0, cols - 1);
                     float ix = AT(gx, stride, yy, xx), iy = AT(gy, stride, yy, xx);
                     float w = g[wy + r] * g[wx + r]; /* gauss * gauss.t(), Harris.cpp:63 */
-                    mxx = fmaf(w, ix * ix, mxx);
-                    mxy = fmaf(w, ix * iy, mxy);
-                    myy = fmaf(w, iy * iy, myy);
+                    if (mode == ORC_HARRIS_CPU) {
+                        /* Harris.cpp:81-87: gradVals holds float products; `secondMoment + weight * gradVals`
+                         * is a MatExpr that cv::scaleAdd evaluates per element as a multiply then an add */
+                        mxx = mxx + w * (ix * ix);
+                        mxy = mxy + w * (ix * iy);
+                        myy = myy + w * (iy * iy);
+                    } else { /* Harris.cu:36-43,85: fma.rn.f32 weight, intensity, moment */
+                        mxx = fmaf(w, ix * ix, mxx);
+                        mxy = fmaf(w, ix * iy, mxy);
+                        myy = fmaf(w, iy * iy, myy);
+                    }
                 }
-            float trace = mxx + myy;
-            float det = mxx * myy - mxy * mxy;
-            AT(resp, rstride, y, x) = det - alpha * trace * trace;
+            float trace = mxx + myy; /* cv::trace sums in double and is stored to float: the same value */
+            float R;
+            if (mode == ORC_HARRIS_CPU) {
+                /* Harris.cpp:91-92: cv::determinant of a 2x2 CV_32F is det2 in double; `harrisScore * trace *
+                 * trace` is float arithmetic; the difference is taken in double and stored to float */
+                double det = (double)mxx * myy - (double)mxy * mxy;
+                R = (float)(det - (double)(alpha * trace * trace));
+            } else if (mode == ORC_HARRIS_GPU_FMAD) {
+                /* Harris.cu:89-91 as nvcc's default -fmad=true would contract it: a*b - c*d -> fma(a, b, -(c*d)),
+                 * det - (alpha*trace)*trace -> fma(-(alpha*trace), trace, det).  Bounding variant only. */
+                float det = fmaf(mxx, myy, -(mxy * mxy));
+                R = fmaf(-(alpha * trace), trace, det);
+            } else {
+                float det = mxx * myy - mxy * mxy;
+                R = det - alpha * trace * trace;
+            }
+            AT(resp, rstride, y, x) = R;
         }
     return 0;
+}
+
+int orc_harris_response(const float *gx, const float *gy, int rows, int cols, size_t stride,
+                        int win, double sigma, float alpha, float *resp, size_t rstride) {
+    return orc_harris_response_ex(gx, gy, rows, cols, stride, win, sigma, alpha, ORC_HARRIS_GPU, resp, rstride);
 }
 
 /* harris::refineCorners, Harris.cpp:115-143: R >= threshold (double compare) and strictly

@@ -173,6 +173,45 @@ def lk_flow_pyr(prev, nxt, win, levels):
     return u, v
 
 
+_sepcv = _sig("orc_sep_filter_cvcpu", None, [vp, i32, i32, sz, vp, i32, vp, i32, vp, sz, i32])
+_lkex = _sig("orc_lk_flow_ex", i32, [vp, vp, i32, i32, sz, i32, i32, vp, vp, sz, vp])
+_lkpex = _sig("orc_lk_flow_pyr_ex", i32, [vp, vp, i32, i32, sz, i32, i32, i32, vp, vp, sz, vp])
+VAR_BLUR_CVCPU, VAR_BLUR_FUSED = 1, 2          # oracle.h: bounding variants of the window sums
+HARRIS_GPU, HARRIS_CPU, HARRIS_GPU_FMAD = 0, 1, 2
+
+
+def sep_filter_cvcpu(src, krow, kcol, fused=False):
+    """OpenCV's CPU FilterEngine order (row left->right, column folded from the centre): a bounding variant."""
+    src = _f(src); krow = _f(krow); kcol = _f(kcol)
+    r, c = src.shape
+    out = np.empty_like(src)
+    _sepcv(_p(src), r, c, c, _p(krow), len(krow), _p(kcol), len(kcol), _p(out), c, int(bool(fused)))
+    return out
+
+
+def lk_flow_ex(prev, nxt, win, variant=0, want_det=False):
+    prev = _f(prev); nxt = _f(nxt)
+    r, c = prev.shape
+    u = np.empty_like(prev); v = np.empty_like(prev)
+    det = np.empty((r, c), np.float64) if want_det else None
+    rc = _lkex(_p(prev), _p(nxt), r, c, c, win, variant, _p(u), _p(v), c, _p(det) if want_det else None)
+    if rc:
+        raise ValueError(f"orc_lk_flow_ex rc={rc}")
+    return (u, v, det) if want_det else (u, v)
+
+
+def lk_flow_pyr_ex(prev, nxt, win, levels, variant=0, want_det=False):
+    prev = _f(prev); nxt = _f(nxt)
+    r, c = prev.shape
+    u = np.empty_like(prev); v = np.empty_like(prev)
+    det = np.empty((r, c), np.float64) if want_det else None
+    rc = _lkpex(_p(prev), _p(nxt), r, c, c, win, levels, variant, _p(u), _p(v), c, _p(det) if want_det else None)
+    if rc:
+        raise ValueError(f"orc_lk_flow_pyr_ex rc={rc}")
+    return (u, v, det) if want_det else (u, v)
+
+
+_hrespex = _sig("orc_harris_response_ex", i32, [vp, vp, i32, i32, sz, i32, f64, f32, i32, vp, sz])
 _hresp = _sig("orc_harris_response", i32, [vp, vp, i32, i32, sz, i32, f64, f32, vp, sz])
 _hrefine = _sig("orc_harris_refine", i64, [vp, i32, i32, sz, f64, i32, vp, sz, vp, i64])
 _sang = _sig("orc_sift_angles", None, [vp, vp, i32, i32, sz, vp, sz])
@@ -193,6 +232,17 @@ def harris_response(gx, gy, win, sigma, alpha):
     rc = _hresp(_p(gx), _p(gy), r, c, c, win, float(sigma), float(np.float32(alpha)), _p(out), c)
     if rc:
         raise ValueError(f"orc_harris_response rc={rc}")
+    return out
+
+
+def harris_response_ex(gx, gy, win, sigma, alpha, mode):
+    """mode: HARRIS_GPU (the contract), HARRIS_CPU (harris::cpu as written), HARRIS_GPU_FMAD (bounding variant)."""
+    gx = _f(gx); gy = _f(gy)
+    r, c = gx.shape
+    out = np.empty_like(gx)
+    rc = _hrespex(_p(gx), _p(gy), r, c, c, win, float(sigma), float(np.float32(alpha)), int(mode), _p(out), c)
+    if rc:
+        raise ValueError(f"orc_harris_response_ex rc={rc}")
     return out
 
 
