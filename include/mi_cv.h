@@ -266,6 +266,19 @@ int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, in
 int micv_harris_response_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
                               size_t gstride, int win, double sigma, float alpha, float *resp,
                               size_t rstride);
+/* The same with the arithmetic selected.  flags = 0: harris::gpu (Harris.cu:36-43,85-91: `fma.rn` accumulation in
+ * (wy, wx) raster order, float `det - alpha tr^2`) -- the default of both functions above, because the reference's
+ * configuration sets use_gpu: true (config/ps4.yaml:16).  MICV_HARRIS_CPU: harris::cpu::getCornerResponse as
+ * written (ps4_cpp/lib/Harris.cpp:78-92): `secondMoment + weight * gradVals` is a multiply then an add per element,
+ * cv::determinant is taken in double, `harrisScore * trace * trace` in float, and the difference is rounded to
+ * float once.  Same window, weights, clamping and raster order. */
+#define MICV_HARRIS_CPU 1
+int micv_harris_response_ex_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                                size_t gstride, int win, double sigma, float alpha, int flags, float *resp,
+                                size_t rstride, micv_stream stream);
+int micv_harris_response_ex_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                                 size_t gstride, int win, double sigma, float alpha, int flags, float *resp,
+                                 size_t rstride);
 /* harris::{cpu,gpu}::refineCorners, Harris.cpp:99-147 / Harris.cu:243-329 (a10).
  * corners: rows x cols f32, zero except kept maxima.  locs_yx: capacity `cap` (y,x) int32
  * pairs, filled in row-major order; *count receives the number found (may exceed cap).

@@ -100,6 +100,8 @@ SIGNATURES = {
     "micv_sobel_host": (i32, [vp, vp, i32, i32, sz, i32, f32, vp, vp, sz]),
     "micv_harris_response_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, vp, sz, vp]),
     "micv_harris_response_host": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, vp, sz]),
+    "micv_harris_response_ex_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, i32, vp, sz, vp]),
+    "micv_harris_response_ex_host": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, i32, vp, sz]),
     "micv_harris_refine_dev": (i32, [vp, vp, i32, i32, sz, f64, i32, vp, sz, vp, i64, vp, vp]),
     "micv_harris_refine_host": (i32, [vp, vp, i32, i32, sz, f64, i32, vp, sz, vp, i64, vp]),
     "micv_sift_angles_dev": (i32, [vp, vp, vp, i32, i32, sz, vp, sz, vp]),

@@ -9,6 +9,21 @@ namespace micv {
 // Tile 64x16 outputs; Ix, Iy staged in LDS with a clamped (2r)-halo (Harris.cpp:73-76 /
 // texture clamp on the CUDA path).  Accumulation exactly as Harris.cu:36-43,85: per tap
 // M = fma(w, I, M) in (wy, wx) raster order, w = g[wy]*g[wx] (float), then :87-91 in float.
+// R from the second-moment sums.  CPU = harris::cpu as written (Harris.cpp:91-92): cv::determinant of a 2x2 CV_32F
+// matrix is det2 in double, `harrisScore * trace * trace` float arithmetic, the difference taken in double and
+// stored to float (one rounding).  Otherwise harris::gpu (Harris.cu:87-91): float throughout, unfused.
+template <bool CPU>
+__device__ __forceinline__ float harris_r(float mxx, float mxy, float myy, float alpha) {
+    const float trace = mxx + myy;
+    if (CPU) {
+        const double det = (double)mxx * (double)myy - (double)mxy * (double)mxy;
+        return (float)(det - (double)(alpha * trace * trace));
+    }
+    const float det = mxx * myy - mxy * mxy;
+    return det - alpha * trace * trace;
+}
+
+template <bool CPU>
 __global__ __launch_bounds__(256) void harris_response_kernel(const float *__restrict__ gx,
                                                                const float *__restrict__ gy,
                                                                int gstride, int rows, int cols,
@@ -39,14 +54,18 @@ __global__ __launch_bounds__(256) void harris_response_kernel(const float *__res
             for (int wx = 0; wx <= 2 * r; wx++) {
                 const float ix = px[wx], iy = py[wx];
                 const float w = gw * g.k[wx];
-                mxx = fmaf(w, ix * ix, mxx);
-                mxy = fmaf(w, ix * iy, mxy);
-                myy = fmaf(w, iy * iy, myy);
+                if (CPU) {  // Harris.cpp:81-87: `secondMoment + weight * gradVals`, a multiply then an add
+                    mxx = mxx + w * (ix * ix);
+                    mxy = mxy + w * (ix * iy);
+                    myy = myy + w * (iy * iy);
+                } else {
+                    mxx = fmaf(w, ix * ix, mxx);
+                    mxy = fmaf(w, ix * iy, mxy);
+                    myy = fmaf(w, iy * iy, myy);
+                }
             }
         }
-        const float trace = mxx + myy;
-        const float det = mxx * myy - mxy * mxy;
-        resp[(size_t)y * rstride + x] = det - alpha * trace * trace;
+        resp[(size_t)y * rstride + x] = harris_r<CPU>(mxx, mxy, myy, alpha);
     }
 }
 
@@ -71,7 +90,7 @@ struct HarrisW {
 typedef float hv4f __attribute__((ext_vector_type(4)));
 typedef float hv2f __attribute__((ext_vector_type(2)));
 
-template <int R, int TH>
+template <int R, int TH, bool CPU = false>
 __global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
     const float *__restrict__ gx, const float *__restrict__ gy, int gstride, int rows, int cols,
     HarrisW<R> hw, float alpha, float *__restrict__ resp, int rstride, int vec_ok) {
@@ -153,7 +172,10 @@ __global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
                 for (int j = 0; j < 2; j++) {
                     const int cell = SH + 2 * j + wx;
                     const hv2f d = (cell & 1) ? O[cell >> 1] : E[cell >> 1];
-                    acc[f][j] = __builtin_elementwise_fma(w2, d, acc[f][j]);
+                    if (CPU)  // harris::cpu: the product rounded, then added (v_pk_mul_f32 + v_pk_add_f32; -ffp-contract=off)
+                        acc[f][j] = acc[f][j] + w2 * d;
+                    else
+                        acc[f][j] = __builtin_elementwise_fma(w2, d, acc[f][j]);
                 }
             }
         }
@@ -168,10 +190,7 @@ __global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
     float out[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const float mxx = acc[0][j >> 1][j & 1], mxy = acc[1][j >> 1][j & 1], myy = acc[2][j >> 1][j & 1];
-        const float trace = mxx + myy;
-        const float det = mxx * myy - mxy * mxy;
-        out[j] = det - alpha * trace * trace;
+        out[j] = harris_r<CPU>(acc[0][j >> 1][j & 1], acc[1][j >> 1][j & 1], acc[2][j >> 1][j & 1], alpha);
     }
     const int x = x0 + c0;
     if (vec_ok && x + 3 < cols) {
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
     }
 }
 
-template <int R>
+template <int R, bool CPU>
 static void launch_harris_tiled(hipStream_t s, const float *gx, const float *gy, int gstride, int rows,
                                 int cols, const Taps &g, float alpha, float *resp, int rstride) {
     HarrisW<R> hw;
@@ -193,10 +212,10 @@ static void launch_harris_tiled(hipStream_t s, const float *gx, const float *gy,
                        (gstride & 3) == 0 && (rstride & 3) == 0;
     // 64x32 tiles (512 threads) carry a sixth less halo per output; small images keep 64x16 for more blocks
     if ((size_t)cdiv(cols, 64) * cdiv(rows, 32) >= 1024)
-        harris_response_tiled_kernel<R, 32><<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 512, 0, s>>>(
+        harris_response_tiled_kernel<R, 32, CPU><<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 512, 0, s>>>(
             gx, gy, gstride, rows, cols, hw, alpha, resp, rstride, vec_ok);
     else
-        harris_response_tiled_kernel<R, 16><<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, 0, s>>>(
+        harris_response_tiled_kernel<R, 16, CPU><<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, 0, s>>>(
             gx, gy, gstride, rows, cols, hw, alpha, resp, rstride, vec_ok);
 }
 
@@ -416,9 +435,9 @@ using namespace micv;
 
 extern "C" {
 
-int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
-                             size_t gstride, int win, double sigma, float alpha, float *resp,
-                             size_t rstride, micv_stream stream) {
+int micv_harris_response_ex_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                                size_t gstride, int win, double sigma, float alpha, int flags, float *resp,
+                                size_t rstride, micv_stream stream) {
     MICV_REQUIRE(ctx && gx && gy && resp, "micv_harris_response: null argument");
     MICV_REQUIRE(rows > 0 && cols > 0, "micv_harris_response: bad size %dx%d", rows, cols);
     MICV_REQUIRE(win >= 1 && (win & 1) && win <= kMaxWin,
@@ -426,32 +445,45 @@ int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, in
     MICV_REQUIRE(sigma > 0, "micv_harris_response: sigma must be > 0");
     MICV_REQUIRE(stride_ok(gstride, cols, 4) && stride_ok(rstride, cols, 4),
                  "micv_harris_response: bad stride");
+    MICV_REQUIRE((flags & ~MICV_HARRIS_CPU) == 0, "micv_harris_response: unknown flags %#x", flags);
     MICV_HIP(hipSetDevice(ctx->device));
     Taps g;
     gaussian_taps(win, sigma, &g);  // cv::getGaussianKernel(win, sigma, CV_32F), Harris.cpp:61
     const int r = win / 2;
+    const bool cpu = (flags & MICV_HARRIS_CPU) != 0;
     const bool force_generic = ctx->opt[MICV_OPT_HARRIS_GENERIC] != 0;
     if (!force_generic && r >= 1 && r <= 3) {
         hipStream_t st = static_cast<hipStream_t>(stream);
         const int gs = (int)(gstride / 4), rs = (int)(rstride / 4);
-        if (r == 1) launch_harris_tiled<1>(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
-        if (r == 2) launch_harris_tiled<2>(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
-        if (r == 3) launch_harris_tiled<3>(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
+        if (r == 1) (cpu ? launch_harris_tiled<1, true> : launch_harris_tiled<1, false>)(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
+        if (r == 2) (cpu ? launch_harris_tiled<2, true> : launch_harris_tiled<2, false>)(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
+        if (r == 3) (cpu ? launch_harris_tiled<3, true> : launch_harris_tiled<3, false>)(st, gx, gy, gs, rows, cols, g, alpha, resp, rs);
         MICV_LAUNCH_CHECK();
         return MICV_OK;
     }
     const size_t lds = (size_t)(64 + 2 * r) * (16 + 2 * r) * 2 * sizeof(float);
     static thread_local int attr_dev = -1;
     if (attr_dev != ctx->device) {
-        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&harris_response_kernel),
+        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&harris_response_kernel<false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&harris_response_kernel<true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_dev = ctx->device;
     }
-    harris_response_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, lds,
-                             static_cast<hipStream_t>(stream)>>>(
-        gx, gy, (int)(gstride / 4), rows, cols, r, g, alpha, resp, (int)(rstride / 4));
+    const dim3 grid(cdiv(cols, 64), cdiv(rows, 16));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cpu)
+        harris_response_kernel<true><<<grid, 256, lds, st>>>(gx, gy, (int)(gstride / 4), rows, cols, r, g, alpha, resp, (int)(rstride / 4));
+    else
+        harris_response_kernel<false><<<grid, 256, lds, st>>>(gx, gy, (int)(gstride / 4), rows, cols, r, g, alpha, resp, (int)(rstride / 4));
     MICV_LAUNCH_CHECK();
     return MICV_OK;
+}
+
+int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                             size_t gstride, int win, double sigma, float alpha, float *resp,
+                             size_t rstride, micv_stream stream) {
+    return micv_harris_response_ex_dev(ctx, gx, gy, rows, cols, gstride, win, sigma, alpha, 0, resp, rstride, stream);
 }
 
 int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,

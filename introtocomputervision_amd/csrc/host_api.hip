@@ -311,9 +311,9 @@ int micv_sobel_host(micv_ctx *ctx, const float *src, int rows, int cols, size_t 
 // ---- ps4 / ps2 / ps1 host flavours -----------------------------------------------------------
 extern "C" {
 
-int micv_harris_response_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
-                              size_t gstride, int win, double sigma, float alpha, float *resp,
-                              size_t rstride) {
+int micv_harris_response_ex_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                                 size_t gstride, int win, double sigma, float alpha, int flags, float *resp,
+                                 size_t rstride) {
     HOST_PROLOGUE("micv_harris_response_host");
     MICV_REQUIRE(gx && gy && resp && rows > 0 && cols > 0, "micv_harris_response_host: bad argument");
     MICV_REQUIRE(stride_ok(gstride, cols, 4) && stride_ok(rstride, cols, 4),
@@ -323,11 +323,17 @@ int micv_harris_response_host(micv_ctx *ctx, const float *gx, const float *gy, i
     MICV_ALLOC_OK(dx); MICV_ALLOC_OK(dy); MICV_ALLOC_OK(dr);
     MICV_TRY(up2d(dx.p, gx, gstride, rb, rows, s));
     MICV_TRY(up2d(dy.p, gy, gstride, rb, rows, s));
-    MICV_TIMED("cornerResponseKernel", micv_harris_response_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb, win,
-                                      sigma, alpha, dr.as<float>(), rb, s));
+    MICV_TIMED("cornerResponseKernel", micv_harris_response_ex_dev(ctx, dx.as<float>(), dy.as<float>(), rows, cols, rb, win,
+                                      sigma, alpha, flags, dr.as<float>(), rb, s));
     MICV_TRY(down2d(resp, rstride, dr.p, rb, rows, s));
     MICV_HIP(hipStreamSynchronize(s));
     return MICV_OK;
+}
+
+int micv_harris_response_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
+                              size_t gstride, int win, double sigma, float alpha, float *resp,
+                              size_t rstride) {
+    return micv_harris_response_ex_host(ctx, gx, gy, rows, cols, gstride, win, sigma, alpha, 0, resp, rstride);
 }
 
 int micv_harris_refine_host(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,

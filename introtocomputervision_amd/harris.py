@@ -29,8 +29,13 @@ def getGradients(img, kernelSize=3, scale=1.0, ctx=None):
     return gx, gy
 
 
-def getCornerResponse(gradX, gradY, windowSize, gaussianSigma, harrisScore, ctx=None):
-    """harris::{cpu,gpu}::getCornerResponse (Harris.cpp:43-97 / Harris.cu:96-159) -> R."""
+HARRIS_CPU = 1  # mi_cv.h MICV_HARRIS_CPU
+
+
+def getCornerResponse(gradX, gradY, windowSize, gaussianSigma, harrisScore, ctx=None, cpu_arithmetic=False):
+    """harris::{cpu,gpu}::getCornerResponse (Harris.cpp:43-97 / Harris.cu:96-159) -> R.
+    cpu_arithmetic: harris::cpu's arithmetic as written (Harris.cpp:78-92; MICV_HARRIS_CPU) instead of
+    harris::gpu's (the default, as in the reference's configuration)."""
     B.check2d(gradX, np.float32, name="gradX")
     B.check2d(gradY, np.float32, name="gradY")
     if tuple(gradX.shape) != tuple(gradY.shape) or B.stride_bytes(gradX) != B.stride_bytes(gradY):
@@ -38,16 +43,17 @@ def getCornerResponse(gradX, gradY, windowSize, gaussianSigma, harrisScore, ctx=
     rows, cols = gradX.shape
     resp = B.empty_like_shape(gradX, (rows, cols))
     c = _ctx_for(gradX, ctx)
+    flags = HARRIS_CPU if cpu_arithmetic else 0
     if B.is_dev(gradX):
-        check(lib.micv_harris_response_dev(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
-                                           B.stride_bytes(gradX), int(windowSize),
-                                           float(gaussianSigma), float(harrisScore), B.ptr(resp),
-                                           B.stride_bytes(resp), B.stream_of(gradX)))
+        check(lib.micv_harris_response_ex_dev(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                              B.stride_bytes(gradX), int(windowSize),
+                                              float(gaussianSigma), float(harrisScore), flags, B.ptr(resp),
+                                              B.stride_bytes(resp), B.stream_of(gradX)))
     else:
-        check(lib.micv_harris_response_host(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
-                                            B.stride_bytes(gradX), int(windowSize),
-                                            float(gaussianSigma), float(harrisScore), B.ptr(resp),
-                                            B.stride_bytes(resp)))
+        check(lib.micv_harris_response_ex_host(c.handle, B.ptr(gradX), B.ptr(gradY), rows, cols,
+                                               B.stride_bytes(gradX), int(windowSize),
+                                               float(gaussianSigma), float(harrisScore), flags, B.ptr(resp),
+                                               B.stride_bytes(resp)))
     return resp
 
 

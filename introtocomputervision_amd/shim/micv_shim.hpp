@@ -220,17 +220,17 @@ inline void getGradients(const Mat &in, int kernelSize, Mat &diffX, Mat &diffY) 
 
 namespace detail {
 inline void response(const Mat &gradX, const Mat &gradY, const size_t windowSize,
-                     const double gaussianSigma, const float harrisScore, Mat &cornerResponse) {
+                     const double gaussianSigma, const float harrisScore, Mat &cornerResponse, int flags) {
     micv_shim::require(gradX.rows == gradY.rows && gradX.cols == gradY.cols &&
                            gradX.type() == micv_shim::F32 && gradY.type() == micv_shim::F32 &&
                            gradX.step == gradY.step,
                        "harris::getCornerResponse: gradient mismatch");  // Harris.cpp:49-50
     micv_shim::require(windowSize % 2 == 1, "harris::getCornerResponse: windowSize must be odd");
     Mat out(gradX.rows, gradX.cols, micv_shim::F32);
-    micv_shim::check(micv_harris_response_host(micv_shim::context(), gradX.ptr<float>(),
-                                               gradY.ptr<float>(), gradX.rows, gradX.cols, gradX.step,
-                                               static_cast<int>(windowSize), gaussianSigma,
-                                               harrisScore, out.ptr<float>(), out.step));
+    micv_shim::check(micv_harris_response_ex_host(micv_shim::context(), gradX.ptr<float>(),
+                                                  gradY.ptr<float>(), gradX.rows, gradX.cols, gradX.step,
+                                                  static_cast<int>(windowSize), gaussianSigma,
+                                                  harrisScore, flags, out.ptr<float>(), out.step));
     cornerResponse = out;
 }
 inline void refine(const Mat &cornerResponse, const double threshold, const int minDistance,
@@ -252,10 +252,16 @@ inline void refine(const Mat &cornerResponse, const double threshold, const int 
 }  // namespace detail
 
 namespace cpu {
+// harris::cpu's own arithmetic (Harris.cpp:78-92: unfused accumulation, double determinant, one rounding),
+// computed on the GPU: MICV_HARRIS_CPU.  -DMICV_SHIM_HARRIS_CPU_AS_GPU=1 routes it to harris::gpu's instead.
 inline void getCornerResponse(const Mat &gradX, const Mat &gradY, const size_t windowSize,
                               const double gaussianSigma, const float harrisScore,
                               Mat &cornerResponse) {
-    detail::response(gradX, gradY, windowSize, gaussianSigma, harrisScore, cornerResponse);
+#if defined(MICV_SHIM_HARRIS_CPU_AS_GPU) && MICV_SHIM_HARRIS_CPU_AS_GPU
+    detail::response(gradX, gradY, windowSize, gaussianSigma, harrisScore, cornerResponse, 0);
+#else
+    detail::response(gradX, gradY, windowSize, gaussianSigma, harrisScore, cornerResponse, MICV_HARRIS_CPU);
+#endif
 }
 inline void refineCorners(const Mat &cornerResponse, const double threshold, const int minDistance,
                           Mat &corners, std::vector<std::pair<int, int>> &cornerLocs) {
@@ -266,7 +272,7 @@ namespace gpu {
 inline void getCornerResponse(const Mat &gradX, const Mat &gradY, const size_t windowSize,
                               const double gaussianSigma, const float harrisScore,
                               Mat &cornerResponse) {
-    detail::response(gradX, gradY, windowSize, gaussianSigma, harrisScore, cornerResponse);
+    detail::response(gradX, gradY, windowSize, gaussianSigma, harrisScore, cornerResponse, 0);
 }
 inline void refineCorners(const Mat &cornerResponse, const double threshold, const int minDistance,
                           Mat &corners, std::vector<std::pair<int, int>> &cornerLocs) {

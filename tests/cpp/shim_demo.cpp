@@ -108,6 +108,16 @@ int main(int argc, char **argv) {
         std::vector<std::pair<int, int>> locs;
         harris::gpu::refineCorners(R, 5e8, 5, corners, locs);
         save(dir + "/harris_R.f32", R);
+        {   // use_gpu: false -> harris::cpu:: (Solution.cpp:92-124): its own arithmetic, its appending list
+            Mat Rc, cornersC;
+            harris::cpu::getCornerResponse(gx, gy, 5, 1.5, 0.04f, Rc);
+            std::vector<std::pair<int, int>> locsC = {{-1, -1}};
+            harris::cpu::refineCorners(Rc, 5e8, 5, cornersC, locsC);
+            save(dir + "/harris_cpu_R.f32", Rc);
+            std::vector<int> flatC;
+            for (auto &p : locsC) { flatC.push_back(p.first); flatC.push_back(p.second); }
+            save(dir + "/harris_cpu_locs.i32", flatC.data(), flatC.size() * 4);
+        }
         std::vector<int> flat;
         for (auto &p : locs) { flat.push_back(p.first); flat.push_back(p.second); }
         save(dir + "/harris_locs.i32", flat.data(), flat.size() * 4);

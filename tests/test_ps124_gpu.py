@@ -50,6 +50,50 @@ def test_harris_response(M, rows, cols, win, sigma):
     assert np.array_equal(harris.getCornerResponse(gx, gy, win, sigma, 0.04), exp)
 
 
+@pytest.mark.parametrize("rows,cols", [(480, 640), (61, 200), (17, 65), (130, 3)])
+@pytest.mark.parametrize("win,sigma", [(5, 1.5), (3, 1.0), (7, 2.0), (9, 2.0)])
+def test_harris_response_cpu_arithmetic(M, rows, cols, win, sigma):
+    """MICV_HARRIS_CPU: harris::cpu::getCornerResponse as written (Harris.cpp:78-92) -- unfused
+    `secondMoment + weight * gradVals`, cv::determinant in double, the difference rounded to float once --
+    bit-exact against the oracle's twin on the tiled kernels (windows 3 / 5 / 7), the generic one (9), the
+    device and the host entry point; it differs from the gpu:: arithmetic, and C1's corner list does not."""
+    harris, stereo, hough, synth = M
+    img = synth.checkerboard(rows, cols, square=40 if rows >= 400 else 12, seed=0x5EED0001)
+    img[rows // 2, cols // 2] += 3e4  # a large value: products near 1e18, where double and float determinants part
+    gx, gy = orc.sobel(img, 3, 1.0)
+    exp = orc.harris_response_ex(gx, gy, win, sigma, 0.04, orc.HARRIS_CPU)
+    got = harris.getCornerResponse(dev(gx), dev(gy), win, sigma, 0.04, cpu_arithmetic=True)
+    assert host(got).tobytes() == exp.tobytes()
+    assert harris.getCornerResponse(gx, gy, win, sigma, 0.04, cpu_arithmetic=True).tobytes() == exp.tobytes()
+    gpu = orc.harris_response(gx, gy, win, sigma, 0.04)
+    if rows * cols > 4000:
+        assert not np.array_equal(exp, gpu)
+    if (rows, cols, win) == (480, 640, 5):
+        img = synth.checkerboard(rows, cols, square=40, seed=0x5EED0001)
+        dgx, dgy = harris.getGradients(dev(img), 3)
+        Rc = harris.getCornerResponse(dgx, dgy, 5, 1.5, 0.04, cpu_arithmetic=True)
+        Rg = harris.getCornerResponse(dgx, dgy, 5, 1.5, 0.04)
+        _, lc = harris.refineCorners(Rc, 5e8, 5)
+        _, lg = harris.refineCorners(Rg, 5e8, 5)
+        assert len(lc) == 165 and np.array_equal(host(lc), host(lg))
+
+
+def test_harris_response_cpu_arithmetic_nonfinite_and_views(M):
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(11)
+    bx = (rng.standard_normal((75, 456)) * 300).astype(np.float32)
+    by = (rng.standard_normal((75, 456)) * 300).astype(np.float32)
+    bx[7, 130] = np.inf
+    by[40, 70] = np.nan
+    bx[50, 300] = 1e19  # squares overflow float, not double
+    for xoff, cols in ((0, 448), (1, 330), (4, 260)):
+        ex = orc.harris_response_ex(np.ascontiguousarray(bx[:, xoff:xoff + cols]), np.ascontiguousarray(by[:, xoff:xoff + cols]),
+                                    5, 1.5, 0.04, orc.HARRIS_CPU)
+        got = host(harris.getCornerResponse(dev(bx)[:, xoff:xoff + cols], dev(by)[:, xoff:xoff + cols], 5, 1.5, 0.04,
+                                            cpu_arithmetic=True))
+        assert got.tobytes() == ex.tobytes()
+
+
 def test_harris_pipeline_c1(M):
     """C1: 480x640 checkerboard with config/ps4.yaml parameters (sobel 3, window 5, sigma 1.5,
     alpha 0.04, threshold 5e8, minDistance 5): corner list identical to the oracle's, and it is

@@ -95,6 +95,10 @@ def test_shim_matches_oracle(tmp_path):
     assert np.array_equal(rd("harris_R.f32", np.float32, (rows, cols)), R)
     _, locs = orc.harris_refine(R, 5e8, 5)
     assert len(locs) > 5 and np.array_equal(rd("harris_locs.i32", np.int32).reshape(-1, 2), locs)
+    Rc = orc.harris_response_ex(gx, gy, 5, 1.5, 0.04, orc.HARRIS_CPU)  # harris::cpu:: keeps its own arithmetic
+    assert rd("harris_cpu_R.f32", np.float32, (rows, cols)).tobytes() == Rc.tobytes() and not np.array_equal(Rc, R)
+    _, locs_c = orc.harris_refine(Rc, 5e8, 5)
+    assert np.array_equal(rd("harris_cpu_locs.i32", np.int32).reshape(-1, 2), np.vstack([[[-1, -1]], locs_c]))  # appended (Harris.cpp:138)
     kp = rd("kps.f32", np.float32).reshape(-1, 4)
     ekp = orc.sift_keypoints(gx, gy, locs, 10)
     assert np.array_equal(kp[:, :3], ekp[:, :3]) and np.allclose(kp[:, 3], ekp[:, 3], atol=1e-3, rtol=0)
