@@ -105,6 +105,31 @@ def cpu_baseline(sample_pairs, hip_uv=None):
     return out, parity
 
 
+_PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER", "ROCTRACER", "ROCTX", "HSA_TOOLS", "RPDT_")
+
+
+def under_profiler():
+    """True when this process already runs under rocprofv3 / rocprof (its tool library is preloaded or its
+    environment is set): the live PMC pass must not start counter-collecting children from inside a traced
+    process -- tracing and --pmc may not be mixed on this pool, and the nested passes can wedge."""
+    if any(k.startswith(_PROFILER_ENV_PREFIXES) for k in os.environ):
+        return True
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+
+
+def scrubbed_env():
+    """The environment for a profiler child: nothing inherited from an enclosing profiler."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith(_PROFILER_ENV_PREFIXES)}
+    pre = [x for x in env.get("LD_PRELOAD", "").replace(":", " ").split() if "rocprof" not in x.lower()]
+    if pre:
+        env["LD_PRELOAD"] = ":".join(pre)
+    else:
+        env.pop("LD_PRELOAD", None)
+    env["TMPDIR"] = "/tmp"
+    env.pop("MICV_BENCH_FORCE_DIST", None)
+    return env
+
+
 def measure_traffic_live(pairs, extra_opts):
     """HBM traffic and VALU instructions of the level-0 launch, measured NOW: three child runs of this
     bench under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU in separate passes, no tracing
@@ -117,7 +142,7 @@ def measure_traffic_live(pairs, extra_opts):
     import glob
     import shutil
     import tempfile
-    if not shutil.which("rocprofv3"):
+    if not shutil.which("rocprofv3") or under_profiler():
         return None
     means = {}
     kernel = None
@@ -128,10 +153,8 @@ def measure_traffic_live(pairs, extra_opts):
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
                    "python3", os.path.abspath(__file__), "--cpu-pairs", "0", "--steps", "3", "--warmup", "1",
                    "--no-profile-pass", "--lk-groups", "1", "--inflight", "1", "--sustained-s", "0", "--preroll-s", "0",
-                   "--pairs", str(pairs), "--no-pmc"] + [x for o in extra_opts for x in ("--opt", o)]
-            env = dict(os.environ, TMPDIR="/tmp")
-            env.pop("MICV_BENCH_FORCE_DIST", None)
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                   "--pairs", str(pairs), "--no-pmc", "--no-secondary"] + [x for o in extra_opts for x in ("--opt", o)]
+            r = subprocess.run(cmd, cwd="/tmp", env=scrubbed_env(), capture_output=True, text=True, timeout=240)
             if r.returncode != 0:
                 return None
             per = {}
@@ -158,6 +181,147 @@ def measure_traffic_live(pairs, extra_opts):
                       "doubled per MI355X_MICROARCH.md section HBM"}
 
 
+def secondary_block(ctx, stream, torch, np):
+    """BASELINE.json's other single-GPU configs in the driver-run line: C3 (ps2 stereo SSD + NCC,
+    1080p, 11x11 window, 128 disparities; DisparitySSD.cu:143-207), C1 (ps4 Harris chain on 480x640 with the
+    parameters of the reference's own config/ps4.yaml; Harris.cu:96-159,243-329) and C5 (4K Harris -> ordered corner
+    list -> keypoints -> descriptors -> 5-level LK sampled at the corners).  Device-resident inputs, HIP-event time per
+    call; every entry carries an in-run bit-exact check of the SAME functions against the CPU oracle at a size the
+    oracle covers in about a second (the oracle is the checker here, never the thing timed)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    from introtocomputervision_amd import config, harris, lk, stereo, synth
+    from introtocomputervision_amd._capi import Timer
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def timeit(fn, iters=10, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t = Timer()
+        t.start(stream)
+        for _ in range(iters):
+            fn()
+        t.stop(stream)
+        return t.elapsed_ms() / iters
+
+    def wall(fn, iters=10, warm=2):  # chains with a host read-back inside (the corner count)
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / iters
+
+    out = {}
+    # ---- C3: stereo, 1080p, r = 5, d in [-127, 0] (128 candidates fit int8) ------------------------------
+    rows, cols, rad, nd = 1080, 1920, 5, 128
+    left, right, _ = synth.stereo_pair(0x5EED0002, rows, cols)
+    L, R = dev(left), dev(right)
+    sl, sr, _ = synth.stereo_pair(0x5EED0002, 160, 320)   # the check: same generator, 160x320, 48 disparities
+    SL, SR = dev(sl), dev(sr)
+    # box-filter form of the window sum: per pixel and disparity 1 subtract + 1 multiply + (2r+1) column adds
+    # + (2r+1) row adds + compare = 2 (2r+1) + 3 flop
+    flop_pd = 2 * (2 * rad + 1) + 3
+    for key, fn, ofn in (("C3_ssd", stereo.disparitySSD, orc.disparity_ssd), ("C3_ncc", stereo.disparityNCorr, orc.disparity_ncorr)):
+        ms = timeit(lambda: fn(L, R, rad, -(nd - 1), 0, ctx=ctx))
+        exp = ofn(sl, sr, rad, -47, 0)
+        got = fn(SL, SR, rad, -47, 0, ctx=ctx).cpu().numpy()
+        px = rows * cols
+        out[key] = {
+            "workload": f"{cols}x{rows} rectified synthetic pair, {2 * rad + 1}x{2 * rad + 1} window, {nd} disparities, device-resident",
+            "ms": ms, "Mpix_per_s": px / ms / 1e3, "Gpix_disp_per_s": px * nd / ms / 1e6,
+            "algorithmic_bytes_per_px": 9, "frac_of_hbm_peak": px * 9 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "valu_flop_per_px_disp": flop_pd if key == "C3_ssd" else None,
+            "frac_of_fp32_vector_peak": (px * nd * flop_pd / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS) if key == "C3_ssd" else None,
+            "bound": "valu",
+            "check": {"vs": "oracle, 320x160, 48 disparities, same window", "bit_exact": bool(np.array_equal(got, exp)),
+                      "mismatching_values": int(np.count_nonzero(got != exp))},
+        }
+    # ---- C1: ps4 Harris chain, 480x640, parameters from the reference's config/ps4.yaml ------------------
+    cfg = config.load(os.path.join(ROOT, "tests", "golden", "config", "ref", "ps4.yaml"))
+    hp = config.harris_params(cfg, "harris_trans")
+    img = synth.checkerboard(480, 640, square=40, seed=0x5EED0001)
+    dimg = dev(img)
+
+    def c1(cpu_arith=False):
+        gx, gy = harris.getGradients(dimg, hp["sobel_kernel_size"], ctx=ctx)
+        Rr = harris.getCornerResponse(gx, gy, hp["window_size"], hp["gaussian_sigma"], hp["alpha"], ctx=ctx, cpu_arithmetic=cpu_arith)
+        _, locs = harris.refineCorners(Rr, hp["response_threshold"], hp["min_distance"], ctx=ctx)
+        return Rr, locs
+    ms = wall(c1)
+    Rg, lg = c1()
+    Rc, lc = c1(True)
+    ogx, ogy = orc.sobel(img, hp["sobel_kernel_size"], 1.0)
+    eR = orc.harris_response(ogx, ogy, hp["window_size"], hp["gaussian_sigma"], hp["alpha"])
+    _, el = orc.harris_refine(eR, hp["response_threshold"], hp["min_distance"])
+    eRc = orc.harris_response_ex(ogx, ogy, hp["window_size"], hp["gaussian_sigma"], hp["alpha"], orc.HARRIS_CPU)
+    _, elc = orc.harris_refine(eRc, hp["response_threshold"], hp["min_distance"])
+    out["C1_harris"] = {
+        "workload": "640x480 greyscale checkerboard, config/ps4.yaml harris_trans (sobel 3, window 5, sigma 1.5, alpha 0.04, "
+                    "threshold 5e8, minDistance 5): getGradients -> getCornerResponse -> refineCorners, corner count read back",
+        "ms": ms, "Mpix_per_s": 480 * 640 / ms / 1e3, "corners": int(len(lg)),
+        "algorithmic_bytes_per_px": 32, "frac_of_hbm_peak": 480 * 640 * 32 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bound": "latency (three launches + one read-back on 0.3 Mpx)",
+        "reference_gtx1080_ms": {"cornerResponseKernel": 0.80, "refineCornersKernel": 0.59},
+        "check": {"vs": "oracle at full size, gpu:: and cpu:: arithmetic",
+                  "bit_exact": bool(np.array_equal(Rg.cpu().numpy(), eR) and np.array_equal(lg.cpu().numpy(), el)
+                                    and Rc.cpu().numpy().tobytes() == eRc.tobytes() and np.array_equal(lc.cpu().numpy(), elc))},
+    }
+    # ---- C5: 4K Harris + descriptors + LK refine ------------------------------------------------------------
+    def c5_frames(rows, cols):
+        tex = synth.smooth_noise(0x5EED0004, rows, cols)
+        chk = synth.checkerboard(rows, cols, square=40)
+        p = np.round(tex * (chk / 192.0)).astype(np.float32)
+        return p, np.ascontiguousarray(np.roll(p, shift=(-2, 3), axis=(0, 1)))
+
+    def c5(P, N):
+        gx, gy = harris.getGradients(P, 3, ctx=ctx)
+        Rr = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04, ctx=ctx)
+        _, locs = harris.refineCorners(Rr, 5e8, 5, capacity=1 << 20, ctx=ctx)
+        kp = harris.getKeypoints(gx, gy, locs, 10, ctx=ctx)
+        desc = harris.computeDescriptors(gx, gy, kp, ctx=ctx)
+        u_, v_ = lk.calcOpticalFlowPyr(P, N, WIN, LEVELS, ctx=ctx)
+        yy, xx = locs[:, 0].long(), locs[:, 1].long()
+        return locs, kp, desc, u_[yy, xx], v_[yy, xx]
+    p4, n4 = c5_frames(2160, 3840)
+    P4, N4 = dev(p4), dev(n4)
+    ms = wall(lambda: c5(P4, N4), iters=6)
+    n_corners = int(len(c5(P4, N4)[0]))
+    ps, ns = c5_frames(270, 480)
+    locs, kp, desc, fu, fv = c5(dev(ps), dev(ns))
+    ogx, ogy = orc.sobel(ps, 3, 1.0)
+    eR = orc.harris_response(ogx, ogy, 5, 1.5, 0.04)
+    _, el = orc.harris_refine(eR, 5e8, 5)
+    ekp = orc.sift_keypoints(ogx, ogy, el, 10)
+    edesc = orc.sift_descriptors(ogx, ogy, ekp)
+    eu, ev = orc.lk_flow_pyr(ps, ns, WIN, LEVELS if 270 >> (LEVELS - 1) >= 1 else 4)
+    same_list = np.array_equal(locs.cpu().numpy(), el)
+    kpn = kp.cpu().numpy()
+    ok = bool(same_list and np.array_equal(kpn[:, :3], ekp[:, :3]) and np.allclose(kpn[:, 3], ekp[:, 3], atol=1e-3, rtol=0)
+              and np.array_equal(fu.cpu().numpy(), eu[el[:, 0], el[:, 1]]) and np.array_equal(fv.cpu().numpy(), ev[el[:, 0], el[:, 1]]))
+    # descriptors depend on the keypoint angle (device atan2f vs libm, 1e-3 deg): compare on the oracle's keypoints
+    gdesc = harris.computeDescriptors(dev(ogx), dev(ogy), dev(ekp), ctx=ctx).cpu().numpy() if len(ekp) else edesc
+    ok = ok and bool(np.array_equal(gdesc, edesc))
+    px = 2160 * 3840
+    bpp = algorithmic_bytes_pair(2160, 3840, LEVELS) / px + 12 + 12 + 9   # LK + Sobel pair + response + NMS
+    out["C5_4k_chain"] = {
+        "workload": "3840x2160 textured checkerboard pair: Harris (sobel 3, window 5) -> ordered corner list -> keypoints -> "
+                    "4x4x8 descriptors -> 5-level LK (win 15) sampled at the corners; one corner-count read-back",
+        "ms": ms, "Mpix_per_s": px / ms / 1e3, "corners": n_corners,
+        "algorithmic_bytes_per_px": bpp, "frac_of_hbm_peak": px * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bound": "valu (LK level 0) + latency (list read-back, descriptors on a short list)",
+        "check": {"vs": "oracle on the same chain at 480x270 (corner list, keypoints, descriptors, flow at the corners)",
+                  "bit_exact": ok, "corners_checked": int(len(el))},
+    }
+    return out
+
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +341,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure roofline.traffic / roofline.valu live (three short rocprofv3 --pmc child "
                          "runs, ~25 s); fall back to the committed profiles/traffic.json")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (BASELINE configs C1 / C3 / C5 timed and checked in this run, ~3 s of GPU)")
     ap.add_argument("--preroll-s", type=float, default=0.25,
                     help="seconds of untimed steps before the warm-up steps (clock pre-roll; 0 = none)")
     ap.add_argument("--sustained-s", type=float, default=2.0,
@@ -545,6 +711,21 @@ def main(argv=None):
                     "concurrent launches)",
         }
 
+    # every lane (context / stream / output buffers) ran the same inputs: their last outputs must be the same bits
+    lanes_identical = None
+    if args.mode == "pairs" and max(1, args.inflight) > 1:
+        for c_, st_, out_ in lanes:
+            lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=c_, out=out_, stream=st_.cuda_stream)
+        torch.cuda.synchronize()
+        lanes_identical = all(bool(torch.equal(o[0], u)) and bool(torch.equal(o[1], v)) for _, _, o in lanes[1:])
+
+    secondary = None
+    if rank == 0 and n_gpus == 1 and args.mode == "pairs" and not args.no_secondary:
+        try:
+            secondary = secondary_block(ctx, stream, torch, np)
+        except Exception as e:  # the headline line must survive a failure here; the failure is reported, not hidden
+            secondary = {"error": f"{type(e).__name__}: {e}"}
+
     cpu, parity = None, None
     if rank == 0 and n_gpus == 1 and args.cpu_pairs > 0:
         def hip_uv(i):
@@ -580,6 +761,7 @@ def main(argv=None):
                 "flow_check": {"median_u": um, "median_v": vm, "ok": ok},
                 "parity_1080p": None if parity is None else parity["bit_exact"],
                 "parity_1080p_detail": parity,
+                "lanes_identical": lanes_identical,
                 "passes_in_flight": max(1, args.inflight) if args.mode == "pairs" else 1,
                 "preroll_s": args.preroll_s,
                 "one_pass_at_a_time_ms_per_step": serial_ms,
@@ -596,7 +778,12 @@ def main(argv=None):
                                          / (ROWS * COLS) / 1e9,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "secondary": secondary,
         }
+        if args.mode == "rowshard":
+            out["config"]["note"] = ("row-shard mode: every pair split by rows over the ranks (north_star's halo exchange); NOT the "
+                                     "SCALE axis -- it costs ~2.5x the GPU time of the unsharded batch and replicates the `next` "
+                                     "pyramid on every rank (DESIGN.md section 7), so strong-scaling efficiency is <= 0.4 by construction")
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -176,6 +176,8 @@ class Context:
 
     @property
     def handle(self):
+        if not self._h:
+            raise RuntimeError("micv Context used after close()")
         return self._h
 
     def scratch_bytes(self):

@@ -172,8 +172,14 @@ __global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit em
         const int64_t pos = excl + wcount[j * 4 + wave] + before[j];
         if (pos < cap) emit(pos, base + j * 256 + threadIdx.x);
     }
-    // the last chunk out leaves the state as it found it: all zero
-    if (threadIdx.x == 0) s_last = atomicAdd(&counters[1], 1u) == (unsigned)(nchunks - 1);
+    // the last chunk out leaves the state as it found it: all zero.  Thread 0 is the one that stored this chunk's
+    // status words (sc1 stores): it waits for their acknowledgement before it counts the chunk out, so no such
+    // store can still be on its way when the last chunk zeroes the words (a wait, not a fence -- an
+    // agent-scope release would write back the whole L2 once per chunk).
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(&counters[1], 1u) == (unsigned)(nchunks - 1);
+    }
     __syncthreads();
     if (s_last) {
         for (int i = threadIdx.x; i < nchunks; i += 256) status[i] = 0;

@@ -18,17 +18,25 @@ _DEFAULT_CTX_MAX = 8
 def default_context(device=0, stream=0):
     """One default context per (device, stream): a context owns ONE scratch arena and its auxiliary
     streams, so launches from two streams must not share it (they would race on the arena with no
-    error).  The cache holds the 8 most recently used pairs; an evicted context is destroyed (its arena,
-    streams and cached device blocks are freed), so a caller that runs under many short-lived torch
-    streams does not grow device memory without bound.  Long-running callers pass their own Context."""
+    error).  The cache holds the 8 most recently used pairs; beyond that the least recently used context
+    that NOBODY ELSE HOLDS is destroyed (its arena, streams and cached device blocks are freed), so a caller
+    that runs under many short-lived torch streams does not grow device memory without bound.  A context a
+    caller still references is never closed under it (the cache grows instead), and a closed Context raises
+    on use.  Long-running callers pass their own Context."""
+    import sys
     key = (int(device), int(stream or 0))
     ctx = _default_ctx.get(key)
     if ctx is None:
         ctx = Context(device)
         _default_ctx[key] = ctx
-        while len(_default_ctx) > _DEFAULT_CTX_MAX:
-            _, old = _default_ctx.popitem(last=False)
-            old.close()  # micv_ctx_destroy synchronises the device before freeing what launches may still use
+        if len(_default_ctx) > _DEFAULT_CTX_MAX:
+            for k in list(_default_ctx)[:-1]:  # oldest first, never the one just made
+                old = _default_ctx[k]
+                if sys.getrefcount(old) <= 3:  # the cache, `old`, getrefcount's argument: no outside holder
+                    del _default_ctx[k]
+                    old.close()  # micv_ctx_destroy synchronises the device before freeing what launches may still use
+                    if len(_default_ctx) <= _DEFAULT_CTX_MAX:
+                        break
     else:
         _default_ctx.move_to_end(key)
     return ctx

@@ -346,13 +346,7 @@ class RowShardBatch:
         exchange is torch work -- slab copies and the RCCL point-to-point ops order themselves against
         torch's CURRENT stream -- so it is issued with `stream` made current: launches and exchange are
         then one in-order sequence whatever stream the caller passed (r02 raced when they differed)."""
-        import contextlib
-
-        import torch
-        cur = torch.cuda.current_stream(prev.device)
-        s = stream if stream is not None else cur.cuda_stream
-        same = int(s or 0) == int(cur.cuda_stream or 0)
-        on_s = contextlib.nullcontext() if same else torch.cuda.stream(torch.cuda.ExternalStream(int(s), device=prev.device))
+        s, on_s = _launch_stream(stream, prev.device)
         self.build_pyramids(prev, nxt, s)
         for l in range(self.levels - 1, -1, -1):
             if l < self.levels - 1:
@@ -374,9 +368,15 @@ class RowShardBatch:
                                             fr, fc, fc * 4, r0, r1, float(self.level_margin[l]) / 2.0,
                                             self.flag.data_ptr(), stream))
 
-    def violated(self):
-        """True when the last run() met a vertical flow beyond the declared margin (host synchronisation)."""
-        return self.flag is not None and bool(self.flag.item())
+    def violated(self, stream=None):
+        """True when the last run() met a vertical flow beyond the declared margin (host synchronisation).
+        `stream`: the stream that run() was given -- the flag is written by a kernel on it, so it is read with
+        that stream current (a read on another, non-blocking stream could come before the level kernels finish)."""
+        if self.flag is None:
+            return False
+        _, on_s = _launch_stream(stream, self.flag.device)
+        with on_s:
+            return bool(self.flag.item())
 
     def run_checked(self, prev, nxt, u, v, stream=None):
         """run() with the declared margin; when the bound check fires, the same step again on the whole
@@ -385,15 +385,22 @@ class RowShardBatch:
         if self.next_rows is None:
             self.run(prev, nxt, u, v, stream)
             return True
-        self.flag.zero_()
+        # The flag is zeroed, written (micv_flow_bound_check_dev on the launch stream), reduced and read in ONE
+        # in-order sequence: all of it is issued with the launch stream current (on torch's current
+        # stream the zero could land after a check and .item() could read before the level kernels had run).
+        _, on_s = _launch_stream(stream, prev.device)
+        with on_s:
+            self.flag.zero_()
         self.full_next = False
         self.run(prev, nxt, u, v, stream)
-        flag = self.flag
-        dist = getattr(self.comm, "dist", None)
-        if dist is not None and self.world > 1:
-            flag = self.flag.clone()
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if not bool(flag.item()):
+        with on_s:
+            flag = self.flag
+            dist = getattr(self.comm, "dist", None)
+            if dist is not None and self.world > 1:
+                flag = self.flag.clone()
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            ok = not bool(flag.item())
+        if ok:
             return True
         self.full_next = True  # fall back: the whole `next` pyramid, no bound to check
         try:
@@ -403,13 +410,25 @@ class RowShardBatch:
         return False
 
 
+def _launch_stream(stream, device):
+    """(raw HIP stream handle, context manager that makes it torch's current stream).  Kernels of the C ABI go
+    to the raw handle; torch work that must stay ordered with them (slab copies, collectives, flag reads) is
+    issued inside the context."""
+    import contextlib
+
+    import torch
+    cur = torch.cuda.current_stream(device)
+    s = stream if stream is not None else cur.cuda_stream
+    same = int(s or 0) == int(cur.cuda_stream or 0)
+    return s, (contextlib.nullcontext() if same else torch.cuda.stream(torch.cuda.ExternalStream(int(s), device=device)))
+
+
 def run_virtual_batch(runners, prev, nxt, u, v, stream=None, poison=None, shared_pyramids=True):
     """All ranks of a row-sharded batch on ONE device ("virtual shards"): the same
     band launches and the same transfer list as the distributed run, the exchange done by row copies
     between the ranks' private flow buffers.  The pyramids are built once and shared (the virtual
     ranks share the device's memory) unless shared_pyramids=False; `poison` overwrites rows a rank does not own after every level."""
-    import torch
-    s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+    s, on_s = _launch_stream(stream, prev.device)
     r0 = runners[0]
     if shared_pyramids:
         r0.build_pyramids(prev, nxt, s, restrict=False)
@@ -418,16 +437,17 @@ def run_virtual_batch(runners, prev, nxt, u, v, stream=None, poison=None, shared
     else:  # as distributed ranks do: every rank builds the rows its band touches, into its own buffers
         for r in runners:
             r.build_pyramids(prev, nxt, s, restrict=True)
-    for l in range(r0.levels - 1, -1, -1):
-        if l < r0.levels - 1:
-            for src, dst, a, b in r0.plan.transfers(l + 1):
-                runners[dst].flow[l + 1][:, :, a:b].copy_(runners[src].flow[l + 1][:, :, a:b])
-        for r in runners:
-            r.level(l, prev, nxt, u, v, s)
-            if poison is not None and l > 0:
-                a, b = r.plan.band(l, r.rank)
-                r.flow[l][:, :, :a] = poison
-                r.flow[l][:, :, b:] = poison
+    with on_s:  # the row copies and poison fills are torch work: same stream as the launches
+        for l in range(r0.levels - 1, -1, -1):
+            if l < r0.levels - 1:
+                for src, dst, a, b in r0.plan.transfers(l + 1):
+                    runners[dst].flow[l + 1][:, :, a:b].copy_(runners[src].flow[l + 1][:, :, a:b])
+            for r in runners:
+                r.level(l, prev, nxt, u, v, s)
+                if poison is not None and l > 0:
+                    a, b = r.plan.band(l, r.rank)
+                    r.flow[l][:, :, :a] = poison
+                    r.flow[l][:, :, b:] = poison
 
 
 def run_virtual_batch_checked(runners, prev, nxt, u, v, stream=None, poison=None):
@@ -435,11 +455,14 @@ def run_virtual_batch_checked(runners, prev, nxt, u, v, stream=None, poison=None
     (runners built with next_margin=...), the bound checks run per rank and level, and when any rank's flag
     is raised ALL ranks repeat the step on the whole frame -- the decision a distributed run takes after
     OR-reducing the flags.  Returns True when the margin sufficed."""
-    import torch
-    s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+    s, on_s = _launch_stream(stream, prev.device)
     r0 = runners[0]
 
     def one_pass(full):
+        with on_s:  # flag fills, row copies, poison fills and the flag read: one in-order sequence with the launches
+            return _one_pass(full)
+
+    def _one_pass(full):
         for r in runners:
             r.full_next = full
             if r.flag is not None:
@@ -458,7 +481,7 @@ def run_virtual_batch_checked(runners, prev, nxt, u, v, stream=None, poison=None
                     a, b = r.plan.band(l, r.rank)
                     r.flow[l][:, :, :a] = poison
                     r.flow[l][:, :, b:] = poison
-        return any(r.violated() for r in runners) if not full else False
+        return any(r.violated(s) for r in runners) if not full else False
 
     try:
         if not one_pass(False):

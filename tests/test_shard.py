@@ -261,3 +261,57 @@ def test_declared_next_margin_with_fallback(kind, margin, expect_ok):
     assert torch.equal(u, gu) and torch.equal(v, gv)
     if expect_ok:  # the cheap path really skipped rows: some level's `next` buffer still holds NaN rows
         assert any(bool(torch.isnan(t).any()) for t in runners[1].npyr[1:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,margin,expect_ok", [("textured", 64, True), ("smooth", 24, False)])
+def test_declared_margin_on_a_side_stream(kind, margin, expect_ok):
+    """run_checked / run_virtual_batch_checked given a NON-current, non-blocking stream.  The flag fill,
+    the bound checks, the row copies and the flag read must all follow the launch stream; a busy kernel queued on that
+    stream first makes any work left on torch's current stream overtake it (stale flag -> missed violation, or rows
+    copied before they were computed)."""
+    import torch
+    from introtocomputervision_amd import lk
+    from introtocomputervision_amd._capi import Context
+    rows, cols, levels, world, batch = 540, 960, 5, 4, 2
+    ctx = Context(0)
+    if kind == "textured":
+        rng = np.random.default_rng(3)
+        pairs = []
+        for i in range(batch):
+            big = (rng.random((rows + 8, cols + 8)) * 255).astype(np.float32)
+            k = np.array([1, 2, 1], np.float32) / 4
+            big = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 0, big)
+            big = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 1, big).astype(np.float32)
+            pairs.append((np.ascontiguousarray(big[4:4 + rows, 4:4 + cols]), np.ascontiguousarray(big[2:2 + rows, 7:7 + cols])))
+    else:
+        pairs = [synth.lk_pair(0x5EED0005 + i, rows, cols, 3, -2) for i in range(batch)]
+    prev = torch.from_numpy(np.stack([p for p, _ in pairs])).cuda()
+    nxt = torch.from_numpy(np.stack([n for _, n in pairs])).cuda()
+    gu, gv = lk.calcOpticalFlowPyrBatch(prev, nxt, 15, levels, ctx=ctx)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()  # non-blocking with respect to the null stream, and not current
+    runners = [shard.RowShardBatch(ctx, rows, cols, levels, 15, batch, g, world, next_margin=margin) for g in range(world)]
+    busy = torch.empty(1 << 26, device="cuda")
+    for rep in range(3):
+        u = torch.full_like(prev, float("nan"))
+        v = torch.full_like(prev, float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):  # ~ms of work ahead of the step on the side stream
+            for _ in range(20):
+                busy.mul_(1.0001)
+        ok = shard.run_virtual_batch_checked(runners, prev, nxt, u, v, stream=side.cuda_stream, poison=float("nan"))
+        side.synchronize()
+        assert ok == expect_ok
+        assert torch.equal(u, gu) and torch.equal(v, gv)
+    # the single-rank distributed form takes the same path (no process group: the exchange list is empty)
+    r1 = shard.RowShardBatch(ctx, rows, cols, levels, 15, batch, 0, 1, next_margin=margin)
+    u = torch.full_like(prev, float("nan"))
+    v = torch.full_like(prev, float("nan"))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            busy.mul_(1.0001)
+    r1.run_checked(prev, nxt, u, v, side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(u, gu) and torch.equal(v, gv)

@@ -16,10 +16,10 @@ for stop in 0 2 3 41 42 43 4 -1; do
   export MICV_LK_STOP=$stop
   rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS \
       --output-format csv -d "$out/pmc_$stop" -- \
-      python3 "$repo/bench.py" --cpu-pairs 0 --steps 2 --warmup 1 --no-profile-pass --inflight 1 --lk-groups 1 --sustained-s 0 > "$out/bench_pmc_$stop.log" 2>&1
+      python3 "$repo/bench.py" --cpu-pairs 0 --no-pmc --no-secondary --steps 2 --warmup 1 --no-profile-pass --inflight 1 --lk-groups 1 --sustained-s 0 > "$out/bench_pmc_$stop.log" 2>&1
   echo "stop=$stop pmc rc=$?"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$stop" -- \
-      python3 "$repo/bench.py" --cpu-pairs 0 --steps 10 --warmup 3 --no-profile-pass --inflight 1 --lk-groups 1 --sustained-s 0 > "$out/bench_trace_$stop.log" 2>&1
+      python3 "$repo/bench.py" --cpu-pairs 0 --no-pmc --no-secondary --steps 10 --warmup 3 --no-profile-pass --inflight 1 --lk-groups 1 --sustained-s 0 > "$out/bench_trace_$stop.log" 2>&1
   echo "stop=$stop trace rc=$?"
 done
 python3 "$repo/tools/phase_pmc_summary.py" "$out" | tee "$out/summary.txt"

@@ -9,7 +9,7 @@ i=0
 for flags in "$@"; do
   i=$((i+1)); out="$repo/gpurun_out/pmcc_$i"; rm -rf "$out"
   rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d "$out" -- \
-      python3 "$repo/bench.py" --cpu-pairs 0 --steps 3 --warmup 1 --no-profile-pass --inflight 1 --lk-groups 1 --sustained-s 0 --preroll-s 0 $flags > /dev/null 2>&1
+      python3 "$repo/bench.py" --cpu-pairs 0 --no-pmc --no-secondary --steps 3 --warmup 1 --no-profile-pass --inflight 1 --lk-groups 1 --sustained-s 0 --preroll-s 0 $flags > /dev/null 2>&1
   python3 - "$out" "$flags" <<'PY' | tee -a "$outfile"
 import csv, glob, sys, collections, json
 d = collections.defaultdict(lambda: collections.defaultdict(list))

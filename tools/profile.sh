@@ -8,7 +8,8 @@ repo="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 out="$repo/gpurun_out/prof_$tag"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-BENCH=(python3 "$repo/bench.py" --cpu-pairs 0)
+# --no-pmc --no-secondary: no nested rocprofv3 children and no extra kernels inside a profiled run
+BENCH=(python3 "$repo/bench.py" --cpu-pairs 0 --no-pmc --no-secondary)
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- \
     "${BENCH[@]}" --steps 20 --warmup 5 --sustained-s 0 > "$out/bench_trace.log" 2>&1
