@@ -40,6 +40,7 @@ extern "C" {
 
 typedef struct micv_ctx micv_ctx;
 typedef void *micv_stream; /* hipStream_t */
+typedef struct micv_comm micv_comm; /* a communicator over RCCL (multi-GPU entry points, below) */
 
 const char *micv_version(void);
 const char *micv_last_error(void);
@@ -63,7 +64,8 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 #define MICV_OPT_LK_STREAM         10 /* level kernel as a persistent grid that stages the next tile ahead: 1 = on, 0 = off (default; measured slower) */
 #define MICV_OPT_LK_TALL_TILES     11 /* 1024-thread tiles, one workgroup per CU, for big launches: window 15 on 64x64 tiles only with 1 (measured slower); window 21 on 64x32 tiles by default (0 or 1; measured faster); -1 = never */
 #define MICV_OPT_COMPACT_3PASS     12 /* ordered lists (corners, edge points, peak candidates, matches): 0 = one-launch chained scan up to 1 M elements, count / scan / emit launches beyond; 1 = always three launches; -1 = always one */
-#define MICV_OPT_COUNT            13
+#define MICV_OPT_LK_DIRECT_LEVELS  13 /* fused LK: pyramid levels >= n read straight from level 0 with a pixel stride (n = 1: no pyramid-build launch): 0 = off (default: measured faster one pass at a time, slower with two passes in flight), n = 1..15 */
+#define MICV_OPT_COUNT            14
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
 int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value);
 
@@ -149,6 +151,47 @@ int micv_lk_flow_pyr_batch_dev(micv_ctx *ctx, const float *prev, const float *ne
 int micv_flow_bound_check_dev(micv_ctx *ctx, const float *v, int batch, size_t pair_stride, int rows, int cols,
                               size_t stride, int row_begin, int row_end, float bound, uint32_t *flag,
                               micv_stream stream);
+
+/* ------------------------------------------------- multi-GPU: one process per GPU, RCCL -------- */
+/* SURVEY.md section 8e.  The reference has no multi-GPU code; its caller (`denseLKWrapper`,
+ * ps5_cpp/src/Solution.cpp:60-64) is what these entry points let shard: every rank (one process per GPU) holds the
+ * whole frames and computes a band of rows; the only dynamic exchange is the coarse-flow halo per pyramid level --
+ * (win/2 + 2)/2 + 3 rows per neighbour -- sent point to point (ncclSend / ncclRecv in one group, on the launch
+ * stream).  RCCL is loaded at run time (dlopen "librccl.so.1": libmicv.so itself links only libamdhip64, and a
+ * process that already holds an RCCL shares it); without it these calls return MICV_EUNSUPPORTED.
+ *
+ * A communicator wraps an existing ncclComm_t (borrowed, e.g. the application's own) or is created from an RCCL
+ * unique id: rank 0 calls micv_comm_unique_id, ships the MICV_COMM_ID_BYTES bytes to the other ranks by any means
+ * (MPI, a file, torch.distributed), every rank calls micv_comm_create(ctx, NULL, id, rank, world, &comm) -- a
+ * collective call, like ncclCommInitRank. */
+#define MICV_COMM_ID_BYTES 128
+int micv_comm_unique_id(void *id128);
+int micv_comm_create(micv_ctx *ctx, void *nccl_comm, const void *unique_id128, int rank, int world, micv_comm **out);
+int micv_comm_destroy(micv_comm *comm);
+int micv_comm_rank(const micv_comm *comm, int *rank, int *world);
+/* The row plan, host only: rows [row_begin, row_end) of pyramid level `level` that `rank` of `world` computes
+ * (the coarsest level is cut evenly, finer levels double the cuts), and optionally the rows of that level it
+ * needs to compute the next finer one (its band + halo). */
+int micv_rowshard_band(int rows, int cols, int levels, int world, int win, int rank, int level, int *row_begin,
+                       int *row_end, int *need_begin, int *need_end);
+/* lk::calcOpticalFlowPyr (OpticalFlow.cpp:122-167) of `batch` pairs, every pair split by rows over the ranks of
+ * `comm`: this rank writes rows micv_rowshard_band(..., level 0) of u / v (full-size buffers) and nothing else.
+ * prev / next: the whole frames on every rank.  Same bits as micv_lk_flow_pyr_batch_dev.  Collective: every rank
+ * calls it with the same sizes.  Asynchronous on `stream`. */
+int micv_lk_flow_pyr_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const float *prev, const float *next, int batch,
+                                  size_t pair_stride, int rows, int cols, size_t stride, int win, int levels,
+                                  float *u, float *v, size_t opair_stride, size_t ostride, micv_stream stream);
+/* The cv::Mat caller's form: host frames in, the WHOLE flow fields out on every rank (the bands are gathered
+ * with one broadcast per rank and field); synchronous. */
+int micv_lk_flow_pyr_rowshard_host(micv_ctx *ctx, micv_comm *comm, const float *prev, const float *next, int rows,
+                                   int cols, size_t stride, int win, int levels, float *u, float *v, size_t ostride);
+/* cuda::houghLinesAccumulate (Hough.cu:251-309) with the edge points sharded by rows: micv_hough_lines_band_dev
+ * into this rank's private accumulator, then ONE int32 sum all-reduce in place -- the only real collective of the
+ * whole path; integer sums make it bit-exact in any order.  acc: rho_bins x theta_bins on every rank. */
+int micv_hough_lines_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const uint8_t *mask_band, int band_rows, int cols,
+                                  size_t mstride, int row0, int rows, unsigned rho_bin, unsigned theta_bin,
+                                  int32_t *acc, micv_stream stream);
+int micv_allreduce_sum_i32_dev(micv_ctx *ctx, micv_comm *comm, int32_t *buf, size_t count, micv_stream stream);
 
 /* Diagnostic, host only (no device call): the work list the optional chain / streamed launches of the
  * level kernel walk (MICV_OPT_LK_CHAIN, MICV_OPT_LK_STREAM) for a rows x cols level of `batch` pairs.

@@ -34,7 +34,7 @@ STEREO_COLS_2R, STEREO_MIN_SSD_5E6, STEREO_SERIAL, STEREO_ROLLING = 1, 2, 4, 8
 # micv_ctx_set_option (include/mi_cv.h): none of these changes a result
 (OPT_LK_STREAM_GROUPS, OPT_LK_FORCE_GENERIC, OPT_LK_NARROW_TILES, OPT_SOBEL_GENERIC, OPT_HARRIS_GENERIC,
  OPT_NMS_SCAN, OPT_STEREO_ROWS, OPT_LK_CHAIN, OPT_LK_SHORT_TILES, OPT_LK_STREAM, OPT_LK_TALL_TILES,
- OPT_COMPACT_3PASS) = range(1, 13)
+ OPT_COMPACT_3PASS, OPT_LK_DIRECT_LEVELS) = range(1, 14)
 
 
 class MicvError(RuntimeError):
@@ -100,6 +100,15 @@ SIGNATURES = {
     "micv_sobel_host": (i32, [vp, vp, i32, i32, sz, i32, f32, vp, vp, sz]),
     "micv_harris_response_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, vp, sz, vp]),
     "micv_harris_response_host": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, vp, sz]),
+    "micv_comm_unique_id": (i32, [vp]),
+    "micv_comm_create": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp)]),
+    "micv_comm_destroy": (i32, [vp]),
+    "micv_comm_rank": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+    "micv_rowshard_band": (i32, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "micv_lk_flow_pyr_rowshard_dev": (i32, [vp, vp, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
+    "micv_lk_flow_pyr_rowshard_host": (i32, [vp, vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz]),
+    "micv_hough_lines_rowshard_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, C.c_uint, C.c_uint, vp, vp]),
+    "micv_allreduce_sum_i32_dev": (i32, [vp, vp, vp, sz, vp]),
     "micv_harris_response_ex_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, i32, vp, sz, vp]),
     "micv_harris_response_ex_host": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, i32, vp, sz]),
     "micv_harris_refine_dev": (i32, [vp, vp, i32, i32, sz, f64, i32, vp, sz, vp, i64, vp, vp]),

@@ -331,6 +331,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: tall tiles must be -1, 0 or 1");
     if (option == MICV_OPT_COMPACT_3PASS)
         MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: compaction form must be -1, 0 or 1");
+    if (option == MICV_OPT_LK_DIRECT_LEVELS)
+        MICV_REQUIRE(value >= 0 && value <= 15, "micv_ctx_set_option: direct levels must be 0..15");
     ctx->opt[option] = value;
     return MICV_OK;
 }

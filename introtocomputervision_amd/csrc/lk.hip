@@ -525,6 +525,58 @@ __global__ __launch_bounds__(256) void lk_warp_kernel(const float *__restrict__ 
                                                dv[(size_t)y * fstride + x]);
 }
 
+// lk::warp, tiled (r04): a 64x16 tile whose `src` window (tile + 8 px margin, zeros outside the image = cv::remap's
+// BORDER_CONSTANT) is staged in LDS with 16-byte loads; a thread takes four adjacent pixels -- float4 loads of du and dv,
+// one float4 store -- and each sample's four bilinear taps come from the window (warp_sample_staged: the level
+// kernel's sampler, the contract's arithmetic; a flow that leaves the margin takes its global-memory fallback).
+// 8 B of flow + 4 B of output per pixel are 16-byte traffic and the taps cost no vector-memory instruction:
+// 1080p 19.2 -> see DESIGN.md.  Needs 16-byte aligned rows everywhere and cols % 4 == 0 (a chunk never straddles
+// the image edge); other shapes keep the one-pixel-per-thread kernel above.
+constexpr int WT_W = 64, WT_H = 16, WT_M = 8, WT_NW = WT_W + 2 * WT_M + 4, WT_NH = WT_H + 2 * WT_M + 1;
+typedef float wv4f __attribute__((ext_vector_type(4)));
+typedef float wv2f __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void lk_warp_tiled_kernel(const float *__restrict__ src, int sstride,
+                                                             const float *__restrict__ du,
+                                                             const float *__restrict__ dv, int fstride,
+                                                             int rows, int cols,
+                                                             float *__restrict__ dst, int dstride) {
+    __shared__ __attribute__((aligned(16))) float N[WT_NH * WT_NW];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * WT_W, y0 = blockIdx.y * WT_H;
+    const int nx0 = x0 - WT_M, ny0 = y0 - WT_M;
+    constexpr int V4 = WT_NW / 4, NCH = WT_NH * V4, NB = (NCH + 255) / 256;
+    // the thread's own flow quad first: its loads share one memory round trip with the window's
+    const int x = x0 + 4 * (tid & 15), y = y0 + (tid >> 4);
+    const bool mine = x < cols && y < rows;
+    wv4f fu = {0.f, 0.f, 0.f, 0.f}, fv = fu;
+    if (mine) {
+        fu = *reinterpret_cast<const wv4f *>(du + (size_t)y * fstride + x);
+        fv = *reinterpret_cast<const wv4f *>(dv + (size_t)y * fstride + x);
+    }
+    wv4f w[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {  // all loads first, then the LDS writes
+        const int i = tid + k * 256 < NCH ? tid + k * 256 : NCH - 1;
+        const int ly = i / V4, lv = i - ly * V4;
+        const int gy = ny0 + ly, gx = nx0 + 4 * lv;
+        const bool in = (unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols;  // cols % 4 == 0: whole chunk
+        w[k] = (wv4f){0.f, 0.f, 0.f, 0.f};
+        if (in) w[k] = *reinterpret_cast<const wv4f *>(src + (size_t)gy * sstride + gx);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+        if (tid + k * 256 < NCH) *reinterpret_cast<wv4f *>(N + 4 * (tid + k * 256)) = w[k];
+    __syncthreads();
+    if (!mine) return;
+    wv4f out;
+    const float yf32 = 32.f * (float)y;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        out[j] = warp_sample_staged<WT_NW, WT_NH, 32>(N, nx0, ny0, src, rows, cols, sstride,
+                                                      (wv2f){32.f * (float)(x + j), yf32}, (wv2f){fu[j], fv[j]});
+    *reinterpret_cast<wv4f *>(dst + (size_t)y * dstride + x) = out;
+}
+
 // micv_flow_bound_check_dev: raises *flag when a flow value of the given rows exceeds `bound` in magnitude
 // (or is not finite).  One atomic per wave that sees a violation.
 __global__ __launch_bounds__(256) void flow_bound_kernel(const float *__restrict__ v, size_t pair_elems, int stride,
@@ -542,6 +594,15 @@ __global__ __launch_bounds__(256) void flow_bound_kernel(const float *__restrict
 
 int launch_warp(hipStream_t s, const float *src, int sstride, const float *du, const float *dv,
                 int fstride, int rows, int cols, float *dst, int dstride) {
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(dv) |
+                       reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
+                     ((sstride | fstride | dstride | cols) & 3) == 0;
+    if (vec) {
+        lk_warp_tiled_kernel<<<dim3(cdiv(cols, WT_W), cdiv(rows, WT_H)), 256, 0, s>>>(src, sstride, du, dv, fstride, rows, cols,
+                                                                                   dst, dstride);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
     lk_warp_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(src, sstride, du, dv, fstride,
                                                                         rows, cols, dst, dstride);
     MICV_LAUNCH_CHECK();
@@ -647,6 +708,7 @@ struct LkChain {
     size_t opair_elems;
     int ostride;
     bool profile;                      // bracket level launches with events (group 0 only)
+    int direct_from = 0;               // levels >= direct_from (>= 1) are read straight from level 0; 0 = none
 };
 
 // Fused path: OpticalFlow.cpp:135-163 for all pairs of the chain, one launch per level.
@@ -664,6 +726,16 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.next = last ? c.next : c.npyr[k];
         a.img_stride = last ? c.stride : C;
         a.img_pair = last ? c.pair_elems : lvl_elems;
+        if (!last && c.direct_from > 0 && k >= c.direct_from) {
+            // Pyramids.cu:31 applied k times: L_k(y, x) = L_0(2^k y + 2^k - 1, 2^k x + 2^k - 1) -- the level is
+            // level 0 seen through a row stride of 2^k rows and a pixel stride of 2^k (lk_fused.hip, GATHER)
+            const size_t o = ((size_t)1 << k) - 1;
+            a.prev = c.prev + o * c.stride + o;
+            a.next = c.next + o * c.stride + o;
+            a.img_stride = c.stride << k;
+            a.img_xstride = 1 << k;
+            a.img_pair = c.pair_elems;
+        }
         // this level's flow goes to the user's u/v at the finest level
         a.out_u = last ? c.u : c.fu[cur ^ 1];
         a.out_v = last ? c.v : c.fv[cur ^ 1];
@@ -784,14 +856,29 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // Pyramids (Pyramids.cpp:19-23): every level is a direct decimation of level 0, so ONE launch
     // builds all levels of both images of every pair.  Level l of pair b sits at
     // pyr + lvl_off[l]*batch + b*rows_l*cols_l.
-    if (levels > 1) {
+    // Fused path, MICV_OPT_LK_DIRECT_LEVELS = n > 0: every level >= n takes its images from level 0 itself and the
+    // build launch only makes the levels below that (none for n = 1).  Measured on MI355X (r04, 8 x 1080p, A/B on one
+    // box, profiles/r04/direct_levels_ab.txt): one pass at a time 0.327 -> 0.318 ms (the 20 us build launch goes,
+    // the gather-staged levels take 61.6 / 27.9 / 27.5 / 12.4 us instead of 58.3 / 26.0 / 23.3 / 11.1: a dword LDS-DMA
+    // moves 256 B where the 16-byte form moves 1 KiB, and a DMA instruction costs the issuing wave 60+ cycles
+    // whatever it moves); with two passes in flight -- the bench's configuration -- 0.294-0.300 against 0.288 ms: the
+    // bandwidth-bound build overlaps the other pass's compute-bound levels, the longer level kernels do not.
+    // Off by default.
+    int direct_from = 0;
+    if (fused && levels > 1) {
+        const int o = ctx->opt[MICV_OPT_LK_DIRECT_LEVELS];
+        direct_from = o <= 0 ? 0 : o;  // off by default: measured below
+        if ((long long)stride << (levels - 1) > 0x7fffffffLL) direct_from = 0;  // the row stride is an int
+    }
+    const int build_levels = direct_from > 0 ? (direct_from < levels ? direct_from : levels) : levels;
+    if (build_levels > 1) {
         float *pd[16], *nd[16];
         pd[0] = nd[0] = nullptr;
         for (int l = 1; l < levels; l++) {
             pd[l] = ppyr + plan.lvl_off[l] * batch;
             nd[l] = npyr + plan.lvl_off[l] * batch;
         }
-        MICV_TRY(launch_pyr_build2(s, prev, next, pair_elems, stride, rows, cols, levels, pd, nd, batch));
+        MICV_TRY(launch_pyr_build2(s, prev, next, pair_elems, stride, rows, cols, build_levels, pd, nd, batch));
     }
     auto make_chain = [&](hipStream_t cs, int b0, int nb, bool profile) {
         LkChain c;
@@ -815,6 +902,7 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
         c.opair_elems = opair_elems;
         c.ostride = ostride;
         c.profile = profile;
+        c.direct_from = direct_from;
         return c;
     };
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
                                                     const float *__restrict__ src, int rows,
                                                     int cols, int stride,
                                                     float __attribute__((ext_vector_type(2))) xy32,
-                                                    float __attribute__((ext_vector_type(2))) flow) {
+                                                    float __attribute__((ext_vector_type(2))) flow, int xs = 1) {
     typedef float v2f_ __attribute__((ext_vector_type(2)));
     const v2f_ t = __builtin_elementwise_fma(flow, (v2f_){(float)FS, (float)FS}, xy32);
     const v2f_ r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};  // v_rndne_f32
@@ -142,11 +142,11 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
         const int gx = clampi(cx >> 5, -32768, 32767), gy = clampi(cy >> 5, -32768, 32767);
         const bool x0 = (unsigned)gx < (unsigned)cols, x1 = (unsigned)(gx + 1) < (unsigned)cols;
         const bool y0 = (unsigned)gy < (unsigned)rows, y1 = (unsigned)(gy + 1) < (unsigned)rows;
-        const float *p = src + (ptrdiff_t)gy * stride + gx;
+        const float *p = src + (ptrdiff_t)gy * stride + (ptrdiff_t)gx * xs;  // xs: pixel stride (levels read from level 0)
         v0 = (x0 && y0) ? p[0] : 0.f;
-        v1 = (x1 && y0) ? p[1] : 0.f;
+        v1 = (x1 && y0) ? p[xs] : 0.f;
         v2 = (x0 && y1) ? p[stride] : 0.f;
-        v3 = (x1 && y1) ? p[stride + 1] : 0.f;
+        v3 = (x1 && y1) ? p[stride + xs] : 0.f;
     }
     // weights as aligned pairs, so the four weight products and the four tap products are two packed
     // multiplies each with a broadcast operand (the scalar form made the compiler shuffle halves)
@@ -163,7 +163,7 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
 // lk::warp (OpticalFlow.cpp:111-119) for one pixel: map = (x + du, y + dv); cv::remap
 // INTER_LINEAR with 1/32-pixel fixed-point coordinates, BORDER_CONSTANT(0).
 __device__ __forceinline__ float warp_sample(const float *__restrict__ src, int rows, int cols,
-                                             int stride, int x, int y, float du, float dv) {
+                                             int stride, int x, int y, float du, float dv, int xs = 1) {
     const float mx = (float)x + du, my = (float)y + dv;
     const int sx = cv_round_i32(mx * 32.f), sy = cv_round_i32(my * 32.f);
     const int fx = sx & 31, fy = sy & 31;
@@ -172,11 +172,11 @@ __device__ __forceinline__ float warp_sample(const float *__restrict__ src, int 
     const float ay1 = (float)fy * 0.03125f, ay0 = 1.f - ay1;
     const bool x0 = (unsigned)ix < (unsigned)cols, x1 = (unsigned)(ix + 1) < (unsigned)cols;
     const bool y0 = (unsigned)iy < (unsigned)rows, y1 = (unsigned)(iy + 1) < (unsigned)rows;
-    const float *p = src + (ptrdiff_t)iy * stride + ix;
+    const float *p = src + (ptrdiff_t)iy * stride + (ptrdiff_t)ix * xs;  // xs: pixel stride (levels read from level 0)
     const float v0 = (x0 && y0) ? p[0] : 0.f;
-    const float v1 = (x1 && y0) ? p[1] : 0.f;
+    const float v1 = (x1 && y0) ? p[xs] : 0.f;
     const float v2 = (x0 && y1) ? p[stride] : 0.f;
-    const float v3 = (x1 && y1) ? p[stride + 1] : 0.f;
+    const float v3 = (x1 && y1) ? p[stride + xs] : 0.f;
     float r = v0 * (ay0 * ax0);
     r = r + v1 * (ay0 * ax1);
     r = r + v2 * (ay1 * ax0);

@@ -423,6 +423,67 @@ __device__ __forceinline__ void dma_rows_clipped(const float *__restrict__ img, 
     }
 }
 
+// ---- pyramid levels read straight from level 0 (r04) ---------------------------------------------------
+// Every pyramid level is a decimation of level 0 (Pyramids.cu:31: L_k(y, x) = L_0(2^k y + 2^k - 1, 2^k x + 2^k - 1)),
+// so a level kernel can take its images from level 0 with a row stride of 2^k rows and a PIXEL stride of
+// xs = 2^k floats instead of from a pyramid some other launch built (that launch was 20 us of a 330 us step
+// at the roofline, i.e. only removable).  The staging then is a gather: global_load_lds_dword gives every lane
+// its own global address and puts lane l's dword at (wave's LDS base) + 4 l, so one wave-instruction fills 64
+// consecutive floats of the dense LDS image from 64 strided pixels -- still no VGPR round trip, no ds_write,
+// every transfer in flight at once; four times the transfers of the 16-byte form and no alignment rules.
+// Decomposition: one wave-instruction = (one row, one 64-float part of it), so the row is wave-uniform -- its
+// address is scalar arithmetic -- and the lane's part, column * xs, never changes: no vector instruction per
+// transfer at all (the dense "64 consecutive slots" split of dma_rows needs five per transfer to walk
+// (row, column) with a carry; at four times the transfers that was +6 % instructions on level 1, measured
+// +3.5 us of 58).  A row of RWC in (64, 128] floats is two parts, the second partly filled.
+template <int NT, int RWC, int NROWS>
+__device__ __forceinline__ void dma_gather(const float *__restrict__ src, int rstride, int xs, float *dst, int tid) {
+    constexpr int PARTS = (RWC + 63) / 64, NWV = NT / 64, RSTEP = NWV / PARTS, NP = (NROWS + RSTEP - 1) / RSTEP;
+    static_assert(NWV % PARTS == 0 && RSTEP >= 1, "a wave keeps its part of the row");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = wave % PARTS, col = 64 * part + lane;
+    const unsigned voff = (unsigned)(col * xs);
+    if (col < RWC) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int row = wave / PARTS + RSTEP * k;  // wave-uniform
+            if (k == NP - 1 ? row < NROWS : true)
+                __builtin_amdgcn_global_load_lds((glb_cvoid *)(src + (size_t)row * rstride + voff),
+                                                 (lds_void *)(dst + row * RWC + 64 * part), 4, 0, 0);
+        }
+    }
+}
+
+// The same for a border tile: the block's top-left element is level pixel (gx0, gy0), possibly outside the
+// rows x cols level image whose pixel (0, 0) is img[0].  Pixels inside the image go by LDS-DMA, the others are
+// zero-filled (ZERO: the `next` window -- lk::warp's constant border) or left alone (the prev tile).
+template <int NT, int RWC, int NROWS, bool ZERO>
+__device__ __forceinline__ void dma_gather_clipped(const float *__restrict__ img, int rstride, int xs, int rows,
+                                                   int cols, int gx0, int gy0, float *dst, int tid) {
+    constexpr int PARTS = (RWC + 63) / 64, NWV = NT / 64, RSTEP = NWV / PARTS, NP = (NROWS + RSTEP - 1) / RSTEP;
+    static_assert(NWV % PARTS == 0 && RSTEP >= 1, "a wave keeps its part of the row");
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int part = wave % PARTS, col = 64 * part + lane;
+    const int gx = gx0 + col;
+    const bool col_in = (unsigned)gx < (unsigned)cols;
+    const unsigned voff = col_in ? (unsigned)(gx * xs) : 0u;
+    if (col < RWC) {
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int row = wave / PARTS + RSTEP * k;  // wave-uniform
+            if (k == NP - 1 ? row < NROWS : true) {
+                const int gy = gy0 + row;
+                const bool row_in = (unsigned)gy < (unsigned)rows;  // wave-uniform
+                if (row_in && col_in)
+                    __builtin_amdgcn_global_load_lds((glb_cvoid *)(img + (size_t)gy * rstride + voff),
+                                                     (lds_void *)(dst + row * RWC + 64 * part), 4, 0, 0);
+                else if (ZERO)
+                    dst[row * RWC + col] = 0.f;
+            }
+        }
+    }
+}
+
 // Streamed tiles (lk_level_stream_kernel): the coarse flow block goes in by LDS-DMA too.  LDS layout:
 // [u row | v row] per coarse row, CWP = CW rounded up to whole float4s each, so that pyrUp reads a
 // (u, v) pair with one ds_read2_b32; a wave-instruction moves as many consecutive half-rows as fit
@@ -489,8 +550,9 @@ __device__ __forceinline__ void lk_stage_ahead(const LkLevelArgs &a, float *lds,
 // the chain follows -- the last QC gradient rows are moved to the front of the gradient area once
 // the row passes are done with them.
 // STREAM: the tile runs in lk_level_stream_kernel's loop (its window and coarse block were staged ahead).
+// GATHER: the level's images are read from pyramid level 0 with a pixel stride (a.img_xstride; above).
 template <int R, int MODE, bool INT, int NTV, bool CARRY = false, int THV = 32, bool STREAM = false,
-          bool IN_LOOP = CARRY || STREAM>
+          bool IN_LOOP = CARRY || STREAM, bool GATHER = false>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
                                         float *lds, int tile_x, int tile_y, int pair, bool more = false,
                                         LkStreamLink *link = nullptr) {
@@ -500,7 +562,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     constexpr int GW = C::GW, GH = C::GH, GS = C::GS, GP = C::GP, CW = C::CW, NT = C::NT;
     constexpr int M = C::M, NW = C::NW;
     static_assert(!CARRY || (INT && C::FAST && MODE == LK_FLOW_COARSE && C::CHAIN_OK), "carry tiles: interior, coarse flow");
-    static_assert(!STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY && C::RW % 4 == 0 && C::NW % 4 == 0),
+    static_assert(!STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY && C::RW % 4 == 0 && C::NW % 4 == 0 && !GATHER),
                   "streamed tiles: interior, coarse flow, LDS-DMA staging");
     static_assert(!(STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY)) || C::CS_F + C::NW * C::NH <= C::X_F,
                   "interior tiles: DMA-staged coarse block + next window fit the gradient area");
@@ -541,6 +603,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     const float *__restrict__ prev = a.prev + pair * a.img_pair;
     const float *__restrict__ next = a.next + pair * a.img_pair;
     const int istride = a.img_stride;
+    const int xs = GATHER ? a.img_xstride : 1;  // pixel stride of prev / next (floats)
     const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};  // Pyramids.cu:19
 #ifdef MICV_DIAG
     // wave-uniform on purpose: the running stamp then lives in SGPRs, not in a (spilled) VGPR pair
@@ -595,8 +658,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         }
     }
     // (the host launches streamed tiles only when this holds)
-    const bool vec_ok = STREAM || (INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
-                                   ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0);
+    const bool vec_ok = STREAM || GATHER ||
+                        (INT && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0);
     // 16-byte rows; the last wave of a transfer may be partial and carry tiles start mid-wave (lanes
     // beyond the range are masked off, the wave's LDS base stays uniform)
     constexpr bool DMA_OK = (RW % 4 == 0) && (NW % 4 == 0);
@@ -604,11 +668,20 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         // LDS-DMA (dma_rows): the LDS images are dense (P: 80-float rows, window: 96-float rows); carry
         // tiles stage region rows [LYC, RH) only
         constexpr int V = RW / 4;
+        if constexpr (GATHER) {
+            // the `next` window first: phase 2 needs it, the prev tile is not read before phase 3
+            if (STAGED)
+                dma_gather<NT, NW, NH>(next + (ptrdiff_t)(ry0 - M + LY0) * istride + (ptrdiff_t)(rx0 - M) * xs, istride, xs, Nx, tid);
+            dma_gather<NT, RW, RH - LY0>(prev + (size_t)(ry0 + LY0) * istride + (size_t)rx0 * xs, istride, xs, P + LY0 * RW, tid);
+            if (MODE == LK_FLOW_NONE)
+                dma_gather<NT, RW, RH - LY0>(next + (size_t)(ry0 + LY0) * istride + (size_t)rx0 * xs, istride, xs, Wp + LY0 * RW, tid);
+        } else {
         dma_rows<NT, V, RH - LY0>(prev + (size_t)(ry0 + LY0) * istride + rx0, istride, P + LY0 * RW, tid);
         if (MODE == LK_FLOW_NONE)
             dma_rows<NT, V, RH - LY0>(next + (size_t)(ry0 + LY0) * istride + rx0, istride, Wp + LY0 * RW, tid);
         if (STAGED && !STREAM)
             dma_rows<NT, NW / 4, NH>(next + (size_t)(ry0 - M + LY0) * istride + rx0 - M, istride, Nx, tid);
+        }
         if (MODE == LK_FLOW_COARSE && !CDMA) {
 #pragma unroll
             for (int k = 0; k < NC; k++) {
@@ -630,9 +703,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         }
         // Border tiles whose 16-byte chunks cannot straddle the image edge take the DMA as well
         // (in-image chunks only; the `next` window's other chunks are zero-filled)
-        const bool clip_dma = fastb && (cols & 3) == 0 && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
-                              ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0;
-        if (clip_dma) {
+        const bool clip_dma = fastb && (GATHER || ((cols & 3) == 0 && (istride & 3) == 0 && ((a.img_pair & 3) == 0) &&
+                              ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0));
+        if (GATHER && clip_dma) {
+            dma_gather_clipped<NT, NW, NH, true>(next, istride, xs, rows, cols, rx0 - M, ry0 - M, Nx, tid);
+            dma_gather_clipped<NT, RW, RH, false>(prev, istride, xs, rows, cols, rx0, ry0, P, tid);
+        } else if (clip_dma) {
             dma_rows_clipped<NT, RW / 4, RH, false>(prev, istride, rows, cols, rx0, ry0, P, tid);
             dma_rows_clipped<NT, NW / 4, NH, true>(next, istride, rows, cols, rx0 - M, ry0 - M, Nx, tid);
         } else
@@ -647,8 +723,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 const int i = tid + k * NT < RH * RW ? tid + k * NT : RH * RW - 1;
                 const int ly = i / RW, lx = i - ly * RW;
                 const int gy = clampi(ry0 + ly, 0, rows - 1), gx = clampi(rx0 + lx, 0, cols - 1);
-                rp[k] = prev[(size_t)gy * istride + gx];
-                if (MODE == LK_FLOW_NONE) rn[k] = next[(size_t)gy * istride + gx];
+                rp[k] = prev[(size_t)gy * istride + (size_t)gx * xs];
+                if (MODE == LK_FLOW_NONE) rn[k] = next[(size_t)gy * istride + (size_t)gx * xs];
             }
 #pragma unroll
             for (int k = 0; k < NB; k++) {
@@ -662,7 +738,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         if (STAGED) {
             for (int i = tid; i < NH * NW; i += NT) {
                 const int ly = i / NW, lx = i - ly * NW;
-                Nx[i] = next[(size_t)(ry0 - M + LY0 + ly) * istride + rx0 - M + lx];
+                Nx[i] = next[(ptrdiff_t)(ry0 - M + LY0 + ly) * istride + (ptrdiff_t)(rx0 - M + lx) * xs];
             }
         }
         if (fastb && !clip_dma) {
@@ -679,7 +755,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 for (int k = 0; k < HB; k++) {
                     const int gy = ry0 - M + ly2, gx = rx0 - M + lx2;
                     const bool ok = (unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols;
-                    const float val = next[(size_t)clampi(gy, 0, rows - 1) * istride + clampi(gx, 0, cols - 1)];
+                    const float val = next[(size_t)clampi(gy, 0, rows - 1) * istride + (size_t)clampi(gx, 0, cols - 1) * xs];
                     rn[k] = ok ? val : 0.f;
                     lx2 += B;
                     const bool c = lx2 >= NW;
@@ -811,7 +887,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         // the warped image from region row LYC on (the base flow of every own row)
                         if (!CARRY || ly0 + j >= LY0)
                             wrow[j * PS] = warp_sample_staged<NW, NH, MODE == LK_FLOW_COARSE ? 64 : 32>(
-                                Nx, nx0s, ny0s, next, rows, cols, istride, (v2f){xf32, yf32 + 32.f * (float)j}, half_uv);
+                                Nx, nx0s, ny0s, next, rows, cols, istride, (v2f){xf32, yf32 + 32.f * (float)j}, half_uv, xs);
                         // 512-thread tiles run at a 128-VGPR budget: keep the rows from interleaving
                         if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
                     }
@@ -879,7 +955,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                     bu = a.flow_u[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
                     bv = a.flow_v[pair * a.flow_pair + (size_t)gy * a.flow_cols + gx];
                 }
-                Wp[ly * PS + lx] = warp_sample(next, rows, cols, istride, gx, gy, bu, bv);
+                Wp[ly * PS + lx] = warp_sample(next, rows, cols, istride, gx, gy, bu, bv, xs);
             };
             {
                 const int c = tid & (TW - 1), grp = tid / TW;
@@ -1231,7 +1307,7 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
     }
 }
 
-template <int R, int MODE, int NTV, int THV = 32>
+template <int R, int MODE, int NTV, int THV = 32, bool GATHER = false>
 __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
     using C = LkCfg<R, NTV, THV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1243,15 +1319,15 @@ __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_kernel(L
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
     if (interior)
-        lk_tile<R, MODE, true, NTV, false, THV>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, true, NTV, false, THV, false, false, GATHER>(a, g, lds, tile_x, tile_y, blockIdx.y);
     else
-        lk_tile<R, MODE, false, NTV, false, THV>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, false, NTV, false, THV, false, false, GATHER>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
 // Chain launch: workgroup b runs the `count` vertically adjacent tiles of sched[b] (tile_x, first
 // tile_y, count, pair), carrying the gradient rows from one tile to the next.  A 1-D grid: the
 // host-built schedule already contains the batch, the XCD-aware placement and the order of issue.
-template <int R, int NTV>
+template <int R, int NTV, bool GATHER = false>
 __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_chain_kernel(LkLevelArgs a, TapsN<2 * R + 1> g,
                                                                         const int4 *__restrict__ sched) {
     using C = LkCfg<R, NTV>;
@@ -1263,13 +1339,13 @@ __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_chain_ke
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
     if (!interior) {  // border tiles are never chained
-        lk_tile<R, LK_FLOW_COARSE, false, NTV>(a, g, lds, e.x, e.y, e.w);
+        lk_tile<R, LK_FLOW_COARSE, false, NTV, false, 32, false, false, GATHER>(a, g, lds, e.x, e.y, e.w);
         return;
     }
-    lk_tile<R, LK_FLOW_COARSE, true, NTV, false>(a, g, lds, e.x, e.y, e.w, e.z > 1);
+    lk_tile<R, LK_FLOW_COARSE, true, NTV, false, 32, false, false, GATHER>(a, g, lds, e.x, e.y, e.w, e.z > 1);
     for (int t = 1; t < e.z; t++) {
         __syncthreads();  // the tile above is done with the row buffers / staged images this one overwrites
-        lk_tile<R, LK_FLOW_COARSE, true, NTV, true>(a, g, lds, e.x, e.y + t, e.w, t + 1 < e.z);
+        lk_tile<R, LK_FLOW_COARSE, true, NTV, true, 32, false, true, GATHER>(a, g, lds, e.x, e.y + t, e.w, t + 1 < e.z);
     }
 }
 
@@ -1456,9 +1532,13 @@ static int get_schedule(const LkLevelArgs &a, int max_chain, const int4 **sched,
     return MICV_OK;
 }
 
-template <int R, int NTV, int THV = 32>
+template <int R, int NTV, int THV = 32, bool GATHER = false>
 static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     using C = LkCfg<R, NTV, THV>;
+    if constexpr (!GATHER) {
+        // pyramid level k read straight from level 0 (img_xstride = 2^k): the gather-staging instantiations
+        if (a.img_xstride != 1) return launch_r<R, NTV, THV, true>(s, a);
+    }
     static TapsN<2 * R + 1> taps;
     static std::once_flag once;
     std::call_once(once, [] {
@@ -1472,13 +1552,13 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         int dev = 0;
         MICV_HIP(hipGetDevice(&dev));
         if (done_dev != dev) {
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0, NTV, THV>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0, NTV, THV, GATHER>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1, NTV, THV>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1, NTV, THV, GATHER>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2, NTV, THV>),
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2, NTV, THV, GATHER>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
             done_dev = dev;
@@ -1488,7 +1568,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         set_error("lk fused: bad row band [%d, %d) for %d rows", a.row_begin, a.row_end, a.rows);
         return MICV_EINVAL;
     }
-    if constexpr (C::FAST && C::RW % 4 == 0 && C::NW % 4 == 0 && ((THV == 32 && NTV == 512) || (THV == 64 && NTV == 1024))) {
+    if constexpr (!GATHER && C::FAST && C::RW % 4 == 0 && C::NW % 4 == 0 && ((THV == 32 && NTV == 512) || (THV == 64 && NTV == 1024))) {
         // Streamed launch (MICV_OPT_LK_STREAM = 1; off by default): whole frames with a coarse flow whose
         // images the LDS-DMA can address (16-byte rows).  Measured on MI355X (8 x 1080p, tools/stream_bench.py,
         // one box): level-0 launch 0.244 ms against 0.220 ms for the plain grid -- the loop's staging
@@ -1573,12 +1653,12 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
                     int dev = 0;
                     MICV_HIP(hipGetDevice(&dev));
                     if (chain_dev != dev) {
-                        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_chain_kernel<R, NTV>),
+                        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_chain_kernel<R, NTV, GATHER>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
                         chain_dev = dev;
                     }
                 }
-                lk_level_chain_kernel<R, NTV><<<nblocks, C::NT, C::LDS_BYTES, s>>>(a, taps, sched);
+                lk_level_chain_kernel<R, NTV, GATHER><<<nblocks, C::NT, C::LDS_BYTES, s>>>(a, taps, sched);
                 MICV_LAUNCH_CHECK();
                 return MICV_OK;
             }
@@ -1593,7 +1673,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
     switch (a.mode) {
         case LK_FLOW_NONE:
-            lk_level_kernel<R, 0, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
+            lk_level_kernel<R, 0, NTV, THV, GATHER><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         case LK_FLOW_COARSE:
             if (a.rows != 2 * a.flow_rows || a.cols != 2 * a.flow_cols) {
@@ -1601,10 +1681,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
                           a.flow_cols, a.rows, a.cols);
                 return MICV_EINVAL;
             }
-            lk_level_kernel<R, 1, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
+            lk_level_kernel<R, 1, NTV, THV, GATHER><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         case LK_FLOW_FULL:
-            lk_level_kernel<R, 2, NTV, THV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
+            lk_level_kernel<R, 2, NTV, THV, GATHER><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         default:
             set_error("lk fused: bad mode %d", a.mode);

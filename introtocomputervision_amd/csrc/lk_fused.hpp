@@ -14,7 +14,8 @@ enum LkFlowMode {
 
 struct LkLevelArgs {
     const float *prev, *next;  // level images of pair 0
-    int img_stride;            // elements
+    int img_stride;            // elements between rows
+    int img_xstride = 1;       // elements between pixels: 2^k when pyramid level k is read straight from level 0
     size_t img_pair;           // elements between consecutive pairs
     int rows, cols, batch, win;
     int mode;

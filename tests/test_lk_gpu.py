@@ -508,6 +508,43 @@ def test_streamed_launch_is_bit_exact(mods, rows, cols, levels, batch, win):
         ctx.set_option(_capi.OPT_LK_STREAM, 2)
 
 
+@pytest.mark.parametrize("rows,cols,levels,batch,win", [(1080, 1920, 5, 2, 15), (540, 960, 4, 9, 15), (270, 481, 3, 2, 15),
+                                                        (333, 517, 4, 1, 15), (97, 400, 2, 2, 15), (300, 520, 3, 2, 7),
+                                                        (300, 520, 3, 3, 11), (540, 960, 3, 2, 21), (64, 64, 3, 1, 15)])
+@pytest.mark.parametrize("direct", [1, 2])
+def test_levels_read_straight_from_level_0_are_bit_exact(mods, rows, cols, levels, batch, win, direct):
+    """MICV_OPT_LK_DIRECT_LEVELS = n: the fused level kernels of levels >= n take prev / next from level 0 itself
+    (L_k(y, x) = L_0(2^k y + 2^k - 1, 2^k x + 2^k - 1), Pyramids.cu:31, staged by dword LDS-DMA gathers) instead of
+    from a pyramid another launch built; n = 1 drops that launch.  Odd sizes (unaligned rows, odd-sized levels
+    with a resized base flow), border-only levels, tile chains (540x960 x 9 pairs at level 2) and NaN pixels:
+    the same bits as the built pyramid and as the oracle.  Off by default (measured)."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(7000 + i + rows, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    prev[0, rows // 3, cols // 3] = np.nan
+    nxt[-1, rows // 2, cols // 2] = np.inf
+    ctx = _capi.Context(0)
+    bu, bv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), win, levels, ctx=ctx)
+    ctx.set_option(_capi.OPT_LK_DIRECT_LEVELS, direct)
+    u = torch.full((batch, rows, cols), float("nan"), device="cuda")
+    v = torch.full((batch, rows, cols), float("nan"), device="cuda")
+    for rep in range(2):
+        lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), win, levels, ctx=ctx, out=(u, v))
+    assert host(u).tobytes() == host(bu).tobytes() and host(v).tobytes() == host(bv).tobytes()
+    eu, ev = orc.lk_flow_pyr(prev[batch - 1], nxt[batch - 1], win, levels)
+    # (against the oracle a NaN matches a NaN: the sign of a produced NaN is not part of the contract)
+    assert np.array_equal(host(u[batch - 1]), eu, equal_nan=True) and np.array_equal(host(v[batch - 1]), ev, equal_nan=True)
+    # a pitched view (rows of a wider buffer, base not 16-byte aligned): the gather has no alignment rules
+    wide_p = torch.zeros((batch, rows, cols + 7), device="cuda"); wide_n = torch.zeros_like(wide_p)
+    wide_p[:, :, 3:3 + cols] = dev(prev); wide_n[:, :, 3:3 + cols] = dev(nxt)
+    if batch == 1:
+        gu, gv = lk.calcOpticalFlowPyr(wide_p[0, :, 3:3 + cols], wide_n[0, :, 3:3 + cols], win, levels, ctx=ctx)
+        assert host(gu).tobytes() == host(bu[0]).tobytes() and host(gv).tobytes() == host(bv[0]).tobytes()
+    with pytest.raises(Exception):
+        ctx.set_option(_capi.OPT_LK_DIRECT_LEVELS, 16)
+
+
 @pytest.mark.parametrize("rows,cols,levels,batch", [(270, 480, 3, 1), (135, 240, 2, 8), (67, 120, 1, 3), (1080, 1920, 5, 1), (100, 333, 3, 2)])
 def test_short_tiles_are_bit_exact(mods, rows, cols, levels, batch):
     """Launches of at most one 64x16 tile per CU run the half-height form of the win-15 level kernel
