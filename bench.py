@@ -520,9 +520,14 @@ def main(argv=None):
         if dist is not None:
             for t in (prev, nxt):
                 dist.broadcast(t, src=0)
-        runner = shard.RowShardBatch(ctx, ROWS, COLS, LEVELS, WIN, B, rank, n_gpus,
-                                     comm=shard.DistComm(rank, n_gpus) if dist is not None else None,
-                                     next_margin=args.next_margin)
+        if args.next_margin is None:
+            # the C ABI's own driver (micv_lk_flow_pyr_rowshard_dev: band launches + ncclSend / ncclRecv halo exchange
+            # on the launch stream) -- the path a C++ caller links; torch.distributed only carries the RCCL unique id
+            runner = shard.RowShardNative(ctx, ROWS, COLS, LEVELS, WIN, B, shard.MicvComm(ctx, rank, n_gpus, dist=dist))
+        else:  # declared bound on |dv|: the Python driver with its device-side check and whole-frame fallback
+            runner = shard.RowShardBatch(ctx, ROWS, COLS, LEVELS, WIN, B, rank, n_gpus,
+                                         comm=shard.DistComm(rank, n_gpus) if dist is not None else None,
+                                         next_margin=args.next_margin)
         a0, b0 = runner.band0
         margin_stats = [0, 0]  # steps, steps on which the declared margin sufficed
 
@@ -754,7 +759,9 @@ def main(argv=None):
                 "workload": f"C2 x{B}: {B} x 1920x1080 synthetic translated pairs per GPU per step "
                             f"(C4 per-GPU share), {LEVELS}-level pyramid, win {WIN}, device-resident",
                 "pairs_per_gpu_per_step": B, "levels": LEVELS, "win": WIN,
-                "parallelism": f"pair-dp{n_gpus}" if args.mode == "pairs" else f"row-shard{n_gpus} (coarse-flow halo, p2p)",
+                "parallelism": f"pair-dp{n_gpus}" if args.mode == "pairs" else
+                               (f"row-shard{n_gpus} (coarse-flow halo, ncclSend/ncclRecv inside micv_lk_flow_pyr_rowshard_dev)"
+                                if args.next_margin is None else f"row-shard{n_gpus} (coarse-flow halo, torch p2p, declared next margin)"),
                 "mode": args.mode,
                 "rccl_ranks": dist.get_world_size() if dist is not None else 1,
                 "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],

@@ -181,6 +181,14 @@ int micv_rowshard_band(int rows, int cols, int levels, int world, int win, int r
 int micv_lk_flow_pyr_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const float *prev, const float *next, int batch,
                                   size_t pair_stride, int rows, int cols, size_t stride, int win, int levels,
                                   float *u, float *v, size_t opair_stride, size_t ostride, micv_stream stream);
+/* The same plan, packing and band launches for `world` VIRTUAL ranks in this process on one device, the exchange
+ * done by copies between the ranks' private slabs: whole u / v come back (every rank writes its band).  What a
+ * one-GPU box can run at world sizes > 1; `poison` != 0 fills every rank's private memory with NaNs first, so a halo
+ * row that was neither computed nor received shows up in the result.  Synchronises `stream` before it returns. */
+int micv_lk_flow_pyr_rowshard_virtual_dev(micv_ctx *ctx, int world, const float *prev, const float *next, int batch,
+                                          size_t pair_stride, int rows, int cols, size_t stride, int win, int levels,
+                                          float *u, float *v, size_t opair_stride, size_t ostride, int poison,
+                                          micv_stream stream);
 /* The cv::Mat caller's form: host frames in, the WHOLE flow fields out on every rank (the bands are gathered
  * with one broadcast per rank and field); synchronous. */
 int micv_lk_flow_pyr_rowshard_host(micv_ctx *ctx, micv_comm *comm, const float *prev, const float *next, int rows,

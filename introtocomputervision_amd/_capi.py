@@ -37,6 +37,9 @@ STEREO_COLS_2R, STEREO_MIN_SSD_5E6, STEREO_SERIAL, STEREO_ROLLING = 1, 2, 4, 8
  OPT_COMPACT_3PASS, OPT_LK_DIRECT_LEVELS) = range(1, 14)
 
 
+MICV_COMM_ID_BYTES = 128  # mi_cv.h
+
+
 class MicvError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"micv error {code}: {msg}")
@@ -106,6 +109,7 @@ SIGNATURES = {
     "micv_comm_rank": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     "micv_rowshard_band": (i32, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "micv_lk_flow_pyr_rowshard_dev": (i32, [vp, vp, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
+    "micv_lk_flow_pyr_rowshard_virtual_dev": (i32, [vp, i32, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, i32, vp]),
     "micv_lk_flow_pyr_rowshard_host": (i32, [vp, vp, vp, vp, i32, i32, sz, i32, i32, vp, vp, sz]),
     "micv_hough_lines_rowshard_dev": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, C.c_uint, C.c_uint, vp, vp]),
     "micv_allreduce_sum_i32_dev": (i32, [vp, vp, vp, sz, vp]),

@@ -271,102 +271,100 @@ int micv_hough_lines_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const uint8_t 
     return micv_allreduce_sum_i32_dev(ctx, comm, acc, (size_t)rb * tb, stream);
 }
 
-int micv_lk_flow_pyr_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const float *prev, const float *next, int batch,
-                                  size_t pair_stride, int rows, int cols, size_t stride, int win, int levels,
-                                  float *u, float *v, size_t opair_stride, size_t ostride, micv_stream stream) {
-    MICV_REQUIRE(ctx && comm && prev && next && u && v, "micv_lk_flow_pyr_rowshard: null argument");
-    MICV_REQUIRE(rows > 0 && cols > 0 && rows <= 32767 && cols <= 32767, "micv_lk_flow_pyr_rowshard: bad size %dx%d", rows, cols);
-    MICV_REQUIRE(stride_ok(stride, cols, 4) && stride_ok(ostride, cols, 4), "micv_lk_flow_pyr_rowshard: bad stride");
-    MICV_REQUIRE(win >= 1 && win <= kMaxWin && (win & 1), "micv_lk_flow_pyr_rowshard: window %d must be odd and <= %d", win, kMaxWin);
-    MICV_REQUIRE(batch >= 1 && batch <= 32767, "micv_lk_flow_pyr_rowshard: bad batch %d", batch);
-    MICV_REQUIRE(levels >= 1 && levels <= 16 && (rows >> (levels - 1)) > 0 && (cols >> (levels - 1)) > 0,
-                 "micv_lk_flow_pyr_rowshard: %d levels do not fit a %dx%d image", levels, rows, cols);
-    MICV_REQUIRE(pair_stride % 4 == 0 && opair_stride % 4 == 0 &&
-                     (batch == 1 || (pair_stride >= stride * (size_t)rows && opair_stride >= ostride * (size_t)rows)),
-                 "micv_lk_flow_pyr_rowshard: bad pair stride");
-    MICV_REQUIRE(comm->device == ctx->device, "micv_lk_flow_pyr_rowshard: communicator and context are on different devices");
+// ---- the row-shard driver ------------------------------------------------------------------------------------
+// One rank's share of a row-sharded lk::calcOpticalFlowPyr, cut into the steps between which the transport runs:
+// build() -- pyramids; per level, coarsest first: pack(l + 1) -> [transport] -> unpack(l + 1) -> launch(l).
+// The transport is RCCL point-to-point (micv_lk_flow_pyr_rowshard_dev) or, for `world` virtual ranks in one process
+// on one device, row copies between the ranks' slabs (micv_lk_flow_pyr_rowshard_virtual_dev: the same plan, the
+// same packing, the same band launches -- what the tests run at world sizes a one-GPU box cannot give RCCL).
+}  // extern "C"
+
+namespace micv {
+
+struct RowShardRun {
+    micv_ctx *ctx;
+    hipStream_t s;
     RowPlan plan;
-    if (!plan.build(rows, cols, levels, comm->world, win)) {
-        set_error("micv_lk_flow_pyr_rowshard: %d ranks cannot split the %d-row coarsest level", comm->world, rows >> (levels - 1));
-        return MICV_EINVAL;
-    }
-    MICV_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int me = comm->rank;
-    // ---- memory: pyramids (levels >= 1, both image sets, whole frames), flow [B][2][rows_l][cols_l] per level >= 1,
-    //      one slab per transfer this rank takes part in
+    int me, batch, win, levels;
+    const float *prev, *next;
+    size_t pair_stride, stride;
+    float *u, *v;
+    size_t opair_stride, ostride;
+    float *mem = nullptr;
     size_t lvl_elems[16], pyr_off[16], flow_off[16], total = 0;
-    for (int l = 1; l < levels; l++) {
-        lvl_elems[l] = (size_t)plan.rows[l] * plan.cols[l];
-        pyr_off[l] = total;
-        total += Carver::need(lvl_elems[l] * batch * 4, 1) / 4 * 2;  // prev block then next block
-    }
-    for (int l = 1; l < levels; l++) {
-        flow_off[l] = total;
-        total += Carver::need(lvl_elems[l] * batch * 2 * 4, 1) / 4;
-    }
     std::vector<RowPlan::Xfer> xf[16];
     std::vector<size_t> slab_off[16];
-    for (int l = 1; l < levels; l++) {
-        for (const auto &t : plan.transfers(l))
-            if (t.src == me || t.dst == me) {
-                xf[l].push_back(t);
-                slab_off[l].push_back(total);
-                total += Carver::need((size_t)(t.r1 - t.r0) * plan.cols[l] * batch * 2 * 4, 1) / 4;
-            }
+
+    // memory: pyramids (levels >= 1, both image sets, whole frames), flow [B][2][rows_l][cols_l] per level >= 1, one
+    // slab per transfer this rank takes part in.  Returns the floats needed.
+    size_t layout() {
+        total = 0;
+        for (int l = 1; l < levels; l++) {
+            lvl_elems[l] = (size_t)plan.rows[l] * plan.cols[l];
+            pyr_off[l] = total;
+            total += pyr_block(l) * 2;  // prev block then next block
+        }
+        for (int l = 1; l < levels; l++) {
+            flow_off[l] = total;
+            total += Carver::need(lvl_elems[l] * batch * 2 * 4, 1) / 4;
+        }
+        for (int l = 1; l < levels; l++) {
+            xf[l].clear();
+            slab_off[l].clear();
+            for (const auto &t : plan.transfers(l))
+                if (t.src == me || t.dst == me) {
+                    xf[l].push_back(t);
+                    slab_off[l].push_back(total);
+                    total += Carver::need(slab_floats(l, t) * 4, 1) / 4;
+                }
+        }
+        return total + 64;
     }
-    void *base = nullptr;
-    MICV_TRY(comm->reserve((total + 64) * 4, &base));
-    float *mem = static_cast<float *>(base);
-    if (levels > 1) {
+    size_t pyr_block(int l) const { return Carver::need(lvl_elems[l] * batch * 4, 1) / 4; }
+    size_t slab_floats(int l, const RowPlan::Xfer &t) const { return (size_t)(t.r1 - t.r0) * plan.cols[l] * batch * 2; }
+    float *slab(int l, size_t i) const { return mem + slab_off[l][i]; }
+
+    int build() {
+        if (levels <= 1) return MICV_OK;
         float *pd[16], *nd[16];
         pd[0] = nd[0] = nullptr;
         for (int l = 1; l < levels; l++) {
             pd[l] = mem + pyr_off[l];
-            nd[l] = pd[l] + Carver::need(lvl_elems[l] * batch * 4, 1) / 4;
+            nd[l] = pd[l] + pyr_block(l);
         }
-        MICV_TRY(launch_pyr_build2(s, prev, next, pair_stride / 4, (int)(stride / 4), rows, cols, levels, pd, nd, batch));
+        return launch_pyr_build2(s, prev, next, pair_stride / 4, (int)(stride / 4), plan.rows[0], plan.cols[0], levels, pd, nd, batch);
     }
-    const Rccl *r = rccl();
-    for (int l = levels - 1; l >= 0; l--) {
-        const int R = plan.rows[l], C = plan.cols[l];
-        if (l < levels - 1 && !xf[l + 1].empty()) {
-            // ---- halo rows of the coarse flow (level l + 1): pack, one grouped send / receive, unpack -- all on `s`
-            const int cl = l + 1, CR = plan.rows[cl], CC = plan.cols[cl];
-            float *flow = mem + flow_off[cl];
-            const size_t plane = (size_t)CR * CC * 4;
-            for (size_t i = 0; i < xf[cl].size(); i++) {
-                const auto &t = xf[cl][i];
-                if (t.src != me) continue;
-                const size_t w = (size_t)(t.r1 - t.r0) * CC * 4;
-                MICV_HIP(hipMemcpy2DAsync(mem + slab_off[cl][i], w, flow + (size_t)t.r0 * CC, plane, w, 2 * (size_t)batch,
-                                          hipMemcpyDeviceToDevice, s));
-            }
-            MICV_NCCL(r->GroupStart());
-            for (size_t i = 0; i < xf[cl].size(); i++) {
-                const auto &t = xf[cl][i];
-                const size_t n = (size_t)(t.r1 - t.r0) * CC * batch * 2;
-                ncclResult_t nr = t.src == me ? r->Send(mem + slab_off[cl][i], n, ncclFloat32, t.dst, comm->comm, s)
-                                              : r->Recv(mem + slab_off[cl][i], n, ncclFloat32, t.src, comm->comm, s);
-                if (nr != ncclSuccess) {
-                    (void)r->GroupEnd();
-                    set_error("micv_lk_flow_pyr_rowshard: halo exchange of level %d -> %s", cl, r->GetErrorString(nr));
-                    return MICV_EHIP;
-                }
-            }
-            MICV_NCCL(r->GroupEnd());
-            for (size_t i = 0; i < xf[cl].size(); i++) {
-                const auto &t = xf[cl][i];
-                if (t.dst != me) continue;
-                const size_t w = (size_t)(t.r1 - t.r0) * CC * 4;
-                MICV_HIP(hipMemcpy2DAsync(flow + (size_t)t.r0 * CC, plane, mem + slab_off[cl][i], w, w, 2 * (size_t)batch,
-                                          hipMemcpyDeviceToDevice, s));
-            }
+    // rows [r0, r1) of every (pair, field) plane of level l's flow block <-> a dense slab: one 2-D copy
+    int pack(int l) {
+        const size_t plane = lvl_elems[l] * 4;
+        for (size_t i = 0; i < xf[l].size(); i++) {
+            const auto &t = xf[l][i];
+            if (t.src != me) continue;
+            const size_t w = (size_t)(t.r1 - t.r0) * plan.cols[l] * 4;
+            MICV_HIP(hipMemcpy2DAsync(slab(l, i), w, mem + flow_off[l] + (size_t)t.r0 * plan.cols[l], plane, w, 2 * (size_t)batch,
+                                      hipMemcpyDeviceToDevice, s));
         }
+        return MICV_OK;
+    }
+    int unpack(int l) {
+        const size_t plane = lvl_elems[l] * 4;
+        for (size_t i = 0; i < xf[l].size(); i++) {
+            const auto &t = xf[l][i];
+            if (t.dst != me) continue;
+            const size_t w = (size_t)(t.r1 - t.r0) * plan.cols[l] * 4;
+            MICV_HIP(hipMemcpy2DAsync(mem + flow_off[l] + (size_t)t.r0 * plan.cols[l], plane, slab(l, i), w, w, 2 * (size_t)batch,
+                                      hipMemcpyDeviceToDevice, s));
+        }
+        return MICV_OK;
+    }
+    // the band of level l for all pairs (micv_lk_level_batch_dev: the unsharded kernels on a row range)
+    int launch(int l) {
+        const int R = plan.rows[l], C = plan.cols[l];
         int a, b;
         plan.band(l, me, &a, &b);
+        if (a >= b) return MICV_OK;
         const float *pl = l == 0 ? prev : mem + pyr_off[l];
-        const float *nl = l == 0 ? next : mem + pyr_off[l] + Carver::need(lvl_elems[l] * batch * 4, 1) / 4;
+        const float *nl = l == 0 ? next : mem + pyr_off[l] + pyr_block(l);
         const size_t ps = l == 0 ? pair_stride : lvl_elems[l] * 4, st = l == 0 ? stride : (size_t)C * 4;
         const float *fu = nullptr, *fv = nullptr;
         int fr = 0, fc = 0;
@@ -378,17 +376,154 @@ int micv_lk_flow_pyr_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const float *p
             fv = fu + (size_t)fr * fc;
             fps = 2 * (size_t)fr * fc * 4;
         }
-        float *ou, *ov;
-        size_t ops, ost;
-        if (l == 0) {
-            ou = u; ov = v; ops = opair_stride; ost = ostride;
-        } else {
-            ou = mem + flow_off[l]; ov = ou + lvl_elems[l]; ops = 2 * lvl_elems[l] * 4; ost = (size_t)C * 4;
+        float *ou = u, *ov = v;
+        size_t ops = opair_stride, ost = ostride;
+        if (l > 0) {
+            ou = mem + flow_off[l];
+            ov = ou + lvl_elems[l];
+            ops = 2 * lvl_elems[l] * 4;
+            ost = (size_t)C * 4;
         }
-        if (a < b)
-            MICV_TRY(micv_lk_level_batch_dev(ctx, pl, nl, batch, ps, R, C, st, win, fu, fv, fr, fc, fps, a, b, ou, ov, ops, ost, stream));
+        return micv_lk_level_batch_dev(ctx, pl, nl, batch, ps, R, C, st, win, fu, fv, fr, fc, fps, a, b, ou, ov, ops, ost, s);
+    }
+};
+
+static int rowshard_check_args(const char *fn, micv_ctx *ctx, const float *prev, const float *next, int batch, size_t pair_stride,
+                               int rows, int cols, size_t stride, int win, int levels, float *u, float *v, size_t opair_stride,
+                               size_t ostride) {
+    MICV_REQUIRE(ctx && prev && next && u && v, "%s: null argument", fn);
+    MICV_REQUIRE(rows > 0 && cols > 0 && rows <= 32767 && cols <= 32767, "%s: bad size %dx%d", fn, rows, cols);
+    MICV_REQUIRE(stride_ok(stride, cols, 4) && stride_ok(ostride, cols, 4), "%s: bad stride", fn);
+    MICV_REQUIRE(win >= 1 && win <= kMaxWin && (win & 1), "%s: window %d must be odd and <= %d", fn, win, kMaxWin);
+    MICV_REQUIRE(batch >= 1 && batch <= 32767, "%s: bad batch %d", fn, batch);
+    MICV_REQUIRE(levels >= 1 && levels <= 16 && (rows >> (levels - 1)) > 0 && (cols >> (levels - 1)) > 0,
+                 "%s: %d levels do not fit a %dx%d image", fn, levels, rows, cols);
+    MICV_REQUIRE(pair_stride % 4 == 0 && opair_stride % 4 == 0 &&
+                     (batch == 1 || (pair_stride >= stride * (size_t)rows && opair_stride >= ostride * (size_t)rows)),
+                 "%s: bad pair stride", fn);
+    return MICV_OK;
+}
+
+}  // namespace micv
+
+extern "C" {
+
+int micv_lk_flow_pyr_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const float *prev, const float *next, int batch,
+                                  size_t pair_stride, int rows, int cols, size_t stride, int win, int levels,
+                                  float *u, float *v, size_t opair_stride, size_t ostride, micv_stream stream) {
+    MICV_REQUIRE(comm != nullptr, "micv_lk_flow_pyr_rowshard: null communicator");
+    MICV_TRY(rowshard_check_args("micv_lk_flow_pyr_rowshard", ctx, prev, next, batch, pair_stride, rows, cols, stride, win, levels,
+                                 u, v, opair_stride, ostride));
+    MICV_REQUIRE(comm->device == ctx->device, "micv_lk_flow_pyr_rowshard: communicator and context are on different devices");
+    RowShardRun run;
+    if (!run.plan.build(rows, cols, levels, comm->world, win)) {
+        set_error("micv_lk_flow_pyr_rowshard: %d ranks cannot split the %d-row coarsest level", comm->world, rows >> (levels - 1));
+        return MICV_EINVAL;
+    }
+    MICV_HIP(hipSetDevice(ctx->device));
+    run.ctx = ctx; run.s = static_cast<hipStream_t>(stream); run.me = comm->rank; run.batch = batch; run.win = win; run.levels = levels;
+    run.prev = prev; run.next = next; run.pair_stride = pair_stride; run.stride = stride;
+    run.u = u; run.v = v; run.opair_stride = opair_stride; run.ostride = ostride;
+    void *base = nullptr;
+    MICV_TRY(comm->reserve(run.layout() * 4, &base));
+    run.mem = static_cast<float *>(base);
+    MICV_TRY(run.build());
+    const Rccl *r = rccl();
+    for (int l = levels - 1; l >= 0; l--) {
+        const int cl = l + 1;
+        if (l < levels - 1 && !run.xf[cl].empty()) {
+            // halo rows of the coarse flow: pack, ONE grouped send / receive on the launch stream, unpack
+            MICV_TRY(run.pack(cl));
+            MICV_NCCL(r->GroupStart());
+            for (size_t i = 0; i < run.xf[cl].size(); i++) {
+                const auto &t = run.xf[cl][i];
+                const size_t n = run.slab_floats(cl, t);
+                const ncclResult_t nr = t.src == run.me ? r->Send(run.slab(cl, i), n, ncclFloat32, t.dst, comm->comm, run.s)
+                                                        : r->Recv(run.slab(cl, i), n, ncclFloat32, t.src, comm->comm, run.s);
+                if (nr != ncclSuccess) {
+                    (void)r->GroupEnd();
+                    set_error("micv_lk_flow_pyr_rowshard: halo exchange of level %d -> %s", cl, r->GetErrorString(nr));
+                    return MICV_EHIP;
+                }
+            }
+            MICV_NCCL(r->GroupEnd());
+            MICV_TRY(run.unpack(cl));
+        }
+        MICV_TRY(run.launch(l));
     }
     return MICV_OK;
+}
+
+int micv_lk_flow_pyr_rowshard_virtual_dev(micv_ctx *ctx, int world, const float *prev, const float *next, int batch,
+                                          size_t pair_stride, int rows, int cols, size_t stride, int win, int levels,
+                                          float *u, float *v, size_t opair_stride, size_t ostride, int poison,
+                                          micv_stream stream) {
+    MICV_TRY(rowshard_check_args("micv_lk_flow_pyr_rowshard_virtual", ctx, prev, next, batch, pair_stride, rows, cols, stride, win,
+                                 levels, u, v, opair_stride, ostride));
+    MICV_REQUIRE(world >= 1 && world <= 64, "micv_lk_flow_pyr_rowshard_virtual: %d ranks", world);
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<RowShardRun> runs(world);
+    std::vector<void *> blocks(world, nullptr);
+    auto free_all = [&]() {
+        (void)hipStreamSynchronize(s);
+        for (void *p : blocks)
+            if (p) (void)hipFree(p);
+    };
+    int rc = MICV_OK;
+    for (int g = 0; g < world && rc == MICV_OK; g++) {
+        RowShardRun &run = runs[g];
+        if (!run.plan.build(rows, cols, levels, world, win)) {
+            set_error("micv_lk_flow_pyr_rowshard_virtual: %d ranks cannot split the %d-row coarsest level", world, rows >> (levels - 1));
+            rc = MICV_EINVAL;
+            break;
+        }
+        run.ctx = ctx; run.s = s; run.me = g; run.batch = batch; run.win = win; run.levels = levels;
+        run.prev = prev; run.next = next; run.pair_stride = pair_stride; run.stride = stride;
+        run.u = u; run.v = v; run.opair_stride = opair_stride; run.ostride = ostride;
+        const size_t bytes = run.layout() * 4;
+        if (hipMalloc(&blocks[g], bytes) != hipSuccess) {
+            set_error("micv_lk_flow_pyr_rowshard_virtual: out of device memory");
+            rc = MICV_ENOMEM;
+            break;
+        }
+        run.mem = static_cast<float *>(blocks[g]);
+        // poison: every byte of the rank's private block is 0xFF (a NaN in every float) before anything is built, so a
+        // flow row the rank neither computed nor received shows up in the result
+        if (poison && hipMemsetAsync(blocks[g], 0xFF, bytes, s) != hipSuccess) rc = MICV_EHIP;
+        if (rc == MICV_OK) rc = run.build();
+    }
+    for (int l = levels - 1; l >= 0 && rc == MICV_OK; l--) {
+        const int cl = l + 1;
+        if (l < levels - 1) {
+            for (int g = 0; g < world && rc == MICV_OK; g++) rc = runs[g].pack(cl);
+            // the transport: the sender's slab of transfer (src, dst, r0, r1) into the receiver's slab of the same transfer
+            for (int g = 0; g < world && rc == MICV_OK; g++) {
+                RowShardRun &dstr = runs[g];
+                for (size_t i = 0; i < dstr.xf[cl].size() && rc == MICV_OK; i++) {
+                    const auto &t = dstr.xf[cl][i];
+                    if (t.dst != g) continue;
+                    RowShardRun &srcr = runs[t.src];
+                    size_t j = 0;
+                    for (; j < srcr.xf[cl].size(); j++) {
+                        const auto &q = srcr.xf[cl][j];
+                        if (q.src == t.src && q.dst == t.dst && q.r0 == t.r0 && q.r1 == t.r1) break;
+                    }
+                    if (j == srcr.xf[cl].size()) {
+                        set_error("micv_lk_flow_pyr_rowshard_virtual: rank %d has no send for rank %d's receive", t.src, g);
+                        rc = MICV_EINVAL;
+                        break;
+                    }
+                    if (hipMemcpyAsync(dstr.slab(cl, i), srcr.slab(cl, j), dstr.slab_floats(cl, t) * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                        rc = MICV_EHIP;
+                }
+            }
+            for (int g = 0; g < world && rc == MICV_OK; g++) rc = runs[g].unpack(cl);
+        }
+        for (int g = 0; g < world && rc == MICV_OK; g++) rc = runs[g].launch(l);
+    }
+    free_all();
+    return rc;
 }
 
 int micv_lk_flow_pyr_rowshard_host(micv_ctx *ctx, micv_comm *comm, const float *prev, const float *next, int rows, int cols,

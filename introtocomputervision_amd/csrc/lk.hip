@@ -865,7 +865,8 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // bandwidth-bound build overlaps the other pass's compute-bound levels, the longer level kernels do not.
     // Off by default.
     int direct_from = 0;
-    if (fused && levels > 1) {
+    if (fused && levels > 1 && lk_fused_supports_direct_levels(win) && !ctx->opt[MICV_OPT_LK_NARROW_TILES] &&
+        ctx->opt[MICV_OPT_LK_TALL_TILES] <= 0 && !ctx->opt[MICV_OPT_LK_STREAM]) {
         const int o = ctx->opt[MICV_OPT_LK_DIRECT_LEVELS];
         direct_from = o <= 0 ? 0 : o;  // off by default: measured below
         if ((long long)stride << (levels - 1) > 0x7fffffffLL) direct_from = 0;  // the row stride is an int

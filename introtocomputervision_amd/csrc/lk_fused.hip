@@ -1490,6 +1490,7 @@ static void build_chain_schedule(int rows, int cols, int batch, int max_chain, s
 }
 
 bool lk_fused_supports(int win) { return win == 15 || win == 7 || win == 21 || win == 11; }
+bool lk_fused_supports_direct_levels(int win) { return win == 15; }
 
 // Host-only view of the schedule the chain / streamed launches walk (micv_lk_schedule_host): lets a
 // CPU test check that every (tile x, tile y, pair) is covered exactly once.
@@ -1535,9 +1536,14 @@ static int get_schedule(const LkLevelArgs &a, int max_chain, const int4 **sched,
 template <int R, int NTV, int THV = 32, bool GATHER = false>
 static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     using C = LkCfg<R, NTV, THV>;
-    if constexpr (!GATHER) {
+    if constexpr (!GATHER && R == 7 && NTV == 512) {
         // pyramid level k read straight from level 0 (img_xstride = 2^k): the gather-staging instantiations
+        // (window 15, 512-thread tiles only -- the option is off by default and every instantiation costs build time)
         if (a.img_xstride != 1) return launch_r<R, NTV, THV, true>(s, a);
+    }
+    if (!GATHER && a.img_xstride != 1) {
+        set_error("lk fused: levels read from level 0 (pixel stride %d) are built for window 15 only", a.img_xstride);
+        return MICV_EUNSUPPORTED;
     }
     static TapsN<2 * R + 1> taps;
     static std::once_flag once;

@@ -47,6 +47,7 @@ struct LkLevelArgs {
 };
 
 bool lk_fused_supports(int win);
+bool lk_fused_supports_direct_levels(int win);  // MICV_OPT_LK_DIRECT_LEVELS has kernels for this window
 // Host-only: the (tile x, first tile y, count, pair) entries of the chain / streamed launch schedule,
 // 8 per round (one per XCD, count 0 = padding).  Returns the tile height, 0 for windows without one.
 int lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, std::vector<int4> *out);

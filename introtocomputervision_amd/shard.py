@@ -491,3 +491,114 @@ def run_virtual_batch_checked(runners, prev, nxt, u, v, stream=None, poison=None
     finally:
         for r in runners:
             r.full_next = False
+
+
+# ---- the C ABI's own multi-GPU path (csrc/comm.hip): what a C++ caller links, and what Python runs too --------
+
+class MicvComm:
+    """A micv_comm: the library's communicator over RCCL (loaded at run time by libmicv.so; the copy PyTorch already
+    holds is shared).  Created from an RCCL unique id that rank 0 makes; `dist` (torch.distributed, any backend,
+    initialised) carries the 128 bytes to the other ranks -- or pass `unique_id` yourself.  Collective, like
+    ncclCommInitRank: every rank constructs it."""
+
+    def __init__(self, ctx, rank=0, world=1, dist=None, unique_id=None):
+        import ctypes as C
+
+        from ._capi import MICV_COMM_ID_BYTES, check, lib
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        if unique_id is None:
+            buf = (C.c_char * MICV_COMM_ID_BYTES)()
+            if rank == 0:
+                check(lib.micv_comm_unique_id(buf))
+            if world > 1:
+                if dist is None:
+                    raise ValueError("world > 1 needs torch.distributed (or a unique_id) to share the RCCL unique id")
+                box = [bytes(buf.raw)]
+                dist.broadcast_object_list(box, src=0)
+                unique_id = box[0]
+            else:
+                unique_id = bytes(buf.raw)
+        if len(unique_id) != MICV_COMM_ID_BYTES:
+            raise ValueError(f"an RCCL unique id has {MICV_COMM_ID_BYTES} bytes")
+        self.unique_id = bytes(unique_id)
+        h = C.c_void_p()
+        check(lib.micv_comm_create(ctx.handle, None, self.unique_id, self.rank, self.world, C.byref(h)))
+        self._h = h
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("MicvComm used after close()")
+        return self._h
+
+    def close(self):
+        from ._capi import lib
+        if self._h:
+            lib.micv_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allreduce_sum_i32(self, t, stream=None):
+        """In-place int32 sum over the ranks (the Hough accumulator merge) on `stream` / the current stream."""
+        import torch
+
+        from ._capi import check, lib
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise ValueError("a contiguous int32 tensor is expected")
+        s = stream if stream is not None else torch.cuda.current_stream(t.device).cuda_stream
+        check(lib.micv_allreduce_sum_i32_dev(self.ctx.handle, self.handle, t.data_ptr(), t.numel(), s))
+        return t
+
+
+def native_band(rows, cols, levels, world, win, rank, level=0, needed=False):
+    """micv_rowshard_band: the C ABI's row plan (host only) -- equal to RowShardPlan by construction, and by test."""
+    import ctypes as C
+
+    from ._capi import check, lib
+    a, b, n0, n1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    check(lib.micv_rowshard_band(rows, cols, levels, world, win, rank, level, C.byref(a), C.byref(b), C.byref(n0), C.byref(n1)))
+    return ((a.value, b.value), (n0.value, n1.value)) if needed else (a.value, b.value)
+
+
+class RowShardNative:
+    """RowShardBatch's job done by the library itself: micv_lk_flow_pyr_rowshard_dev builds the pyramids, launches
+    the bands and exchanges the coarse-flow halo with ncclSend / ncclRecv on the launch stream -- no Python between
+    the levels, and the same entry point a C++ caller (shim lk::calcOpticalFlowPyr with a communicator) uses.
+    Whole `next` frames on every rank (the exact default); the declared-margin variant stays in RowShardBatch."""
+
+    def __init__(self, ctx, rows, cols, levels, win, batch, comm):
+        self.ctx, self.rows, self.cols, self.levels, self.win, self.batch, self.comm = ctx, rows, cols, levels, win, batch, comm
+        self.band0 = native_band(rows, cols, levels, comm.world, win, comm.rank, 0)
+
+    def run(self, prev, nxt, u, v, stream=None):
+        import torch
+
+        from ._capi import check, lib
+        B, rows, cols = prev.shape
+        if (B, rows, cols) != (self.batch, self.rows, self.cols):
+            raise ValueError("shape differs from the runner's")
+        s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+        check(lib.micv_lk_flow_pyr_rowshard_dev(self.ctx.handle, self.comm.handle, prev.data_ptr(), nxt.data_ptr(), B,
+                                                rows * cols * 4, rows, cols, cols * 4, self.win, self.levels, u.data_ptr(),
+                                                v.data_ptr(), rows * cols * 4, cols * 4, s))
+
+
+def run_virtual_native(ctx, world, prev, nxt, win, levels, poison=True, stream=None):
+    """micv_lk_flow_pyr_rowshard_virtual_dev: `world` virtual ranks of the C ABI's driver on one device (same plan,
+    packing and band launches; the transport is a copy between the ranks' slabs).  Returns whole (u, v)."""
+    import torch
+
+    from ._capi import check, lib
+    B, rows, cols = prev.shape
+    u = torch.full_like(prev, float("nan"))
+    v = torch.full_like(prev, float("nan"))
+    s = stream if stream is not None else torch.cuda.current_stream(prev.device).cuda_stream
+    check(lib.micv_lk_flow_pyr_rowshard_virtual_dev(ctx.handle, int(world), prev.data_ptr(), nxt.data_ptr(), B, rows * cols * 4,
+                                                    rows, cols, cols * 4, int(win), int(levels), u.data_ptr(), v.data_ptr(),
+                                                    rows * cols * 4, cols * 4, 1 if poison else 0, s))
+    return u, v

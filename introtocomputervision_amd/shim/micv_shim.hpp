@@ -91,6 +91,26 @@ inline void check(int rc) {
 inline void require(bool ok, const char *what) {
     if (!ok) throw std::invalid_argument(what);
 }
+// Multi-GPU (include/mi_cv.h, "multi-GPU"): one process per GPU.  With a communicator set, lk::calcOpticalFlowPyr on
+// CV_32F frames splits every call by rows over the ranks (each computes its band, the coarse-flow halo travels over
+// RCCL, the bands are gathered) and still returns whole fields -- the reference's caller (ps5_cpp/src/Solution.cpp:
+// 60-64) does not change.  Rank 0 makes the id (micv_comm_unique_id) and ships its MICV_COMM_ID_BYTES bytes to the
+// others by whatever the application has (MPI, a file); every rank then calls init_comm(id, rank, world) --
+// collective -- or use_comm() with an ncclComm_t / micv_comm it already owns.
+inline micv_comm *&comm_slot() {
+    static micv_comm *c = nullptr;
+    return c;
+}
+inline void use_comm(micv_comm *c) { comm_slot() = c; }
+inline void init_comm(const void *unique_id, int rank, int world) {
+    micv_comm *c = nullptr;
+    check(micv_comm_create(context(), nullptr, unique_id, rank, world, &c));
+    comm_slot() = c;
+}
+inline void close_comm() {
+    if (comm_slot()) micv_comm_destroy(comm_slot());
+    comm_slot() = nullptr;
+}
 inline bool frame_type_ok(const Mat &m) {  // what cvtColor(COLOR_RGB2GRAY) + convertTo(CV_32F) take here
     return (m.depth() == U8 || m.depth() == F32) && (m.channels() == 1 || m.channels() == 3 || m.channels() == 4);
 }
@@ -163,10 +183,15 @@ inline void calcOpticalFlowPyr(const Mat &prevImg, const Mat &nextImg, Mat &u, M
     }
     const Mat p = micv_shim::to_f32(prevImg), n = micv_shim::to_f32(nextImg);
     micv_shim::require(p.step == n.step, "lk::calcOpticalFlowPyr: inputs need equal row pitch");
-    micv_shim::check(micv_lk_flow_pyr_host(micv_shim::context(), p.ptr<float>(), n.ptr<float>(),
-                                           p.rows, p.cols, p.step, static_cast<int>(winSize),
-                                           static_cast<int>(levels), uu.ptr<float>(),
-                                           vv.ptr<float>(), uu.step));
+    if (micv_shim::comm_slot())  // row-sharded over the ranks of the communicator, whole fields on every rank
+        micv_shim::check(micv_lk_flow_pyr_rowshard_host(micv_shim::context(), micv_shim::comm_slot(), p.ptr<float>(),
+                                                        n.ptr<float>(), p.rows, p.cols, p.step, static_cast<int>(winSize),
+                                                        static_cast<int>(levels), uu.ptr<float>(), vv.ptr<float>(), uu.step));
+    else
+        micv_shim::check(micv_lk_flow_pyr_host(micv_shim::context(), p.ptr<float>(), n.ptr<float>(),
+                                               p.rows, p.cols, p.step, static_cast<int>(winSize),
+                                               static_cast<int>(levels), uu.ptr<float>(),
+                                               vv.ptr<float>(), uu.step));
     u = uu;  // :165-166
     v = vv;
 }

@@ -517,7 +517,8 @@ def test_levels_read_straight_from_level_0_are_bit_exact(mods, rows, cols, level
     (L_k(y, x) = L_0(2^k y + 2^k - 1, 2^k x + 2^k - 1), Pyramids.cu:31, staged by dword LDS-DMA gathers) instead of
     from a pyramid another launch built; n = 1 drops that launch.  Odd sizes (unaligned rows, odd-sized levels
     with a resized base flow), border-only levels, tile chains (540x960 x 9 pairs at level 2) and NaN pixels:
-    the same bits as the built pyramid and as the oracle.  Off by default (measured)."""
+    the same bits as the built pyramid and as the oracle.  Off by default (measured); the gather
+    kernels exist for window 15, other windows keep building the pyramid whatever the option says."""
     lk, pyr = mods
     from introtocomputervision_amd import synth, _capi
     pairs = [synth.lk_pair(7000 + i + rows, rows, cols, 3, -2) for i in range(batch)]

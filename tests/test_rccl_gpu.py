@@ -125,3 +125,145 @@ def test_sharded_ops_over_rccl_world_1(tmp_path):
         eu, ev = orc.lk_flow_pyr(pn[0], pn[1], 15, 4)
         assert np.array_equal(d["u"][i], eu) and np.array_equal(d["v"][i], ev)
     assert np.array_equal(d["gathered"], np.arange(4.0))
+
+
+# ---- the C ABI's own communicator (csrc/comm.hip) ---------------------------------------------
+
+_CHILD_NATIVE = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+out = sys.argv[2]
+torch.cuda.set_device(0)
+from introtocomputervision_amd import shard, synth, lk, hough
+from introtocomputervision_amd._capi import Context, check, lib
+ctx = Context(0)
+# a communicator of one rank from an RCCL unique id: ncclGetUniqueId + ncclCommInitRank inside libmicv (dlopen'd RCCL)
+comm = shard.MicvComm(ctx, 0, 1)
+B, rows, cols, levels, win = 2, 270, 480, 4, 15
+pn = [synth.lk_pair(77 + i, rows, cols, 2, -1) for i in range(B)]
+prev = torch.from_numpy(np.stack([p for p, _ in pn])).cuda()
+nxt = torch.from_numpy(np.stack([n for _, n in pn])).cuda()
+u = torch.full_like(prev, float("nan")); v = torch.full_like(prev, float("nan"))
+runner = shard.RowShardNative(ctx, rows, cols, levels, win, B, comm)
+side = torch.cuda.Stream()
+torch.cuda.synchronize()
+for _ in range(2):
+    runner.run(prev, nxt, u, v, side.cuda_stream)   # a non-current stream: launches and RCCL calls all follow it
+side.synchronize()
+ref_u, ref_v = lk.calcOpticalFlowPyrBatch(prev, nxt, win, levels, ctx=Context(0))
+# the cv::Mat caller's form
+hu = np.zeros((rows, cols), np.float32); hv = np.zeros_like(hu)
+check(lib.micv_lk_flow_pyr_rowshard_host(ctx.handle, comm.handle, pn[0][0].ctypes.data, pn[0][1].ctypes.data, rows, cols, cols * 4,
+                                         win, levels, hu.ctypes.data, hv.ctypes.data, cols * 4))
+# Hough: band launch + the int32 all-reduce through the library's communicator
+m = synth.hough_mask(270, 480)[0]
+dm = torch.from_numpy(m).cuda()
+ref_acc = hough.houghLinesAccumulate(dm, 1, 1, ctx=ctx)
+acc = torch.empty_like(ref_acc)
+s = torch.cuda.current_stream().cuda_stream
+check(lib.micv_hough_lines_rowshard_dev(ctx.handle, comm.handle, dm.data_ptr(), 270, 480, 480, 0, 270, 1, 1, acc.data_ptr(), s))
+t = torch.arange(1000, device="cuda", dtype=torch.int32)
+comm.allreduce_sum_i32(t)
+torch.cuda.synchronize()
+np.savez(out, u=u.cpu().numpy(), v=v.cpu().numpy(), ref_u=ref_u.cpu().numpy(), ref_v=ref_v.cpu().numpy(), hu=hu, hv=hv,
+         acc=acc.cpu().numpy(), ref_acc=ref_acc.cpu().numpy(), t=t.cpu().numpy(), band=np.array(runner.band0))
+comm.close()
+'''
+
+
+def test_native_communicator_world_1(tmp_path):
+    """micv_comm_unique_id / micv_comm_create (RCCL dlopen'd by libmicv.so), micv_lk_flow_pyr_rowshard_dev on a side
+    stream, the host form, the Hough all-reduce: one rank, fresh process -- results equal the unsharded calls and the
+    oracle.  (World sizes > 1 of the same driver: test_native_virtual_ranks below.)"""
+    import _oracle as orc
+    from introtocomputervision_amd import synth
+    out = str(tmp_path / "out.npz")
+    p = subprocess.run([sys.executable, "-c", _CHILD_NATIVE, ROOT, out], capture_output=True, text=True, env=_env(), timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = np.load(out)
+    assert tuple(d["band"]) == (0, 270)
+    assert np.array_equal(d["u"], d["ref_u"]) and np.array_equal(d["v"], d["ref_v"])
+    pn = synth.lk_pair(77, 270, 480, 2, -1)
+    eu, ev = orc.lk_flow_pyr(pn[0], pn[1], 15, 4)
+    assert np.array_equal(d["u"][0], eu) and np.array_equal(d["hu"], eu) and np.array_equal(d["hv"], ev)
+    assert np.array_equal(d["acc"], d["ref_acc"]) and np.array_equal(d["t"], np.arange(1000))
+
+
+@pytest.mark.parametrize("rows,cols,levels,world,win,batch", [(270, 480, 4, 2, 15, 2), (540, 960, 5, 8, 15, 1), (333, 517, 3, 3, 15, 2),
+                                                              (270, 480, 3, 4, 21, 1), (200, 320, 3, 5, 7, 1), (1080, 1920, 5, 8, 15, 1)])
+def test_native_virtual_ranks(rows, cols, levels, world, win, batch):
+    """The C ABI's row-shard driver at world sizes > 1 on one device (micv_lk_flow_pyr_rowshard_virtual_dev): the plan,
+    the slab packing and the band launches of micv_lk_flow_pyr_rowshard_dev with copies in place of ncclSend / ncclRecv,
+    every rank's private memory NaN-poisoned first.  Same bits as the unsharded call."""
+    torch = pytest.importorskip("torch")
+    from introtocomputervision_amd import lk, shard, synth
+    from introtocomputervision_amd._capi import Context
+    ctx = Context(0)
+    pn = [synth.lk_pair(501 + i + rows, rows, cols, 3, -2) for i in range(batch)]
+    prev = torch.from_numpy(np.stack([p for p, _ in pn])).cuda()
+    nxt = torch.from_numpy(np.stack([n for _, n in pn])).cuda()
+    ref_u, ref_v = lk.calcOpticalFlowPyrBatch(prev, nxt, win, levels, ctx=ctx)
+    u, v = shard.run_virtual_native(ctx, world, prev, nxt, win, levels, poison=True)
+    assert torch.equal(u, ref_u) and torch.equal(v, ref_v)
+
+
+def test_native_halo_is_needed_and_world_too_large_is_refused():
+    torch = pytest.importorskip("torch")
+    from introtocomputervision_amd import lk, shard, synth
+    from introtocomputervision_amd._capi import Context, MicvError
+    ctx = Context(0)
+    p, n = synth.lk_pair(9, 270, 480, 3, -2)
+    prev, nxt = torch.from_numpy(p[None]).cuda(), torch.from_numpy(n[None]).cuda()
+    with pytest.raises(MicvError):  # 16-row coarsest level (270 >> 4) cannot be split 17 ways
+        shard.run_virtual_native(ctx, 17, prev, nxt, 15, 5)
+
+
+_CPP_CALLER = r'''
+// A C++ process sharding lk::calcOpticalFlowPyr without Python: the shim with a communicator (world 1 here).
+#include <cstdio>
+#include <vector>
+#include "introtocomputervision_amd/shim/micv_shim.hpp"
+int main(int argc, char **argv) {
+    const int rows = 135, cols = 240;
+    micv_shim::Mat prev(rows, cols, micv_shim::F32), next(rows, cols, micv_shim::F32), u, v, u1, v1;
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f || std::fread(prev.data, 4, (size_t)rows * cols, f) != (size_t)rows * cols || std::fread(next.data, 4, (size_t)rows * cols, f) != (size_t)rows * cols) return 3;
+    std::fclose(f);
+    lk::calcOpticalFlowPyr(prev, next, u1, v1, 15);             // unsharded
+    unsigned char id[MICV_COMM_ID_BYTES];
+    micv_shim::check(micv_comm_unique_id(id));                 // rank 0 makes it; MPI / a file would carry it to the others
+    micv_shim::init_comm(id, 0, 1);                            // every rank: its rank and the world size
+    lk::calcOpticalFlowPyr(prev, next, u, v, 15);              // row-sharded over the communicator, whole fields back
+    micv_shim::close_comm();
+    f = std::fopen(argv[2], "wb");
+    std::fwrite(u.data, 4, (size_t)rows * cols, f); std::fwrite(v.data, 4, (size_t)rows * cols, f);
+    std::fwrite(u1.data, 4, (size_t)rows * cols, f); std::fwrite(v1.data, 4, (size_t)rows * cols, f);
+    std::fclose(f);
+    return 0;
+}
+'''
+
+
+def test_cpp_caller_shards_through_the_shim(tmp_path):
+    """The reference's caller path (ps5_cpp/src/Solution.cpp:60-64 -> lk::calcOpticalFlowPyr) with a communicator set
+    on the shim: C++ -> micv_lk_flow_pyr_rowshard_host -> RCCL, no Python in the process."""
+    import _oracle as orc
+    from introtocomputervision_amd import synth
+    src = tmp_path / "caller.cpp"
+    src.write_text(_CPP_CALLER)
+    exe = str(tmp_path / "caller")
+    lib = os.path.join(ROOT, "introtocomputervision_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + ROOT, "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe,
+                    "-L" + lib, "-lmicv", "-Wl,-rpath," + lib], check=True)
+    p, n = synth.lk_pair(31, 135, 240, 3, -2)
+    with open(tmp_path / "in.f32", "wb") as f:
+        f.write(p.tobytes()); f.write(n.tobytes())
+    env = _env()
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe, str(tmp_path / "in.f32"), str(tmp_path / "out.f32")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = np.fromfile(tmp_path / "out.f32", np.float32).reshape(4, 135, 240)
+    eu, ev = orc.lk_flow_pyr(p, n, 15, 4)  # the shim keeps the reference's depth of 4 (OpticalFlow.cpp:127)
+    assert np.array_equal(o[0], eu) and np.array_equal(o[1], ev) and np.array_equal(o[2], eu) and np.array_equal(o[3], ev)

@@ -63,6 +63,23 @@ def test_virtual_shards_match_unsharded_oracle(rows, cols, levels, world):
     assert np.array_equal(u, eu) and np.array_equal(v, ev)
 
 
+def test_native_plan_equals_python_plan():
+    """micv_rowshard_band (csrc/comm.hip, the plan the C ABI's row-shard driver walks) against RowShardPlan: bands
+    and needed rows of every rank and level, for sizes with odd levels, uneven cuts and several windows.  Host only."""
+    for rows, cols, levels, world, win in [(1080, 1920, 5, 8, 15), (1080, 1920, 5, 3, 21), (270, 480, 4, 2, 15), (333, 517, 3, 5, 7),
+                                           (2160, 3840, 5, 8, 15), (67, 120, 1, 4, 15), (135, 240, 2, 7, 31), (100, 100, 3, 1, 43)]:
+        plan = shard.RowShardPlan(rows, cols, levels, world, win)
+        for l in range(levels):
+            for g in range(world):
+                band, need = shard.native_band(rows, cols, levels, world, win, g, l, needed=True)
+                assert band == plan.band(l, g) and need == plan.needed(l, g), (rows, cols, levels, world, win, l, g)
+    from introtocomputervision_amd._capi import MicvError
+    with pytest.raises(MicvError):
+        shard.native_band(270, 480, 5, 17, 15, 0)  # a 16-row coarsest level cannot be cut 17 ways
+    with pytest.raises(MicvError):
+        shard.native_band(270, 480, 3, 2, 15, 2)   # rank out of range
+
+
 @pytest.mark.parametrize("win,rows,cols,levels,world", [(21, 135, 96, 3, 3), (31, 135, 64, 3, 2), (31, 101, 77, 3, 4), (43, 160, 48, 2, 3)])
 def test_halo_follows_the_window(win, rows, cols, levels, world):
     """Wide windows need more coarse rows than the 7 of win 15: the plan derives the halo from win
