@@ -1,171 +1,190 @@
 // canny.hip -- the edge front-end of ps1: sol::generateEdge,
 // ps1_cpp/src/Solution.cpp:21-47 = cv::cuda Gaussian blur on CV_8U + Canny (aperture 3, L1 norm).
-// Integer / byte work throughout; the only data-dependent part is the hysteresis, which runs
-// tile-local flood fills in LDS and repeats them until no tile changes (the host reads one flag per
-// round, as OpenCV's own CUDA Canny reads its queue counter).
+// Integer / byte work throughout.  r04: four kernels on bit planes instead of six on byte / int planes --
+//   gauss_u8_tiled_kernel   blur, both passes in one LDS tile (u8 in, u8 out; no float plane in HBM)
+//   canny_gradmap_kernel    3x3 Sobel, L1 magnitude, direction-quantised non-maximum suppression and the double
+//                           threshold from one staged u8 tile; a wave is one 64-pixel row segment, and its two
+//                           ballots ARE the output: one 64-bit word of the `weak` plane and one of the `strong`
+//                           plane per (row, 64-column tile) -- 0.25 bit-plane bytes per pixel instead of 9
+//   canny_hyst_bits_kernel  hysteresis: a WAVE owns a 64-column x 62-row tile (+ ring), lane = row, register =
+//                           the row's 64 pixels; strong floods through weak | strong by whole row runs per step
+//                           (the carry of an addition walks a run in one instruction) and one row up / down per
+//                           step (DPP row shuffles) until the tile is stable -- no LDS, no barriers.  Tiles
+//                           talk through the planes: the launch is repeated until no tile changed (the host
+//                           polls one pinned word per batch of rounds, as OpenCV's CUDA Canny reads its counter)
+//   canny_edges_kernel      strong plane -> 0 / 255 bytes.
+// Same values as the byte-plane form it replaces (oracle_canny.c checks them): 8-connected hysteresis has one
+// fixed point whatever the order of propagation.
+#include <chrono>
+
 #include "kernels.hpp"
 
 namespace micv {
 
-__global__ __launch_bounds__(256) void gauss_u8_rows_kernel(const uint8_t *__restrict__ src,
-                                                             size_t stride, int rows, int cols,
-                                                             float *__restrict__ buf, Taps t) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const uint8_t *s = src + (size_t)y * stride;
-    const int a = t.n / 2;
-    float acc = 0.f;
-    for (int k = 0; k < t.n; k++) acc = fmaf((float)s[reflect101(x + k - a, cols)], t.k[k], acc);
-    buf[(size_t)y * cols + x] = acc;
+// ---- blur: cv::cuda::createGaussianFilter on CV_8U, BORDER_REFLECT_101; row pass then column pass, each an fmaf
+// chain from +0 with the taps in ascending order, float intermediate, round-to-nearest-even + saturate at the end.
+constexpr int GB_TW = 64, GB_TH = 16, GB_AMAX = 15;
+__global__ __launch_bounds__(256) void gauss_u8_tiled_kernel(const uint8_t *__restrict__ src, size_t stride, int rows,
+                                                              int cols, Taps t, uint8_t *__restrict__ dst,
+                                                              size_t dstride) {
+    __shared__ uint8_t S[(GB_TH + 2 * GB_AMAX) * (GB_TW + 2 * GB_AMAX)];
+    __shared__ float R[(GB_TH + 2 * GB_AMAX) * GB_TW];
+    const int a = t.n / 2, RW = GB_TW + 2 * a, RH = GB_TH + 2 * a;
+    const int x0 = blockIdx.x * GB_TW, y0 = blockIdx.y * GB_TH;
+    for (int i = threadIdx.x; i < RH * RW; i += 256) {  // the reflected source pixels, once
+        const int ly = i / RW, lx = i - ly * RW;
+        S[i] = src[(size_t)reflect101(y0 - a + ly, rows) * stride + reflect101(x0 - a + lx, cols)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RH * GB_TW; i += 256) {  // row pass on every staged row
+        const int ly = i / GB_TW, lx = i - ly * GB_TW;
+        const uint8_t *s = S + ly * RW + lx;
+        float acc = 0.f;
+        for (int k = 0; k < t.n; k++) acc = fmaf((float)s[k], t.k[k], acc);
+        R[i] = acc;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, x = x0 + lx;
+    if (x >= cols) return;
+    for (int ly = threadIdx.x >> 6; ly < GB_TH; ly += 4) {
+        const int y = y0 + ly;
+        if (y >= rows) break;
+        float acc = 0.f;
+        for (int k = 0; k < t.n; k++) acc = fmaf(R[(ly + k) * GB_TW + lx], t.k[k], acc);
+        const int r = __float2int_rn(acc);
+        dst[(size_t)y * dstride + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
 }
 
-__global__ __launch_bounds__(256) void gauss_u8_cols_kernel(const float *__restrict__ buf, int rows,
-                                                             int cols, Taps t,
-                                                             uint8_t *__restrict__ dst,
-                                                             size_t dstride) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const int a = t.n / 2;
-    float acc = 0.f;
-    for (int k = 0; k < t.n; k++)
-        acc = fmaf(buf[(size_t)reflect101(y + k - a, rows) * cols + x], t.k[k], acc);
-    const int r = __float2int_rn(acc);
-    dst[(size_t)y * dstride + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
-}
-
-// 3x3 Sobel (replicated border) -> packed (dx, dy) int16 pair and L1 magnitude.
-__global__ __launch_bounds__(256) void canny_grad_kernel(const uint8_t *__restrict__ src,
-                                                          size_t stride, int rows, int cols,
-                                                          int *__restrict__ mag,
-                                                          int *__restrict__ dxy) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const uint8_t *r0 = src + (size_t)clampi(y - 1, 0, rows - 1) * stride;
-    const uint8_t *r1 = src + (size_t)y * stride;
-    const uint8_t *r2 = src + (size_t)clampi(y + 1, 0, rows - 1) * stride;
-    const int xl = clampi(x - 1, 0, cols - 1), xr = clampi(x + 1, 0, cols - 1);
-    const int gx = (r0[xr] + 2 * r1[xr] + r2[xr]) - (r0[xl] + 2 * r1[xl] + r2[xl]);
-    const int gy = (r2[xl] + 2 * r2[x] + r2[xr]) - (r0[xl] + 2 * r0[x] + r0[xr]);
-    const size_t i = (size_t)y * cols + x;
-    mag[i] = abs(gx) + abs(gy);
-    dxy[i] = (gx & 0xFFFF) | (gy << 16);
-}
-
-// Non-maximum suppression along the quantised gradient direction + double threshold.
-__global__ __launch_bounds__(256) void canny_map_kernel(const int *__restrict__ mag,
-                                                         const int *__restrict__ dxy, int rows,
-                                                         int cols, int low, int high,
-                                                         uint8_t *__restrict__ map) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    auto M = [&](int yy, int xx) -> int {
-        return ((unsigned)yy >= (unsigned)rows || (unsigned)xx >= (unsigned)cols) ? 0 : mag[(size_t)yy * cols + xx];
+// ---- gradient, non-maximum suppression, double threshold -> the two bit planes
+// 3x3 Sobel with a replicated border, L1 magnitude; magnitudes outside the image count as 0 in the suppression;
+// direction by the integer tangent test (TG22 = tan 22.5 deg in 15-bit fixed point); weak: m > low, strong: m > high.
+constexpr int GM_TW = 64, GM_TH = 16;
+__global__ __launch_bounds__(256) void canny_gradmap_kernel(const uint8_t *__restrict__ src, size_t stride, int rows,
+                                                             int cols, int low, int high,
+                                                             unsigned long long *__restrict__ weak,
+                                                             unsigned long long *__restrict__ strong, int tiles_x) {
+    __shared__ uint8_t P[(GM_TH + 4) * (GM_TW + 4)];
+    __shared__ int Mg[(GM_TH + 2) * (GM_TW + 2)];
+    constexpr int PW = GM_TW + 4, MW = GM_TW + 2;
+    const int x0 = blockIdx.x * GM_TW, y0 = blockIdx.y * GM_TH;
+    for (int i = threadIdx.x; i < (GM_TH + 4) * PW; i += 256) {
+        const int ly = i / PW, lx = i - ly * PW;
+        P[i] = src[(size_t)clampi(y0 - 2 + ly, 0, rows - 1) * stride + clampi(x0 - 2 + lx, 0, cols - 1)];
+    }
+    __syncthreads();
+    auto sobel = [&](int py, int px, int &gx, int &gy) {  // P coordinates of the centre
+        const uint8_t *r0 = P + (py - 1) * PW + px, *r1 = r0 + PW, *r2 = r1 + PW;
+        gx = (r0[1] + 2 * r1[1] + r2[1]) - (r0[-1] + 2 * r1[-1] + r2[-1]);
+        gy = (r2[-1] + 2 * r2[0] + r2[1]) - (r0[-1] + 2 * r0[0] + r0[1]);
     };
-    const size_t i = (size_t)y * cols + x;
-    const int m = mag[i];
-    uint8_t out = 0;
-    if (m > low) {
-        const int p = dxy[i];
-        const int xs = (short)(p & 0xFFFF), ys = p >> 16;
-        const int ax = abs(xs), ay = abs(ys) << 15;
-        const int TG22 = 13573;  // (int)(0.41421356237 * (1 << 15) + 0.5)
-        const int tg22x = ax * TG22;
-        bool is_max;
-        if (ay < tg22x) {
-            is_max = m > M(y, x - 1) && m >= M(y, x + 1);
-        } else {
-            const int tg67x = tg22x + (ax << 16);
-            if (ay > tg67x) {
-                is_max = m > M(y - 1, x) && m >= M(y + 1, x);
-            } else {
-                const int s = (xs ^ ys) < 0 ? -1 : 1;
-                is_max = m > M(y - 1, x - s) && m > M(y + 1, x + s);
-            }
+    // Replicated border: the tile was staged from clamped coordinates, so the tap of an in-image centre (y, x) at
+    // (y + i, x + j) is src[clamp(y + i)][clamp(x + j)] -- what clamping the Sobel's own taps reads.
+    for (int i = threadIdx.x; i < (GM_TH + 2) * MW; i += 256) {
+        const int my = i / MW, mx = i - my * MW;
+        const int gy_ = y0 - 1 + my, gx_ = x0 - 1 + mx;
+        int m = 0;
+        if ((unsigned)gy_ < (unsigned)rows && (unsigned)gx_ < (unsigned)cols) {
+            int gx, gy;
+            sobel(my + 1, mx + 1, gx, gy);
+            m = abs(gx) + abs(gy);
         }
-        if (is_max) out = m > high ? 2 : 1;
+        Mg[i] = m;
     }
-    map[i] = out;
-}
-
-// One hysteresis round: every 32x32 tile (+1 halo) floods strong pixels (2) into 8-connected
-// candidates (1) inside LDS until the tile is stable, then writes back; *changed is set when a
-// tile promoted anything (its neighbours may need another round).
-__global__ __launch_bounds__(256) void canny_hyst_kernel(uint8_t *__restrict__ map, int rows, int cols,
-                                                          int *__restrict__ changed) {
-    __shared__ uint8_t t[34][36];
-    __shared__ int tile_changed, any;
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-    {   // all five loads per thread in flight at once (clamped addresses, zeroed outside the image)
-        uint8_t v[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int i = threadIdx.x + 256 * k < 34 * 34 ? threadIdx.x + 256 * k : 34 * 34 - 1;
-            const int ly = i / 34, lx = i - ly * 34;
-            const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-            const uint8_t m = map[(size_t)clampi(gy, 0, rows - 1) * cols + clampi(gx, 0, cols - 1)];
-            v[k] = ((unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols) ? m : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int i = threadIdx.x + 256 * k;
-            if (i < 34 * 34) t[i / 34][i % 34] = v[k];
-        }
-    }
-    if (threadIdx.x == 0) any = 0;
     __syncthreads();
-    {   // nothing to promote in a tile without candidates, or without a strong pixel in reach
-        bool weak = false, strong = false;
-        for (int i = threadIdx.x; i < 34 * 34; i += 256) {
-            const int ly = i / 34, lx = i - ly * 34;
-            const uint8_t m = t[ly][lx];
-            weak |= m == 1 && ly >= 1 && ly <= 32 && lx >= 1 && lx <= 32;
-            strong |= m == 2;
-        }
-        if (!__syncthreads_or(weak) || !__syncthreads_or(strong)) return;
-    }
-    for (;;) {
-        if (threadIdx.x == 0) tile_changed = 0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < 32 * 32; i += 256) {
-            const int ly = 1 + i / 32, lx = 1 + (i & 31);
-            if (t[ly][lx] == 1) {
-                const bool strong = t[ly - 1][lx - 1] == 2 || t[ly - 1][lx] == 2 || t[ly - 1][lx + 1] == 2 ||
-                                    t[ly][lx - 1] == 2 || t[ly][lx + 1] == 2 || t[ly + 1][lx - 1] == 2 ||
-                                    t[ly + 1][lx] == 2 || t[ly + 1][lx + 1] == 2;
-                if (strong) {
-                    t[ly][lx] = 2;  // monotone 1 -> 2: a racy read of the old value only delays it
-                    tile_changed = 1;
+    const int lx = threadIdx.x & 63, x = x0 + lx;
+    for (int ly = threadIdx.x >> 6; ly < GM_TH; ly += 4) {  // (wave-uniform: a wave is one row segment)
+        const int y = y0 + ly;
+        if (y >= rows) break;
+        int out = 0;
+        if (x < cols) {
+            const int *mc = Mg + (ly + 1) * MW + lx + 1;
+            const int m = mc[0];
+            if (m > low) {
+                int xs, ys;
+                sobel(ly + 2, lx + 2, xs, ys);
+                xs = (short)xs;  // the packed int16 pair of the byte-plane form: |g| <= 1020 fits
+                const int ax = abs(xs), ay = abs(ys) << 15;
+                const int TG22 = 13573;  // (int)(0.41421356237 * (1 << 15) + 0.5)
+                const int tg22x = ax * TG22;
+                bool is_max;
+                if (ay < tg22x) {
+                    is_max = m > mc[-1] && m >= mc[1];
+                } else {
+                    const int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) {
+                        is_max = m > mc[-MW] && m >= mc[MW];
+                    } else {
+                        const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+                        is_max = m > mc[-MW - sgn] && m > mc[MW + sgn];
+                    }
                 }
+                if (is_max) out = m > high ? 2 : 1;
             }
         }
-        __syncthreads();
-        const int c = tile_changed;
-        __syncthreads();
-        if (!c) break;
-        if (threadIdx.x == 0) any = 1;
-    }
-    __syncthreads();
-    if (any) {
-        for (int i = threadIdx.x; i < 32 * 32; i += 256) {
-            const int ly = 1 + i / 32, lx = 1 + (i & 31);
-            const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-            if (gy < rows && gx < cols) map[(size_t)gy * cols + gx] = t[ly][lx];
+        const unsigned long long w = __ballot(out == 1), st = __ballot(out == 2);
+        if (lx == 0) {
+            weak[(size_t)y * tiles_x + blockIdx.x] = w;
+            strong[(size_t)y * tiles_x + blockIdx.x] = st;
         }
-        if (threadIdx.x == 0) *changed = 1;
     }
 }
 
-__global__ __launch_bounds__(256) void canny_edges_kernel(const uint8_t *__restrict__ map, int rows,
-                                                           int cols, uint8_t *__restrict__ edges,
-                                                           size_t estride) {
+// ---- hysteresis on the bit planes: one wave per tile of 64 columns x 62 rows; lane l holds row y0 - 1 + l (lanes 0
+// and 63: the ring rows, read only), bit b column x0 + b; the ring columns are bit 63 of the word to the left and
+// bit 0 of the word to the right.  One step:
+//   D(row)  = the row's strong pixels dilated by one column, ring columns included
+//   seeds   = strong | weak & (D(row above) | D(row) | D(row below))
+//   strong' = seeds spread over their whole runs of (weak | strong) pixels, both ways: F + seeds carries through
+//             a run upwards, the bit-reversed sum downwards
+// until no lane changes.  Only the owned rows are written back.
+__device__ __forceinline__ unsigned long long run_fill(unsigned long long F, unsigned long long seeds) {
+    const unsigned long long s = seeds & F;
+    const unsigned long long up = ((F + s) ^ F) & F;
+    const unsigned long long Fr = __brevll(F), sr = __brevll(s);
+    const unsigned long long dn = __brevll(((Fr + sr) ^ Fr) & Fr);
+    return seeds | up | dn;
+}
+
+__global__ __launch_bounds__(64) void canny_hyst_bits_kernel(const unsigned long long *__restrict__ weak,
+                                                              unsigned long long *__restrict__ strong, int rows,
+                                                              int tiles_x, int *__restrict__ changed) {
+    const int lane = threadIdx.x, tx = blockIdx.x, y = blockIdx.y * 62 - 1 + lane;
+    const bool row_in = (unsigned)y < (unsigned)rows;
+    unsigned long long W = 0, S = 0, SL = 0, SR = 0;
+    if (row_in) {
+        const size_t o = (size_t)y * tiles_x + tx;
+        W = weak[o];
+        S = strong[o];
+        if (tx > 0) SL = strong[o - 1] >> 63;
+        if (tx + 1 < tiles_x) SR = strong[o + 1] << 63;
+    }
+    const unsigned long long S0 = S, F = W | S;
+    if (__ballot((W != 0) || false) == 0) return;  // no candidate in reach of this tile: nothing to promote
+    for (;;) {
+        const unsigned long long D = S | (S << 1) | (S >> 1) | SL | SR;
+        unsigned long long up = __shfl_up(D, 1), dn = __shfl_down(D, 1);
+        if (lane == 0) up = 0;
+        if (lane == 63) dn = 0;
+        const unsigned long long Sn = run_fill(F, S | (W & (D | up | dn)));
+        const bool ch = Sn != S;
+        S = Sn;
+        if (__ballot(ch) == 0) break;
+    }
+    const bool mine = row_in && lane >= 1 && lane <= 62 && S != S0;
+    if (mine) strong[(size_t)y * tiles_x + tx] = S;
+    if (__ballot(mine) != 0 && lane == 0) *changed = 1;
+}
+
+// the last kernel of a batch of rounds: tells the polling host that the batch's flags are final
+__global__ void canny_mark_kernel(int *done) { *done = 1; }
+
+__global__ __launch_bounds__(256) void canny_edges_kernel(const unsigned long long *__restrict__ strong, int rows, int cols,
+                                                           int tiles_x, uint8_t *__restrict__ edges, size_t estride) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
-    edges[(size_t)y * estride + x] = map[(size_t)y * cols + x] == 2 ? 255 : 0;
+    edges[(size_t)y * estride + x] = ((strong[(size_t)y * tiles_x + blockIdx.x] >> (threadIdx.x & 63)) & 1ull) ? 255 : 0;
 }
 
 }  // namespace micv
@@ -185,49 +204,55 @@ extern "C" int micv_generate_edge_dev(micv_ctx *ctx, const uint8_t *src, int row
     MICV_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)rows * cols;
+    const int tiles_x = cdiv(cols, 64);
+    const size_t nwords = (size_t)rows * tiles_x;
     void *scratch;
-    MICV_TRY(ctx->reserve(Carver::need(n, 4) * 3 + Carver::need(n, 1) * 2 + 256, &scratch));
+    MICV_TRY(ctx->reserve(Carver::need(n, 1) + Carver::need(nwords, 8) * 2 + 256, &scratch));
     Carver c(scratch);
-    float *buf = c.take<float>(n);
-    int *mag = c.take<int>(n), *dxy = c.take<int>(n);
-    uint8_t *blur = c.take<uint8_t>(n), *map = c.take<uint8_t>(n);
-    int *changed = c.take<int>(1);
-    const dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
+    uint8_t *blur = c.take<uint8_t>(n);
+    unsigned long long *weak = c.take<unsigned long long>(nwords), *strong = c.take<unsigned long long>(nwords);
     const uint8_t *cin = src;
     size_t cstride = stride;
     if (gauss_size > 1) {  // a 1-tap Gaussian is the identity (Solution.cpp's problem-2 setting)
         Taps t;
         gaussian_taps(gauss_size, gauss_sigma, &t);
-        gauss_u8_rows_kernel<<<grid, 256, 0, s>>>(src, stride, rows, cols, buf, t);
-        MICV_LAUNCH_CHECK();
-        gauss_u8_cols_kernel<<<grid, 256, 0, s>>>(buf, rows, cols, t, blur, (size_t)cols);
+        gauss_u8_tiled_kernel<<<dim3(cdiv(cols, GB_TW), cdiv(rows, GB_TH)), 256, 0, s>>>(src, stride, rows, cols, t, blur, (size_t)cols);
         MICV_LAUNCH_CHECK();
         cin = blur;
         cstride = cols;
     }
     double lo = low_thresh, hi = high_thresh;
     if (lo > hi) { const double tsw = lo; lo = hi; hi = tsw; }
-    canny_grad_kernel<<<grid, 256, 0, s>>>(cin, cstride, rows, cols, mag, dxy);
+    canny_gradmap_kernel<<<dim3(tiles_x, cdiv(rows, GM_TH)), 256, 0, s>>>(cin, cstride, rows, cols, (int)std::floor(lo), (int)std::floor(hi),
+                                                                         weak, strong, tiles_x);
     MICV_LAUNCH_CHECK();
-    canny_map_kernel<<<grid, 256, 0, s>>>(mag, dxy, rows, cols, (int)std::floor(lo), (int)std::floor(hi), map);
-    MICV_LAUNCH_CHECK();
-    int *h_changed = static_cast<int *>(ctx->pinned);
-    const int max_rounds = (int)(cdiv(cols, 32) * cdiv(rows, 32)) + 2;  // a path crosses each tile at most once per round
-    // Data-dependent loop: rounds are enqueued four at a time and the host reads ONE flag per batch
-    // (did the batch's last round still promote anything?).  A round after convergence changes
-    // nothing, so overshooting is harmless; a host round trip per round was most of the time.
-    constexpr int kBatch = 4;
+    // Data-dependent loop.  A round after convergence changes nothing, so rounds are enqueued kBatch at a time and the
+    // host looks at ONE word per batch: did its last round still promote anything?  The words live in pinned host
+    // memory the kernels write directly (no copy back); word kBatch is stored by a one-thread kernel behind the
+    // batch, and the host polls it instead of paying a stream synchronisation.
+    volatile int *flags = static_cast<volatile int *>(ctx->pinned);
+    const int max_rounds = (int)(tiles_x * cdiv(rows, 62)) + 2;  // a path crosses each tile at most once per round
+    constexpr int kBatch = 3;
+    const dim3 hgrid(tiles_x, cdiv(rows + 1, 62));
     for (int round = 0; round < max_rounds; round += kBatch) {
+        for (int b = 0; b <= kBatch; b++) flags[b] = 0;
         for (int b = 0; b < kBatch; b++) {
-            MICV_HIP(hipMemsetAsync(changed, 0, 4, s));
-            canny_hyst_kernel<<<dim3(cdiv(cols, 32), cdiv(rows, 32)), 256, 0, s>>>(map, rows, cols, changed);
+            canny_hyst_bits_kernel<<<hgrid, 64, 0, s>>>(weak, strong, rows, tiles_x, const_cast<int *>(flags) + b);
             MICV_LAUNCH_CHECK();
         }
-        MICV_HIP(hipMemcpyAsync(h_changed, changed, 4, hipMemcpyDeviceToHost, s));
-        MICV_HIP(hipStreamSynchronize(s));
-        if (!*h_changed) break;
+        canny_mark_kernel<<<1, 1, 0, s>>>(const_cast<int *>(flags) + kBatch);
+        MICV_LAUNCH_CHECK();
+        // poll the marker (a stream synchronisation costs ~25 us on this stack, the store is seen after ~3); after
+        // 5 ms fall back to the synchronisation, which also surfaces a failed launch
+        const auto t0 = std::chrono::steady_clock::now();
+        while (!flags[kBatch])
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+                MICV_HIP(hipStreamSynchronize(s));
+                break;
+            }
+        if (!flags[kBatch - 1]) break;
     }
-    canny_edges_kernel<<<grid, 256, 0, s>>>(map, rows, cols, edges, estride);
+    canny_edges_kernel<<<dim3(tiles_x, cdiv(rows, 4)), 256, 0, s>>>(strong, rows, cols, tiles_x, edges, estride);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }

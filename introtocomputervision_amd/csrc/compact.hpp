@@ -91,45 +91,31 @@ constexpr unsigned long long kCompactAgg = 1ull << 32, kCompactInc = 2ull << 32;
 constexpr int kChunk1 = 4096;  // elements per workgroup of the one-launch form (256 threads x 16)
 
 // 4096 elements per workgroup and a look-back by the whole workgroup (256 predecessors per step).
-template <typename Pred, typename Emit>
-__global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit emit, int64_t n, int nchunks,
-                                                               unsigned long long *__restrict__ status,
-                                                               unsigned *__restrict__ counters, int64_t cap,
-                                                               int64_t *__restrict__ count) {
-    constexpr int J = kChunk1 / 256;
-    static_assert(J * 4 == 64, "one (j, wave) slot per lane of the scanning wave");
-    __shared__ int wcount[J * 4];  // hits of slot (j, wave), then their exclusive prefix: slot order == index order
-    __shared__ unsigned s_chunk, s_last;
-    __shared__ int s_total, s_first[4];
-    __shared__ long long s_part[4];
+// The shared state and the two steps every one-launch kernel runs between counting and writing its hits.
+struct CompactShared {
+    int wcount[64];  // hits of slot (j, wave), then their exclusive prefix: slot order == index order
+    unsigned s_chunk, s_last;
+    int s_total, s_first[4];
+    long long s_part[4];
+};
+
+// After wcount[] holds the chunk's 64 slot counts (and a barrier): turns them into exclusive prefixes, publishes the
+// chunk's count, finds the chunk's offset by the look-back, publishes its running total (and the grand total from
+// the last chunk).  Returns the offset of the chunk's first hit; every thread of the workgroup calls it.
+__device__ __forceinline__ long long compact_chunk_offset(CompactShared &sh, int chunk, int nchunks,
+                                                          unsigned long long *__restrict__ status, int64_t *__restrict__ count) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_chunk = atomicAdd(&counters[0], 1u);
-    __syncthreads();
-    const int chunk = (int)s_chunk;
-    const int64_t base = (int64_t)chunk * kChunk1;
-    unsigned hits = 0;
-    int before[J];
-#pragma unroll
-    for (int j = 0; j < J; j++) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        const bool hit = i < n && pred(i);
-        const unsigned long long m = __ballot(hit);
-        before[j] = __popcll(m & ((1ull << lane) - 1ull));
-        hits |= (unsigned)hit << j;
-        if (lane == 0) wcount[j * 4 + wave] = __popcll(m);
-    }
-    __syncthreads();
     if (wave == 0) {
-        const int c = wcount[lane];
+        const int c = sh.wcount[lane];
         int incl = c;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
-        wcount[lane] = incl - c;
+        sh.wcount[lane] = incl - c;
         if (lane == 63) {
-            s_total = incl;
+            sh.s_total = incl;
             __hip_atomic_store(&status[chunk], (chunk == 0 ? kCompactInc : kCompactAgg) | (unsigned)incl, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -144,50 +130,136 @@ __global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit em
             } while ((st >> 32) == 0);
         }
         const unsigned long long inc = __ballot((st & kCompactInc) != 0);
-        if (lane == 0) s_first[wave] = inc ? __ffsll((long long)inc) - 1 : 64;  // nearest running total in this wave
+        if (lane == 0) sh.s_first[wave] = inc ? __ffsll((long long)inc) - 1 : 64;  // nearest running total in this wave
         __syncthreads();
         int fw = 4;  // first wave (nearest 64 predecessors first) that saw a running total
 #pragma unroll
         for (int w = 3; w >= 0; w--)
-            if (s_first[w] < 64) fw = w;
-        long long v = (wave < fw || (wave == fw && lane <= s_first[wave])) ? (long long)(unsigned)st : 0;
+            if (sh.s_first[w] < 64) fw = w;
+        long long v = (wave < fw || (wave == fw && lane <= sh.s_first[wave])) ? (long long)(unsigned)st : 0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
-        if (lane == 0) s_part[wave] = v;
+        if (lane == 0) sh.s_part[wave] = v;
         __syncthreads();
-        excl += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        excl += sh.s_part[0] + sh.s_part[1] + sh.s_part[2] + sh.s_part[3];
         __syncthreads();  // s_first / s_part are rewritten by the next step
         if (fw < 4) break;
     }
     __syncthreads();  // wcount's prefix and s_total (chunk 0 takes no step above)
     if (threadIdx.x == 0) {
         if (chunk > 0)
-            __hip_atomic_store(&status[chunk], kCompactInc | (unsigned long long)(excl + s_total), __ATOMIC_RELAXED,
+            __hip_atomic_store(&status[chunk], kCompactInc | (unsigned long long)(excl + sh.s_total), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        if (chunk == nchunks - 1) *count = excl + s_total;
+        if (chunk == nchunks - 1) *count = excl + sh.s_total;
     }
-#pragma unroll
-    for (int j = 0; j < J; j++) {
-        if (!((hits >> j) & 1)) continue;
-        const int64_t pos = excl + wcount[j * 4 + wave] + before[j];
-        if (pos < cap) emit(pos, base + j * 256 + threadIdx.x);
-    }
-    // the last chunk out leaves the state as it found it: all zero.  Thread 0 is the one that stored this chunk's
-    // status words (sc1 stores): it waits for their acknowledgement before it counts the chunk out, so no such
-    // store can still be on its way when the last chunk zeroes the words (a wait, not a fence -- an
-    // agent-scope release would write back the whole L2 once per chunk).
+    return excl;
+}
+
+// The last chunk out leaves the state as it found it: all zero.  Thread 0 is the one that stored this chunk's status
+// words (sc1 stores): it waits for their acknowledgement before it counts the chunk out, so no such store can still
+// be on its way when the last chunk zeroes the words (a wait, not a fence -- an agent-scope release would
+// write back the whole L2 once per chunk).
+__device__ __forceinline__ void compact_chunk_exit(CompactShared &sh, int nchunks, unsigned long long *__restrict__ status,
+                                                   unsigned *__restrict__ counters) {
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = atomicAdd(&counters[1], 1u) == (unsigned)(nchunks - 1);
+        sh.s_last = atomicAdd(&counters[1], 1u) == (unsigned)(nchunks - 1);
     }
     __syncthreads();
-    if (s_last) {
+    if (sh.s_last) {
         for (int i = threadIdx.x; i < nchunks; i += 256) status[i] = 0;
         if (threadIdx.x == 0) {
             counters[0] = 0;
             counters[1] = 0;
         }
     }
+}
+
+template <typename Pred, typename Emit>
+__global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit emit, int64_t n, int nchunks,
+                                                               unsigned long long *__restrict__ status,
+                                                               unsigned *__restrict__ counters, int64_t cap,
+                                                               int64_t *__restrict__ count) {
+    constexpr int J = kChunk1 / 256;
+    static_assert(J * 4 == 64, "one (j, wave) slot per lane of the scanning wave");
+    __shared__ CompactShared sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sh.s_chunk = atomicAdd(&counters[0], 1u);
+    __syncthreads();
+    const int chunk = (int)sh.s_chunk;
+    const int64_t base = (int64_t)chunk * kChunk1;
+    unsigned hits = 0;
+    int before[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        const bool hit = i < n && pred(i);
+        const unsigned long long m = __ballot(hit);
+        before[j] = __popcll(m & ((1ull << lane) - 1ull));
+        hits |= (unsigned)hit << j;
+        if (lane == 0) sh.wcount[j * 4 + wave] = __popcll(m);
+    }
+    __syncthreads();
+    const long long excl = compact_chunk_offset(sh, chunk, nchunks, status, count);
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        if (!((hits >> j) & 1)) continue;
+        const int64_t pos = excl + sh.wcount[j * 4 + wave] + before[j];
+        if (pos < cap) emit(pos, base + j * 256 + threadIdx.x);
+    }
+    compact_chunk_exit(sh, nchunks, status, counters);
+}
+
+// The same chained scan over 64-bit MASKS (r04): element i stands for 64 consecutive cells of an image row and
+// contributes popcount(masks[i]) hits -- its set bits in ascending order.  The NMS kernels write one mask per
+// (row, 64-column tile) by wave ballot, so the ordered corner list of a 4K frame is a scan over 130 k words in 32
+// chunks instead of 8.3 M flag bytes in three launches.  emit(pos, i, bit).
+template <typename Emit>
+__global__ __launch_bounds__(256) void compact_masks_onepass_kernel(const unsigned long long *__restrict__ masks, Emit emit,
+                                                                     int64_t n, int nchunks,
+                                                                     unsigned long long *__restrict__ status,
+                                                                     unsigned *__restrict__ counters, int64_t cap,
+                                                                     int64_t *__restrict__ count) {
+    constexpr int J = kChunk1 / 256;
+    __shared__ CompactShared sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sh.s_chunk = atomicAdd(&counters[0], 1u);
+    __syncthreads();
+    const int chunk = (int)sh.s_chunk;
+    const int64_t base = (int64_t)chunk * kChunk1;
+    unsigned long long m[J];
+    int before[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) {  // all loads in flight first
+        const int64_t i = base + j * 256 + threadIdx.x;
+        m[j] = i < n ? masks[i] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const int c = __popcll(m[j]);
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        before[j] = incl - c;
+        if (lane == 63) sh.wcount[j * 4 + wave] = incl;
+    }
+    __syncthreads();
+    const long long excl = compact_chunk_offset(sh, chunk, nchunks, status, count);
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        unsigned long long mm = m[j];
+        int64_t pos = excl + sh.wcount[j * 4 + wave] + before[j];
+        while (mm) {  // a handful of set bits at most in practice (strict maxima are sparse)
+            const int bit = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            if (pos < cap) emit(pos, base + j * 256 + threadIdx.x, bit);
+            pos++;
+        }
+    }
+    compact_chunk_exit(sh, nchunks, status, counters);
 }
 
 inline size_t compact_scratch_bytes(int64_t n) {

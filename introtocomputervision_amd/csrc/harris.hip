@@ -227,29 +227,34 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float *__restrict
                                                           int rstride, int rows, int cols,
                                                           double threshold, int d,
                                                           float *__restrict__ corners, int cstride,
-                                                          uint8_t *__restrict__ flag) {
+                                                          unsigned long long *__restrict__ rowmask, int tiles_x) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= cols || y >= rows) return;
-    const float v = resp[(size_t)y * rstride + x];
+    const bool in = x < cols && y < rows;
     bool keep = false;
-    if ((double)v >= threshold) {
-        keep = true;
-        for (int wy = -d; wy <= d && keep; wy++) {
-            const int cy = clampi(y + wy, 0, rows - 1);
-            const float *row = resp + (size_t)cy * rstride;
-            for (int wx = -d; wx <= d; wx++) {
-                const int cx = clampi(x + wx, 0, cols - 1);
-                if (cy == y && cx == x) continue;
-                if (v <= row[cx]) {
-                    keep = false;
-                    break;
+    float v = 0.f;
+    if (in) {
+        v = resp[(size_t)y * rstride + x];
+        keep = (double)v >= threshold;  // Harris.cpp:115 (double compare)
+        if (keep) {
+            for (int wy = -d; wy <= d && keep; wy++) {
+                const int cy = clampi(y + wy, 0, rows - 1);
+                const float *row = resp + (size_t)cy * rstride;
+                for (int wx = -d; wx <= d; wx++) {
+                    const int cx = clampi(x + wx, 0, cols - 1);
+                    if (cy == y && cx == x) continue;
+                    if (v <= row[cx]) {
+                        keep = false;
+                        break;
+                    }
                 }
             }
         }
+        corners[(size_t)y * cstride + x] = keep ? v : 0.f;
     }
-    corners[(size_t)y * cstride + x] = keep ? v : 0.f;
-    flag[(size_t)y * cols + x] = keep ? 1 : 0;
+    // a wave = 64 consecutive cells of one row: its ballot is that row segment's mask (compact.hpp)
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && y < rows) rowmask[(size_t)y * tiles_x + blockIdx.x] = m;
 }
 
 // LDS-tiled form for minDistance <= 16: "strictly greater than every other pixel of the clamped
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
                                                                 double threshold, int d_rt,
                                                                 float *__restrict__ corners,
                                                                 int cstride,
-                                                                uint8_t *__restrict__ flag) {
+                                                                unsigned long long *__restrict__ rowmask, int tiles_x) {
     constexpr int TW = 64, TH = DT > 0 ? 32 : 16, DMAX = DT > 0 ? DT : 16;  // taller tiles re-fetch less halo
     const int d = DT > 0 ? DT : d_rt;
     __shared__ float T[(TH + 2 * DMAX) * (TW + 2 * DMAX + 1)];
@@ -343,8 +348,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         __syncthreads();
         // column pass: job = (column, group of four rows)
         const int c = threadIdx.x & 63, x = x0 + c;
-        if (x >= cols) return;
-        for (int rg = threadIdx.x >> 6; rg < TH / 4; rg += 4) {
+        for (int rg = threadIdx.x >> 6; rg < TH / 4; rg += 4) {  // (wave-uniform: a wave is one 64-cell row segment)
             const int ry0 = 4 * rg;
             if (y0 + ry0 >= rows) break;
             float v[4 + 2 * DT];
@@ -360,11 +364,12 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int y = y0 + ry0 + j;
-                if (y < rows) {
+                if (y < rows) {  // (wave-uniform)
                     const float pv = T[(ry0 + j + DT) * TS + c + DT];
-                    const bool keep = (double)pv >= threshold && pv == M[j] && N[j] == 1;
-                    corners[(size_t)y * cstride + x] = keep ? pv : 0.f;
-                    flag[(size_t)y * cols + x] = keep ? 1 : 0;
+                    const bool keep = x < cols && (double)pv >= threshold && pv == M[j] && N[j] == 1;
+                    if (x < cols) corners[(size_t)y * cstride + x] = keep ? pv : 0.f;
+                    const unsigned long long m = __ballot(keep);  // the row segment's mask (compact.hpp)
+                    if (c == 0) rowmask[(size_t)y * tiles_x + blockIdx.x] = m;
                 }
             }
         }
@@ -383,8 +388,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
     }
     __syncthreads();
     const int c = threadIdx.x & 63, x = x0 + c;
-    if (x >= cols) return;
-    for (int ry = threadIdx.x >> 6; ry < TH; ry += 4) {
+    for (int ry = threadIdx.x >> 6; ry < TH; ry += 4) {  // (wave-uniform)
         const int y = y0 + ry;
         if (y >= rows) break;
         float M = -INFINITY;
@@ -392,15 +396,36 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         int N = 0;
         for (int k = 0; k <= 2 * d; k++) N += RM[(ry + k) * TW + c] == M ? RN[(ry + k) * TW + c] : 0;
         const float v = T[(ry + d) * TS + c + d];
-        const bool keep = (double)v >= threshold && v == M && N == 1;
-        corners[(size_t)y * cstride + x] = keep ? v : 0.f;
-        flag[(size_t)y * cols + x] = keep ? 1 : 0;
+        const bool keep = x < cols && (double)v >= threshold && v == M && N == 1;
+        if (x < cols) corners[(size_t)y * cstride + x] = keep ? v : 0.f;
+        const unsigned long long m = __ballot(keep);
+        if (c == 0) rowmask[(size_t)y * tiles_x + blockIdx.x] = m;
     }
+}
+
+// masks -> one flag byte per cell (the fallback when no one-launch state slot is free: the three-launch form below
+// then runs on the flags)
+__global__ __launch_bounds__(256) void masks_to_flags_kernel(const unsigned long long *__restrict__ masks, int rows, int cols,
+                                                              int tiles_x, uint8_t *__restrict__ flag) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    flag[(size_t)y * cols + x] = (masks[(size_t)y * tiles_x + blockIdx.x] >> (threadIdx.x & 63)) & 1ull;
 }
 
 struct FlagPred {
     const uint8_t *flag;
     __device__ bool operator()(int64_t i) const { return flag[i] != 0; }
+};
+// mask word i = row i / tiles_x, columns 64 (i % tiles_x) ..: its set bit b is corner (y, x) -- Harris.cu:314-318
+struct MaskYxEmit {
+    int32_t *locs;
+    int tiles_x;
+    __device__ void operator()(int64_t pos, int64_t i, int bit) const {
+        const int y = (int)(i / tiles_x);
+        locs[2 * pos] = y;
+        locs[2 * pos + 1] = 64 * (int)(i - (int64_t)y * tiles_x) + bit;
+    }
 };
 
 // ---- a11 ------------------------------------------------------------------------------------
@@ -499,17 +524,22 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
     MICV_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)rows * cols;
+    // The NMS kernels leave one 64-bit mask per (row, 64-column tile) -- a wave is exactly such a row segment, its
+    // ballot the mask -- and the ordered list is a chained scan over those words (compact_masks_onepass_kernel):
+    // 130 k words in 32 chunks at 4K, where the flag-byte form scanned 8.3 M bytes in three launches.
+    const int tiles_x = cdiv(cols, 64);
+    const int64_t nseg = (int64_t)rows * tiles_x;
     void *scratch;
-    MICV_TRY(ctx->reserve(Carver::need(n, 1) + compact_scratch_bytes(n), &scratch));
+    MICV_TRY(ctx->reserve(Carver::need(nseg, 8) + Carver::need(n, 1) + compact_scratch_bytes(n), &scratch));
     Carver c(scratch);
-    uint8_t *flag = c.take<uint8_t>(n);
+    unsigned long long *rowmask = c.take<unsigned long long>(nseg);
     const bool force_scan = ctx->opt[MICV_OPT_NMS_SCAN] != 0;
     if (min_distance <= 16 && !force_scan) {
 #define MICV_NMS(DT)                                                                             \
-    harris_nms_tiled_kernel<DT><<<dim3(cdiv(cols, 64), cdiv(rows, (DT) > 0 ? 32 : 16)), 256, 0, s>>>(     \
+    harris_nms_tiled_kernel<DT><<<dim3(tiles_x, cdiv(rows, (DT) > 0 ? 32 : 16)), 256, 0, s>>>(     \
         resp, (int)(rstride / 4), rows, cols,                                                     \
                                                      threshold, min_distance, corners,             \
-                                                     (int)(cstride / 4), flag)
+                                                     (int)(cstride / 4), rowmask, tiles_x)
         switch (min_distance) {
             case 1: MICV_NMS(1); break;
             case 2: MICV_NMS(2); break;
@@ -524,12 +554,25 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
 #undef MICV_NMS
     }
     else
-        harris_nms_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(
+        harris_nms_kernel<<<dim3(tiles_x, cdiv(rows, 4)), 256, 0, s>>>(
             resp, (int)(rstride / 4), rows, cols, threshold, min_distance, corners,
-            (int)(cstride / 4), flag);
+            (int)(cstride / 4), rowmask, tiles_x);
+    MICV_LAUNCH_CHECK();
+    const int nchunks = (int)((nseg + kChunk1 - 1) / kChunk1);
+    unsigned long long *status = nullptr;
+    unsigned *counters = nullptr;
+    if (ctx->opt[MICV_OPT_COMPACT_3PASS] <= 0 && ctx->compact_state(s, nchunks, &status, &counters) == MICV_OK) {
+        compact_masks_onepass_kernel<<<nchunks, 256, 0, s>>>(rowmask, MaskYxEmit{locs_yx, tiles_x}, nseg, nchunks, status, counters, cap,
+                                                             count);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
+    // no state slot for this stream (or MICV_OPT_COMPACT_3PASS = 1): flag bytes and the count / scan / emit launches
+    uint8_t *flag = c.take<uint8_t>(n);
+    masks_to_flags_kernel<<<dim3(tiles_x, cdiv(rows, 4)), 256, 0, s>>>(rowmask, rows, cols, tiles_x, flag);
     MICV_LAUNCH_CHECK();
     // (y, x) written directly, Harris.cu:314-318 (Conv1Dto2D)
-    return ordered_compact(ctx, s, FlagPred{flag}, YxEmit{locs_yx, cols}, n, cap, count, c.base + c.off);
+    return ordered_compact3(s, FlagPred{flag}, YxEmit{locs_yx, cols}, n, cap, count, c.base + c.off);
 }
 
 int micv_sift_angles_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,

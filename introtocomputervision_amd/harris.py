@@ -70,7 +70,8 @@ def refineCorners(cornerResponse, threshold, minDistance, capacity=None, ctx=Non
     if B.is_dev(cornerResponse):
         import torch
         locs = torch.empty((cap, 2), dtype=torch.int32, device=cornerResponse.device)
-        cnt = torch.zeros((1,), dtype=torch.int64, device=cornerResponse.device)
+        # the count: a device word when the caller keeps it on the device, else a pinned host word the kernel writes
+        cnt = torch.zeros((1,), dtype=torch.int64, device=cornerResponse.device) if lazy else B.pinned_count(cornerResponse)
         check(lib.micv_harris_refine_dev(c.handle, B.ptr(cornerResponse), rows, cols,
                                          B.stride_bytes(cornerResponse), float(threshold),
                                          int(minDistance), B.ptr(corners), B.stride_bytes(corners),
@@ -78,7 +79,7 @@ def refineCorners(cornerResponse, threshold, minDistance, capacity=None, ctx=Non
                                          B.stream_of(cornerResponse)))
         if lazy:
             return corners, locs, cnt
-        n = min(int(cnt.item()), cap)
+        n = min(B.read_count(cnt, cornerResponse), cap)
         return corners, locs[:n]
     locs = np.empty((cap, 2), np.int32)
     cnt = i64(0)

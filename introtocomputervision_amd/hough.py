@@ -65,12 +65,12 @@ def findLocalMaxima(accumulator, numPeaks, threshold, ctx=None, lazy=False):
     if B.is_dev(accumulator):
         import torch
         peaks = torch.empty((max(k, 1), 2), dtype=torch.int32, device=accumulator.device)
-        cnt = torch.zeros((1,), dtype=torch.int64, device=accumulator.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=accumulator.device) if lazy else B.pinned_count(accumulator)
         check(lib.micv_hough_peaks_dev(c.handle, B.ptr(accumulator), rows, cols, k, int(threshold),
                                        peaks.data_ptr(), cnt.data_ptr(), B.stream_of(accumulator)))
         if lazy:
             return peaks, cnt
-        return peaks[:int(cnt.item())]
+        return peaks[:B.read_count(cnt, accumulator)]
     peaks = np.empty((max(k, 1), 2), np.uint32)
     cnt = i64(0)
     check(lib.micv_hough_peaks_host(c.handle, B.ptr(accumulator), rows, cols, k, int(threshold),
