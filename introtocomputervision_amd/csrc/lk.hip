@@ -844,7 +844,10 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // at level-0 size per pair, and the generic path's temporaries.
     const size_t flow_elems = (n0 + 63) & ~size_t(63);
     size_t total = Carver::need(plan.pyr_elems * batch, 4) * 2 + Carver::need(flow_elems * batch, 4) * 4;
-    if (!fused) total += Carver::need(n0, 4) * 3 + Carver::need(lk_generic_scratch(rows, cols), 4);
+    // Generic path: the pairs of a batch run on up to four forked streams (r04), each with its own temporaries: the
+    // coarse levels are launches of a few workgroups whose time is latency, and the pairs' launches overlap.
+    const int gen_groups = fused ? 0 : (batch < 4 ? batch : 4);
+    if (!fused) total += (Carver::need(n0, 4) * 3 + Carver::need(lk_generic_scratch(rows, cols), 4)) * gen_groups;
     void *base;
     MICV_TRY(ctx->reserve(total, &base));
     Carver carve(base);
@@ -908,10 +911,23 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     };
 
     if (!fused) {
-        float *warped = carve.take<float>(n0), *tmp_a = carve.take<float>(n0), *tmp_b = carve.take<float>(n0);
-        float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
         ctx->prof_pairs = batch;
-        return lk_chain_generic(ctx, plan, make_chain(s, 0, batch, true), win, warped, gen, tmp_a, tmp_b);
+        if (gen_groups > 1) MICV_TRY(ctx->fork(s, gen_groups - 1));
+        int rc = MICV_OK;
+        for (int g = 0; g < gen_groups && rc == MICV_OK; g++) {
+            float *warped = carve.take<float>(n0), *tmp_a = carve.take<float>(n0), *tmp_b = carve.take<float>(n0);
+            float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
+            const int b0 = (int)((long long)batch * g / gen_groups);
+            const int nb = (int)((long long)batch * (g + 1) / gen_groups) - b0;
+            if (g == 0) ctx->prof_pairs = nb;  // the profiled launches are group 0's
+            rc = lk_chain_generic(ctx, plan, make_chain(g == 0 ? s : ctx->aux_stream[g - 1], b0, nb, g == 0), win, warped, gen,
+                                  tmp_a, tmp_b);
+        }
+        if (gen_groups > 1) {  // always re-join, also after an error
+            const int rcj = ctx->join(s, gen_groups - 1);
+            if (rc == MICV_OK) rc = rcj;
+        }
+        return rc;
     }
 
     // Fused path: the batch is split into groups of pairs whose chains run on forked HIP streams and

@@ -92,7 +92,9 @@ __device__ __forceinline__ int cv_round_i32(float v) {
 //  * FS = 32 for a flow given as such; FS = 64 when the caller hands over HALF the flow (pyrUp's value
 //    before OpticalFlow.cpp:142's "* 2"): (2 a) * 32 = a * 64 exactly, so the doubling costs nothing
 //    where only the warp needs it (the halo pixels of a tile).
-template <int NW, int NH, int FS = 32>
+// ASM_TAPS: the four window taps are read by hand-placed ds_read2_b32 + an explicit wait (tiles whose prev DMA is
+// still in flight: a tap the compiler can see would wait for that DMA too, lk_fused.hip DEFER).
+template <int NW, int NH, int FS = 32, bool ASM_TAPS = false>
 __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N, int nx0, int ny0,
                                                     const float *__restrict__ src, int rows,
                                                     int cols, int stride,
@@ -129,10 +131,22 @@ __device__ __forceinline__ float warp_sample_staged(const float *__restrict__ N,
         asm("" : "+s"(nbase));
         lds_cfloat *p = (lds_cfloat *)(size_t)(nbase + 4 * cell);
         asm("" : "+v"(p));
-        v0 = p[0];
-        v1 = p[1];
-        v2 = p[NW];
-        v3 = p[NW + 1];
+        if constexpr (ASM_TAPS) {
+            static_assert(NW + 1 < 256, "ds_read2_b32 offsets are 8 bits");
+            v2f_ t01, t23;
+            asm volatile("ds_read2_b32 %0, %1 offset0:0 offset1:1" : "=v"(t01) : "v"(p) : "memory");
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(t23) : "v"(p), "n"(NW), "n"(NW + 1) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t01), "+v"(t23));
+            v0 = t01.x;
+            v1 = t01.y;
+            v2 = t23.x;
+            v3 = t23.y;
+        } else {
+            v0 = p[0];
+            v1 = p[1];
+            v2 = p[NW];
+            v3 = p[NW + 1];
+        }
     } else {
         // cvRound proper (INT_MIN for NaN and beyond the int range: every tap is then the border
         // constant), cell and fraction from its integer result as cv::remap forms them

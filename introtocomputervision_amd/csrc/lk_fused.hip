@@ -344,8 +344,60 @@ __device__ __forceinline__ void col_bases(const float *rb0, int c, int r0, int (
         cls[k] = base + 4 * (r0 * C::RBS + 4 * ((c >> 2) ^ (2 * ((r0 + k) & 3))) + (c & 3));
 }
 
+// [A, B) as an integer_sequence
+template <int A, int... I>
+constexpr std::integer_sequence<int, (A + I)...> offset_seq(std::integer_sequence<int, I...>) { return {}; }
+template <int A, int B>
+using range_seq = decltype(offset_seq<A>(std::make_integer_sequence<int, B - A>{}));
+
+// s_waitcnt lgkmcnt(N) naming up to four destinations (N = LDS operations that may still be outstanding)
+template <int N>
+__device__ __forceinline__ void lds_wait_upto4(v2f &a, v2f &b, v2f &c, v2f &d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+#ifndef MICV_LK_COL_FULLWAIT
+// Column pass with PARTIAL waits (r04; -DMICV_LK_COL_FULLWAIT builds the single-wait form for A/B:
+// level-0 launch 199.0 -> 197.1 us in every one of four interleaved rounds, profiles/r04/lk_ab.txt): the loads return in order, pairs 0-3 hold
+// staged rows 0..7, pairs 4-7 rows 8..15, pairs 8-9 rows 16..21.  The first chain's first eight steps need rows
+// 0..7 only, so they start when four loads have landed instead of ten; the rest follows the second and third wait.
+// Window 15 at four outputs per thread only (the 64x32 tile); every output still runs its chain over taps 0..2R in
+// order -- same bits.
 template <typename C, int F>
+__device__ __forceinline__ void col_pass_partial(const int (&cls)[4], float (&S)[C::RPT], const TapsN<C::W> &g) {
+    constexpr int NV = C::RPT + 2 * C::R, NP = ((NV + 7) / 8) * 4, W = C::W;
+    static_assert(C::RPT == 4 && C::R == 7 && NP == 12, "written for the 64x32 window-15 tile");
+    v2f V[NP];
+    // scalar loads share the counter and return out of order: none may be outstanding while partial counts are used
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    col_load_all<C, F>(V, cls, std::make_integer_sequence<int, NP>{});  // 10 loads issued (pairs 10, 11 are constants)
+    v2f acc0, acc1;
+    lds_wait_upto4<6>(V[0], V[1], V[2], V[3]);
+    skew_chain<SlotStride4, W, NP, 0>(acc0, V, g, range_seq<0, 8>{});
+    lds_wait_upto4<2>(V[4], V[5], V[6], V[7]);
+    skew_chain<SlotStride4, W, NP, 0>(acc0, V, g, range_seq<8, W + 1>{});
+    skew_chain<SlotStride4, W, NP, 2>(acc1, V, g, range_seq<0, 14>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[8]), "+v"(V[9]));
+    skew_chain<SlotStride4, W, NP, 2>(acc1, V, g, range_seq<14, W + 1>{});
+    S[0] = acc0.x;
+    S[1] = acc0.y;
+    S[2] = acc1.x;
+    S[3] = acc1.y;
+}
+#endif
+
+// PARTIAL (lk_tile's PARTIAL_COLS, set by lk_level_kernel only): only where the compiler keeps scalar loads out of the
+// counted window -- the plain kernel; in the chain /
+// streamed kernels it re-loads the taps there under SGPR pressure (tools/audit_asm_loads.py finds such loads and
+// fails the build's test), and a scalar load returning out of order would break a partial count.
+template <typename C, int F, bool PARTIAL = false>
 __device__ __forceinline__ void col_pass(const int (&cls)[4], float (&S)[C::RPT], const TapsN<C::W> &g) {
+#ifndef MICV_LK_COL_FULLWAIT
+    if constexpr (PARTIAL && C::RPT == 4 && C::R == 7) {
+        col_pass_partial<C, F>(cls, S, g);
+        return;
+    }
+#endif
     constexpr int NV = C::RPT + 2 * C::R, NP = ((NV + 7) / 8) * 4;
     static_assert(C::RPT % 2 == 0, "column outputs in pairs");
     // pairs wholly past the window (a suffix of V) are constants: keep them out of the wait, which would make
@@ -552,7 +604,7 @@ __device__ __forceinline__ void lk_stage_ahead(const LkLevelArgs &a, float *lds,
 // STREAM: the tile runs in lk_level_stream_kernel's loop (its window and coarse block were staged ahead).
 // GATHER: the level's images are read from pyramid level 0 with a pixel stride (a.img_xstride; above).
 template <int R, int MODE, bool INT, int NTV, bool CARRY = false, int THV = 32, bool STREAM = false,
-          bool IN_LOOP = CARRY || STREAM, bool GATHER = false>
+          bool IN_LOOP = CARRY || STREAM, bool GATHER = false, bool PARTIAL_COLS = false>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
                                         float *lds, int tile_x, int tile_y, int pair, bool more = false,
                                         LkStreamLink *link = nullptr) {
@@ -575,6 +627,17 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     constexpr bool CDMA = STREAM || (INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY);
     constexpr int CBF = CDMA ? C::CS_F : (CARRY ? C::CC_F : C::C_F);  // floats of the coarse block (both fields)
     constexpr bool STAGED = INT && C::FAST && MODE != LK_FLOW_NONE;  // next window in LDS (interior tiles: by DMA)
+    // DEFER (r04, -DMICV_LK_DEFER_PREV): the prev tile is not read before phase 3, so its DMA is issued LAST and the
+    // barrier that opens phase 2 waits only for the coarse block and the `next` window (s_waitcnt vmcnt(n) with n = this
+    // wave's prev transfers); the prev tile lands while the march runs and is awaited at the barrier that ends it.
+    // hipcc makes every LDS access it can see wait for ALL outstanding LDS-DMA (it has no alias information for them),
+    // so phase 2 of such tiles touches LDS through inline asm only: the coarse block (already), the warp's taps and
+    // its stores.  Interior, 16-byte-DMA tiles with a coarse flow only.
+#ifdef MICV_LK_DEFER_PREV
+    constexpr bool DEFER = INT && C::FAST && MODE == LK_FLOW_COARSE && !CARRY && !STREAM && !GATHER;
+#else
+    constexpr bool DEFER = false;
+#endif
     // Border tiles take the marching body too when the image is at least 4 x 4 (one reflection per tap):
     // their `next` window is staged with zeros outside the image (= lk::warp's constant border), their
     // coarse block with replicated edges from a possibly negative origin, and pyrUp's reflected taps differ
@@ -664,6 +727,7 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     // 16-byte rows; the last wave of a transfer may be partial and carry tiles start mid-wave (lanes
     // beyond the range are masked off, the wave's LDS base stays uniform)
     constexpr bool DMA_OK = (RW % 4 == 0) && (NW % 4 == 0);
+    bool deferred = false;  // (uniform) this tile's prev DMA is still in flight when phase 2 starts
     if (INT && DMA_OK && vec_ok) {
         // LDS-DMA (dma_rows): the LDS images are dense (P: 80-float rows, window: 96-float rows); carry
         // tiles stage region rows [LYC, RH) only
@@ -675,6 +739,10 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             dma_gather<NT, RW, RH - LY0>(prev + (size_t)(ry0 + LY0) * istride + (size_t)rx0 * xs, istride, xs, P + LY0 * RW, tid);
             if (MODE == LK_FLOW_NONE)
                 dma_gather<NT, RW, RH - LY0>(next + (size_t)(ry0 + LY0) * istride + (size_t)rx0 * xs, istride, xs, Wp + LY0 * RW, tid);
+        } else if constexpr (DEFER) {
+            dma_rows<NT, NW / 4, NH>(next + (size_t)(ry0 - M + LY0) * istride + rx0 - M, istride, Nx, tid);
+            dma_rows<NT, V, RH - LY0>(prev + (size_t)(ry0 + LY0) * istride + rx0, istride, P + LY0 * RW, tid);
+            deferred = true;
         } else {
         dma_rows<NT, V, RH - LY0>(prev + (size_t)(ry0 + LY0) * istride + rx0, istride, P + LY0 * RW, tid);
         if (MODE == LK_FLOW_NONE)
@@ -777,7 +845,24 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     for (int j = 0; j < RPT; j++) base_u[j] = base_v[j] = 0.f;
     // streamed tiles: what phase 2 reads was staged before the previous barrier, and the prev tile's
     // DMA (issued just now) is only needed by phase 3, a barrier further on
-    if (MODE != LK_FLOW_NONE && !STREAM) __syncthreads();
+    if constexpr (DEFER) {
+        if (deferred) {
+            // this wave's prev transfers: every pass but the last is whole; the last one exists for the waves whose
+            // first slot lies inside the block (dma_rows: a wave's slots are 64 consecutive ones)
+            constexpr int V = RW / 4, TOT = (RH - LY0) * V, NPP = (TOT + NT - 1) / NT;
+            static_assert(NPP >= 1 && NPP <= 8, "prev transfers per wave");
+            const bool last = __builtin_amdgcn_readfirstlane(tid) + (NPP - 1) * NT < TOT;
+            if (last) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPP) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPP - 1) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __syncthreads();
+        }
+    } else if (MODE != LK_FLOW_NONE && !STREAM) __syncthreads();
     MICV_STAMP(0)
 
     if (MODE != LK_FLOW_NONE) {
@@ -885,7 +970,17 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                         bv8[j] = bv;
                         // warp right away: the flow pair's live range ends here.  Carry tiles need
                         // the warped image from region row LYC on (the base flow of every own row)
-                        if (!CARRY || ly0 + j >= LY0)
+                        if constexpr (DEFER) {
+                            // (both forms compiled: `deferred` is uniform, and false for unaligned images)
+                            if (deferred) {
+                                const float wv = warp_sample_staged<NW, NH, 64, true>(
+                                    Nx, nx0s, ny0s, next, rows, cols, istride, (v2f){xf32, yf32 + 32.f * (float)j}, half_uv, xs);
+                                asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(wrow), "v"(wv), "n"(4 * j * PS) : "memory");
+                            } else {
+                                wrow[j * PS] = warp_sample_staged<NW, NH, 64>(
+                                    Nx, nx0s, ny0s, next, rows, cols, istride, (v2f){xf32, yf32 + 32.f * (float)j}, half_uv, xs);
+                            }
+                        } else if (!CARRY || ly0 + j >= LY0)
                             wrow[j * PS] = warp_sample_staged<NW, NH, MODE == LK_FLOW_COARSE ? 64 : 32>(
                                 Nx, nx0s, ny0s, next, rows, cols, istride, (v2f){xf32, yf32 + 32.f * (float)j}, half_uv, xs);
                         // 512-thread tiles run at a 128-VGPR budget: keep the rows from interleaving
@@ -979,6 +1074,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
                 do_px(ly, lx, du_, dv_);
             }
         }
+    }
+    if constexpr (DEFER) {
+        if (deferred) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the asm stores above, the prev DMA
     }
     __syncthreads();
     MICV_STAMP(2)
@@ -1161,9 +1259,9 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         MICV_STOP(41)
         int cls[4];  // the column pass's four address registers (all five fields)
         col_bases<C>(rb0, c, r0, cls);
-        col_pass<C, 0>(cls, Sxx, g);
-        col_pass<C, 1>(cls, Sxy, g);
-        col_pass<C, 2>(cls, Syy, g);
+        col_pass<C, 0, PARTIAL_COLS>(cls, Sxx, g);
+        col_pass<C, 1, PARTIAL_COLS>(cls, Sxy, g);
+        col_pass<C, 2, PARTIAL_COLS>(cls, Syy, g);
         // 64x16 tiles: finish the three column chains here instead of letting them sink below the
         // barrier into sweep B (their 48 loaded values would be spilled there)
         if (TH == 16) __builtin_amdgcn_sched_barrier(0);
@@ -1209,8 +1307,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             v4f *dst = reinterpret_cast<v4f *>(X);
             for (int i = tid; i < C::CARRY_F / 4; i += NT) dst[i] = src[i];
         }
-        col_pass<C, 0>(cls, Sxt, g);
-        col_pass<C, 1>(cls, Syt, g);
+        col_pass<C, 0, PARTIAL_COLS>(cls, Sxt, g);
+        col_pass<C, 1, PARTIAL_COLS>(cls, Syt, g);
     }
     MICV_STAMP(4)
 
@@ -1319,9 +1417,9 @@ __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_kernel(L
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
     if (interior)
-        lk_tile<R, MODE, true, NTV, false, THV, false, false, GATHER>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, true, NTV, false, THV, false, false, GATHER, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
     else
-        lk_tile<R, MODE, false, NTV, false, THV, false, false, GATHER>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, false, NTV, false, THV, false, false, GATHER, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
 // Chain launch: workgroup b runs the `count` vertically adjacent tiles of sched[b] (tile_x, first

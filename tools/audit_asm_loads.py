@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """ISA audit of the hand-placed LDS loads of csrc/lk_fused.hip (the column pass's ds_read2st64_b32, which
 hipcc does not count -- MI355X HIP guide, section 5.7): compiles the file with -save-temps and checks, in
-every kernel, that between an asm-block load and the asm-block `s_waitcnt lgkmcnt(0)` that retires it NO
-instruction touches the load's destination registers (a register copy, a spill or a reuse placed there by
+every kernel, that between an asm-block load and the asm-block `s_waitcnt lgkmcnt(N)` that retires it (N = the
+younger operations that may stay outstanding: the column pass waits in three steps, r04) NO instruction touches the
+load's destination registers, and no LDS / scalar-memory instruction of the compiler's own sits inside the counted window (a register copy, a spill or a reuse placed there by
 the compiler would read data that has not landed: wrong results that depend on timing).  Exit status 0 and
 a one-line summary when clean; prints every offending instruction otherwise.  No GPU needed.
   python tools/audit_asm_loads.py [-DMICV_DIAG ...]"""
@@ -29,15 +30,28 @@ def regs_of(operand_text):
 
 
 def audit(asm_text):
+    """pending: the hand-placed LDS operations not yet retired, in issue order (LDS operations return in order, so
+    `s_waitcnt lgkmcnt(N)` retires all but the N youngest).  While any is pending: nothing may touch its destination,
+    no control flow, and -- because the waits count operations -- no LDS or scalar-memory instruction the compiler
+    placed on its own (it would shift a partial count; a scalar load also returns out of order)."""
     problems, loads_seen, kernels = [], 0, 0
     kernel = None
     in_asm = False
-    pending = {}  # vgpr -> line number of the load that writes it
+    pending = []  # (line number, destination vgprs) in issue order
+    foreign = []  # compiler-placed LDS / scalar-memory instructions seen while something is pending
+
+    def pending_regs():
+        out = {}
+        for ln_, regs in pending:
+            for r in regs:
+                out[r] = ln_
+        return out
+
     for ln, raw in enumerate(asm_text.split("\n"), 1):
         line = raw.strip()
         m = re.match(r"^(_Z\w+):", line)
         if m:
-            kernel, pending = m.group(1), {}
+            kernel, pending, foreign = m.group(1), [], []
             kernels += 1
             continue
         if line.startswith(";;#ASMSTART"):
@@ -51,25 +65,38 @@ def audit(asm_text):
         mnem, _, ops = line.partition(" ")
         if in_asm and mnem.startswith("ds_read"):
             dst = regs_of(ops.split(",")[0])
-            clash = dst & set(pending)
+            clash = dst & set(pending_regs())
             if clash:
-                problems.append((kernel, ln, line, f"overwrites v{sorted(clash)} of a load still in flight (line {pending[min(clash)]})"))
-            for r in dst:
-                pending[r] = ln
+                problems.append((kernel, ln, line, f"overwrites v{sorted(clash)} of a load still in flight (line {pending_regs()[min(clash)]})"))
+            pending.append((ln, dst))
             loads_seen += 1
             continue
-        if in_asm and mnem == "s_waitcnt" and "lgkmcnt(0)" in ops:
-            pending = {}
+        if in_asm and mnem.startswith("ds_write") and pending:
+            pending.append((ln, set()))  # counts in lgkmcnt, writes no register
+            continue
+        if in_asm and mnem == "s_waitcnt":
+            mm = re.search(r"lgkmcnt\((\d+)\)", ops)
+            if mm:
+                n = int(mm.group(1))
+                if n > 0:  # a PARTIAL wait counts operations: none of the compiler's own may be among them
+                    for fl, ftxt in foreign:
+                        problems.append((kernel, fl, ftxt, f"a compiler-placed LDS / scalar-memory operation inside a window "
+                                                           f"retired by a partial wait (lgkmcnt({n}) at line {ln})"))
+                pending = pending[len(pending) - n:] if n and n < len(pending) else ([] if n == 0 else pending)
+                if not pending:
+                    foreign = []
             continue
         if pending:
             if mnem in ("s_endpgm", "s_branch", "s_cbranch_execz", "s_cbranch_execnz", "s_cbranch_vccz", "s_cbranch_vccnz",
                         "s_cbranch_scc0", "s_cbranch_scc1", "s_barrier"):
                 problems.append((kernel, ln, line, "control flow or a barrier between a hand-placed load and its wait"))
-                pending = {}
+                pending, foreign = [], []
                 continue
-            touched = regs_of(ops) & set(pending)
+            if not in_asm and (mnem.startswith(("ds_", "s_load", "s_buffer_load", "s_memtime", "s_memrealtime"))):
+                foreign.append((ln, line))  # harmless before a full wait, a miscount before a partial one
+            touched = regs_of(ops) & set(pending_regs())
             if touched:
-                problems.append((kernel, ln, line, f"touches v{sorted(touched)} before the wait (loaded at line {pending[min(touched)]})"))
+                problems.append((kernel, ln, line, f"touches v{sorted(touched)} before the wait (loaded at line {pending_regs()[min(touched)]})"))
     return problems, loads_seen, kernels
 
 
