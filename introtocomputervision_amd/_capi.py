@@ -213,21 +213,23 @@ class Context:
         a doubling coarse flow (mode 1), following csrc/lk_fused.hip's dispatch and this context's options."""
         r = win // 2
         if self.get_option(OPT_LK_NARROW_TILES):
-            return f"lk_level_kernel<{r}, 1, 256, 32>"
+            return f"lk_level_kernel<{r}, 1, 256, 32, false, 64>"
         if win == 21:
             big = self.get_option(OPT_LK_TALL_TILES) >= 0 and -(-cols // 64) * -(-rows // 32) * batch >= 512
-            return "lk_level_kernel<10, 1, 1024, 32>" if big else "lk_level_kernel<10, 1, 512, 16>"
+            return "lk_level_kernel<10, 1, 1024, 32, false, 64>" if big else "lk_level_kernel<10, 1, 512, 16, false, 64>"
         if win != 15:
-            return f"lk_level_kernel<{r}, 1, 512, 32>"
+            return f"lk_level_kernel<{r}, 1, 512, 32, false, 64>"
         short = self.get_option(OPT_LK_SHORT_TILES)
         if short >= 0 and -(-cols // 64) * -(-rows // 16) * batch <= (short if short > 0 else 512):
-            return "lk_level_kernel<7, 1, 512, 16>"
-        tall = self.get_option(OPT_LK_TALL_TILES) > 0 and -(-cols // 64) * -(-rows // 64) * batch >= 1024
+            return "lk_level_kernel<7, 1, 512, 16, false, 64>"
+        if self.get_option(OPT_LK_TALL_TILES) == 2 and -(-cols // 32) * -(-rows // 64) * batch >= 1024:
+            return "lk_level_kernel<7, 1, 512, 64, false, 32>"
+        tall = self.get_option(OPT_LK_TALL_TILES) == 1 and -(-cols // 64) * -(-rows // 64) * batch >= 1024
         if self.get_option(OPT_LK_STREAM):
             return "lk_level_stream_kernel<7, 1024, 64>" if tall else "lk_level_stream_kernel<7, 512, 32>"
         if self.get_option(OPT_LK_CHAIN) > 1 or self.get_option(OPT_LK_CHAIN) < 0:
-            return "lk_level_chain_kernel<7, 512>"
-        return "lk_level_kernel<7, 1, 1024, 64>" if tall else "lk_level_kernel<7, 1, 512, 32>"
+            return "lk_level_chain_kernel<7, 512, false>"
+        return "lk_level_kernel<7, 1, 1024, 64, false, 64>" if tall else "lk_level_kernel<7, 1, 512, 32, false, 64>"
 
     def profile(self, on=True):
         check(lib.micv_profile_enable(self._h, 1 if on else 0))

@@ -49,11 +49,14 @@ struct TapsN {
 // TH_ = 32 is the throughput tile; TH_ = 16 (512 threads, 2 output rows per thread) halves every
 // thread's share of every phase: the form for launches that do not fill the GPU once, where the
 // time of a level is one tile's latency.
-template <int R_, int NT_ = 256, int TH_ = 32>
+// TW_ = 32 (r04): the 32x64 tile -- the same 3 840-pixel region and LDS as 64x32, but the row pass runs 78 gradient
+// rows for 64 output rows (1.22x) instead of 46 for 32 (1.44x): 10 wave-jobs per sweep instead of 12.
+template <int R_, int NT_ = 256, int TH_ = 32, int TW_ = 64>
 struct LkCfg {
     static constexpr int R = R_;
     static constexpr int W = 2 * R + 1;
-    static constexpr int TW = 64, TH = TH_, NT = NT_;
+    static constexpr int TW = TW_, TH = TH_, NT = NT_;
+    static_assert(TW == 64 || (TW == 32 && R_ == 7 && NT_ == 512 && TH_ == 64), "32-wide tiles: window 15, 512 threads, 64 rows");
     // image halo: Sobel + window = R + 1, rounded up to a multiple of 4 so that region rows are whole
     // 16-byte chunks (LDS-DMA) and the halo bands split into whole marching jobs at every window
     static constexpr int H = (R + 1 + 3) & ~3;
@@ -69,7 +72,8 @@ struct LkCfg {
     static constexpr int GS = 3 * GP;
     static constexpr int WV = (4 + 2 * R + 3) / 4;          // float4 loads per row-pass window
     static_assert(4 * (TW / 4 - 1) + 4 * WV <= GP, "row-pass window reads stay inside a plane row");
-    static constexpr int RBS = TW;                          // row-buffer stride (XOR-swizzled chunks)
+    static constexpr int RBS = TW;                          // row-buffer floats per row (XOR-swizzled chunks; rb_off)
+    static_assert(TW == 64 || (TH + 2 * R_) % 2 == 0, "32-wide row buffers hold two rows per 64-float unit");
     static constexpr int CW = RW / 2 + 3, CH = RH / 2 + 3;  // coarse flow block
     static constexpr int M = 8;                             // margin of the staged `next` window
     static constexpr int NW = RW + 2 * M, NH = RH + 2 * M;
@@ -114,6 +118,13 @@ constexpr int lk_waves_per_simd(int nt) { return nt >= 1024 ? 4 : nt / 128; }
 // pass's b128 stores (4 rows x 2 chunks per 8-lane group) and the column pass's b32 loads are
 // both bank-conflict-free with this layout at a 64-float row pitch.
 __device__ __forceinline__ int rb_off(int q, int chunk) { return q * 64 + 4 * (chunk ^ (2 * (q & 3))); }
+// 32-wide tiles: two rows share a 64-float unit, row q in half (q ^ (q >> 2)) & 1 -- rows q and q + 4 (the two row
+// groups a wave's lanes 0-31 / 32-63 read in the column pass) then sit in different halves = different banks -- and
+// the 8 chunks of a row are XOR-ed with 4 ((q >> 1) & 1), which keeps the row pass's b128 stores (a quarter wave =
+// 4 rows x 4 chunks) on 16 different 16-byte slots.  Rows q and q + 8 differ in the unit only.
+__device__ __forceinline__ int rb_off32(int q, int chunk) {
+    return (q >> 1) * 64 + 32 * ((q ^ (q >> 2)) & 1) + 4 * (chunk ^ (4 * ((q >> 1) & 1)));
+}
 
 template <typename C>
 __device__ __forceinline__ void load_window(const float *__restrict__ A, int qy, int c0,
@@ -410,6 +421,60 @@ __device__ __forceinline__ void col_pass(const int (&cls)[4], float (&S)[C::RPT]
     col_pairs<C>(V, S, g, std::make_integer_sequence<int, C::RPT / 2>{});
 }
 
+// ---- the column pass of the 32-wide tile ---------------------------------------------------------------------
+// Thread (c, r0 = 4 k) reads staged rows r0 + I, I = 0..17.  rb_off32: unit (r0 + I) >> 1 = 2 k + (I >> 1), and the
+// half and the chunk swizzle depend on I & 7 (and on k's parity) only -- so rows I and I + 8 share an address
+// register and differ by four units: ONE ds_read2st64_b32 delivers the pair (I, I + 8), eight of them rows 0..15;
+// rows 16 and 17 come as two more (both halves the same row).  Eight address registers per thread and tile.
+struct SlotStride8 {
+    static constexpr int pair(int i) { return i < 16 ? (i & 7) : 8 + (i - 16); }
+    static constexpr int half(int i) { return i < 16 ? (i >> 3) : 0; }
+};
+
+template <typename C>
+__device__ __forceinline__ void col_bases32(const float *rb0, int c, int r0, int (&cls)[8]) {
+    typedef const __attribute__((address_space(3))) float lds_cfloat;
+    const int base = (int)(size_t)(lds_cfloat *)rb0;
+    const int k = r0 >> 2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int half = ((i & 1) ^ ((k + (i >> 2)) & 1));
+        cls[i] = base + 4 * ((r0 >> 1) * 64 + 32 * half + 4 * ((c >> 2) ^ (4 * ((i >> 1) & 1))) + (c & 3));
+    }
+}
+
+template <typename C, int F, bool PARTIAL>
+__device__ __forceinline__ void col_pass32(const int (&cls)[8], float (&S)[C::RPT], const TapsN<C::W> &g) {
+    constexpr int W = C::W, NP = 10, FU = F * (C::GH / 2);  // field offset in 64-float units
+    static_assert(C::RPT == 4 && C::R == 7 && C::TW == 32 && FU + 8 + 4 < 256, "32x64 tile, window 15");
+    v2f V[NP];
+    if (PARTIAL) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // no scalar load may share the counted window
+#define MICV_RD(P, I0, I1) \
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(V[P]) : "v"(cls[(I0) & 7]), "n"(FU + ((I0) >> 1)), "n"(FU + ((I1) >> 1)) : "memory")
+    MICV_RD(0, 0, 8); MICV_RD(1, 1, 9); MICV_RD(2, 2, 10); MICV_RD(3, 3, 11);
+    MICV_RD(4, 4, 12); MICV_RD(5, 5, 13); MICV_RD(6, 6, 14); MICV_RD(7, 7, 15);
+    MICV_RD(8, 16, 16); MICV_RD(9, 17, 17);
+#undef MICV_RD
+    v2f acc0, acc1;
+    if (PARTIAL) {
+        // rows 0..15 have landed when two loads are still out: the first chain whole, the second up to its row 15
+        lds_wait_upto4<2>(V[0], V[1], V[2], V[3]);
+        lds_wait_upto4<2>(V[4], V[5], V[6], V[7]);
+        skew_chain<SlotStride8, W, NP, 0>(acc0, V, g, std::make_integer_sequence<int, W + 1>{});
+        skew_chain<SlotStride8, W, NP, 2>(acc1, V, g, range_seq<0, 14>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[8]), "+v"(V[9]));
+        skew_chain<SlotStride8, W, NP, 2>(acc1, V, g, range_seq<14, W + 1>{});
+    } else {
+        lds_wait_n<NP>(V);
+        skew_chain<SlotStride8, W, NP, 0>(acc0, V, g, std::make_integer_sequence<int, W + 1>{});
+        skew_chain<SlotStride8, W, NP, 2>(acc1, V, g, std::make_integer_sequence<int, W + 1>{});
+    }
+    S[0] = acc0.x;
+    S[1] = acc0.y;
+    S[2] = acc1.x;
+    S[3] = acc1.y;
+}
+
 // ---- the tile body ---------------------------------------------------------------------------
 
 // LDS-DMA of a dense block: `nrows` rows of 4 * V4 floats, global row pitch `istride`, into a dense
@@ -604,13 +669,14 @@ __device__ __forceinline__ void lk_stage_ahead(const LkLevelArgs &a, float *lds,
 // STREAM: the tile runs in lk_level_stream_kernel's loop (its window and coarse block were staged ahead).
 // GATHER: the level's images are read from pyramid level 0 with a pixel stride (a.img_xstride; above).
 template <int R, int MODE, bool INT, int NTV, bool CARRY = false, int THV = 32, bool STREAM = false,
-          bool IN_LOOP = CARRY || STREAM, bool GATHER = false, bool PARTIAL_COLS = false>
+          bool IN_LOOP = CARRY || STREAM, bool GATHER = false, bool PARTIAL_COLS = false, int TWV = 64>
 __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R + 1> &g,
                                         float *lds, int tile_x, int tile_y, int pair, bool more = false,
                                         LkStreamLink *link = nullptr) {
-    using C = LkCfg<R, NTV, THV>;
+    using C = LkCfg<R, NTV, THV, TWV>;
     constexpr int RPT = C::RPT;
     constexpr int TW = C::TW, TH = C::TH, H = C::H, RW = C::RW, RH = C::RH, PS = C::PS;
+    static_assert(TWV == 64 || (!CARRY && !STREAM && !GATHER), "32-wide tiles: the plain kernel only");
     constexpr int GW = C::GW, GH = C::GH, GS = C::GS, GP = C::GP, CW = C::CW, NT = C::NT;
     constexpr int M = C::M, NW = C::NW;
     static_assert(!CARRY || (INT && C::FAST && MODE == LK_FLOW_COARSE && C::CHAIN_OK), "carry tiles: interior, coarse flow");
@@ -1226,7 +1292,8 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     // ---- phase 4: five window sums, two sweeps ----------------------------------------------
     const int c = tid & (TW - 1), r0 = RPT * (tid / TW);
     float Sxx[RPT], Sxy[RPT], Syy[RPT], Sxt[RPT], Syt[RPT];
-    constexpr int RPI = 4 * (NT / 64);  // gradient rows one row-pass iteration covers
+    constexpr int RPW = 64 / (TW / 4);     // gradient rows a wave's 64 row-pass jobs cover (4 outputs per job)
+    constexpr int RPI = RPW * (NT / 64);  // gradient rows one row-pass iteration covers
     constexpr int SWEEP_UNROLL = NT >= 512 ? 1 : 4;  // 512 threads: rolled sweeps keep the 128-VGPR budget
     // 64x16 tiles: one trip per sweep.  As straight-line code the scheduler overlaps the sweeps with the
     // column passes around them and spills; a trip count the compiler cannot see (a.batch is never
@@ -1235,16 +1302,21 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
     const int sweep_trips = SWEEP_TRIPS == 1 ? 1 + (a.batch < 0 ? 1 : 0) : SWEEP_TRIPS;
     {
         const int lane = tid & 63, wave = tid >> 6;
-        const int grp = lane >> 2, c0 = 4 * grp;
+        // lane -> (row within the wave's rows, group of four columns).  64-wide tiles: 4 rows x 16 groups, row in the
+        // low bits.  32-wide tiles: 8 rows x 8 groups with a QUARTER wave = 4 rows x 4 groups (bits g1 g0 r1 r0 | g2 r2
+        // from the top): the 16 ds_read_b128 / ds_write_b128 of a quarter then fall on 16 different 16-byte slots
+        // (plane rows are 36 = 4 (mod 16) slots apart; row buffers: rb_off32).
+        const int grp = TW == 64 ? lane >> 2 : ((lane & 3) | ((lane >> 2) & 4)), c0 = 4 * grp;
+        const int lrow = TW == 64 ? (lane & 3) : (((lane >> 2) & 3) | ((lane >> 3) & 4));
         // sweep A: Ix^2, Ix*Iy, Iy^2  (windows of Ix, Iy read once)
 #pragma unroll SWEEP_UNROLL
         for (int it = 0; it < sweep_trips; it++) {
-            const int qy = it * RPI + wave * 4 + (lane & 3);
+            const int qy = it * RPI + wave * RPW + lrow;
             if (qy < GH) {
                 v2f wx[2 * C::WV], wy[2 * C::WV];
                 load_window_pairs<C>(Gx, qy, c0, wx);
                 load_window_pairs<C>(Gy, qy, c0, wy);
-                const int o = rb_off(qy, grp);
+                const int o = TW == 64 ? rb_off(qy, grp) : rb_off32(qy, grp);
                 row_taps_skew<C>(wx, wx, g, rb0 + o);
                 // 64x16 tiles: the sweep is a single (peeled) trip; keep its three products from
                 // interleaving so the body stays inside the 128-VGPR budget
@@ -1257,11 +1329,18 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         if (STREAM && tid == 0) *link->slot = ticket;
         __syncthreads();
         MICV_STOP(41)
-        int cls[4];  // the column pass's four address registers (all five fields)
-        col_bases<C>(rb0, c, r0, cls);
-        col_pass<C, 0, PARTIAL_COLS>(cls, Sxx, g);
-        col_pass<C, 1, PARTIAL_COLS>(cls, Sxy, g);
-        col_pass<C, 2, PARTIAL_COLS>(cls, Syy, g);
+        int cls[TW == 64 ? 4 : 8];  // the column pass's address registers (all five fields)
+        if constexpr (TW == 64) {
+            col_bases<C>(rb0, c, r0, cls);
+            col_pass<C, 0, PARTIAL_COLS>(cls, Sxx, g);
+            col_pass<C, 1, PARTIAL_COLS>(cls, Sxy, g);
+            col_pass<C, 2, PARTIAL_COLS>(cls, Syy, g);
+        } else {
+            col_bases32<C>(rb0, c, r0, cls);
+            col_pass32<C, 0, PARTIAL_COLS>(cls, Sxx, g);
+            col_pass32<C, 1, PARTIAL_COLS>(cls, Sxy, g);
+            col_pass32<C, 2, PARTIAL_COLS>(cls, Syy, g);
+        }
         // 64x16 tiles: finish the three column chains here instead of letting them sink below the
         // barrier into sweep B (their 48 loaded values would be spilled there)
         if (TH == 16) __builtin_amdgcn_sched_barrier(0);
@@ -1270,12 +1349,12 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
         // sweep B: Ix*It, Iy*It
 #pragma unroll SWEEP_UNROLL
         for (int it = 0; it < sweep_trips; it++) {
-            const int qy = it * RPI + wave * 4 + (lane & 3);
+            const int qy = it * RPI + wave * RPW + lrow;
             if (qy < GH) {
                 v2f wx[2 * C::WV], wt[2 * C::WV];
                 load_window_pairs<C>(Gx, qy, c0, wx);
                 load_window_pairs<C>(Gt, qy, c0, wt);
-                const int o = rb_off(qy, grp);
+                const int o = TW == 64 ? rb_off(qy, grp) : rb_off32(qy, grp);
                 row_taps_skew<C>(wx, wt, g, rb0 + o);
                 // 128-VGPR budget at 512 threads: the Iy window reuses the Ix window's registers
                 if (NT >= 512) __builtin_amdgcn_sched_barrier(0);
@@ -1307,8 +1386,13 @@ __device__ __forceinline__ void lk_tile(const LkLevelArgs &a, const TapsN<2 * R 
             v4f *dst = reinterpret_cast<v4f *>(X);
             for (int i = tid; i < C::CARRY_F / 4; i += NT) dst[i] = src[i];
         }
-        col_pass<C, 0, PARTIAL_COLS>(cls, Sxt, g);
-        col_pass<C, 1, PARTIAL_COLS>(cls, Syt, g);
+        if constexpr (TW == 64) {
+            col_pass<C, 0, PARTIAL_COLS>(cls, Sxt, g);
+            col_pass<C, 1, PARTIAL_COLS>(cls, Syt, g);
+        } else {
+            col_pass32<C, 0, PARTIAL_COLS>(cls, Sxt, g);
+            col_pass32<C, 1, PARTIAL_COLS>(cls, Syt, g);
+        }
     }
     MICV_STAMP(4)
 
@@ -1405,9 +1489,9 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
     }
 }
 
-template <int R, int MODE, int NTV, int THV = 32, bool GATHER = false>
+template <int R, int MODE, int NTV, int THV = 32, bool GATHER = false, int TWV = 64>
 __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
-    using C = LkCfg<R, NTV, THV>;
+    using C = LkCfg<R, NTV, THV, TWV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int E = C::M > 2 ? C::M : 2;
     int tile_x, tile_y;
@@ -1417,9 +1501,9 @@ __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_kernel(L
     const bool interior = rx0 - E >= 0 && rx0 + C::RW + E <= a.cols && ry0 - E >= 0 &&
                           ry0 + C::RH + E <= a.rows;
     if (interior)
-        lk_tile<R, MODE, true, NTV, false, THV, false, false, GATHER, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, true, NTV, false, THV, false, false, GATHER, true, TWV>(a, g, lds, tile_x, tile_y, blockIdx.y);
     else
-        lk_tile<R, MODE, false, NTV, false, THV, false, false, GATHER, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
+        lk_tile<R, MODE, false, NTV, false, THV, false, false, GATHER, true, TWV>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
 // Chain launch: workgroup b runs the `count` vertically adjacent tiles of sched[b] (tile_x, first
@@ -1631,10 +1715,10 @@ static int get_schedule(const LkLevelArgs &a, int max_chain, const int4 **sched,
     return MICV_OK;
 }
 
-template <int R, int NTV, int THV = 32, bool GATHER = false>
+template <int R, int NTV, int THV = 32, bool GATHER = false, int TWV = 64>
 static int launch_r(hipStream_t s, const LkLevelArgs &a) {
-    using C = LkCfg<R, NTV, THV>;
-    if constexpr (!GATHER && R == 7 && NTV == 512) {
+    using C = LkCfg<R, NTV, THV, TWV>;
+    if constexpr (!GATHER && R == 7 && NTV == 512 && TWV == 64) {
         // pyramid level k read straight from level 0 (img_xstride = 2^k): the gather-staging instantiations
         // (window 15, 512-thread tiles only -- the option is off by default and every instantiation costs build time)
         if (a.img_xstride != 1) return launch_r<R, NTV, THV, true>(s, a);
@@ -1656,13 +1740,15 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         int dev = 0;
         MICV_HIP(hipGetDevice(&dev));
         if (done_dev != dev) {
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0, NTV, THV, GATHER>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1, NTV, THV, GATHER>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)C::LDS_BYTES));
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2, NTV, THV, GATHER>),
+            if constexpr (TWV == 64) {  // (32-wide tiles exist for the coarse-flow mode only)
+                MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 0, NTV, THV, GATHER, TWV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)C::LDS_BYTES));
+                MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 2, NTV, THV, GATHER, TWV>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)C::LDS_BYTES));
+            }
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_kernel<R, 1, NTV, THV, GATHER, TWV>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)C::LDS_BYTES));
             done_dev = dev;
@@ -1672,7 +1758,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         set_error("lk fused: bad row band [%d, %d) for %d rows", a.row_begin, a.row_end, a.rows);
         return MICV_EINVAL;
     }
-    if constexpr (!GATHER && C::FAST && C::RW % 4 == 0 && C::NW % 4 == 0 && ((THV == 32 && NTV == 512) || (THV == 64 && NTV == 1024))) {
+    if constexpr (!GATHER && TWV == 64 && C::FAST && C::RW % 4 == 0 && C::NW % 4 == 0 && ((THV == 32 && NTV == 512) || (THV == 64 && NTV == 1024))) {
         // Streamed launch (MICV_OPT_LK_STREAM = 1; off by default): whole frames with a coarse flow whose
         // images the LDS-DMA can address (16-byte rows).  Measured on MI355X (8 x 1080p, tools/stream_bench.py,
         // one box): level-0 launch 0.244 ms against 0.220 ms for the plain grid -- the loop's staging
@@ -1777,7 +1863,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
     switch (a.mode) {
         case LK_FLOW_NONE:
-            lk_level_kernel<R, 0, NTV, THV, GATHER><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
+            if constexpr (TWV == 64) lk_level_kernel<R, 0, NTV, THV, GATHER, TWV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         case LK_FLOW_COARSE:
             if (a.rows != 2 * a.flow_rows || a.cols != 2 * a.flow_cols) {
@@ -1785,10 +1871,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
                           a.flow_cols, a.rows, a.cols);
                 return MICV_EINVAL;
             }
-            lk_level_kernel<R, 1, NTV, THV, GATHER><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
+            lk_level_kernel<R, 1, NTV, THV, GATHER, TWV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         case LK_FLOW_FULL:
-            lk_level_kernel<R, 2, NTV, THV, GATHER><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
+            if constexpr (TWV == 64) lk_level_kernel<R, 2, NTV, THV, GATHER, TWV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);
             break;
         default:
             set_error("lk fused: bad mode %d", a.mode);
@@ -1820,7 +1906,12 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             // MICV_OPT_LK_TALL_TILES: 64x64 tiles, 1024 threads, one workgroup per CU (131.6 KB of LDS): the
             // structural cut of the halo overhead (phases 0-3 on 80x80 for 64x64 = 1.56x instead of 1.875x,
             // row pass 78 rows for 64 = 1.22x instead of 1.44x).  Launches of at least four rounds only.
-            if (a.tall_tiles > 0 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 64) * a.batch >= 1024) return launch_r<7, 1024, 64>(s, a);
+            if (a.tall_tiles == 1 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 64) * a.batch >= 1024) return launch_r<7, 1024, 64>(s, a);
+            // MICV_OPT_LK_TALL_TILES = 2: 32x64 tiles, 512 threads, two workgroups per CU (r04; LkCfg).  Launches of
+            // at least two rounds, whole frames with a doubling coarse flow (the throughput levels).
+            if (a.tall_tiles == 2 && a.mode == LK_FLOW_COARSE && a.img_xstride == 1 && a.row_begin == 0 && a.row_end == a.rows &&
+                (long)cdiv(a.cols, 32) * cdiv(a.rows, 64) * a.batch >= 1024)
+                return launch_r<7, 512, 64, false, 32>(s, a);
             return launch_r<7, 512>(s, a);
         }
         case 7: return a.narrow ? launch_r<3, 256>(s, a) : launch_r<3, 512>(s, a);  // 512 threads: the staged / marching body
