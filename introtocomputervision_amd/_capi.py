@@ -215,6 +215,8 @@ class Context:
         if self.get_option(OPT_LK_NARROW_TILES):
             return f"lk_level_kernel<{r}, 1, 256, 32, false, 64>"
         if win == 21:
+            if self.get_option(OPT_LK_TALL_TILES) == 0 and -(-cols // 64) * -(-rows // 64) * batch >= 256:
+                return "lk_level_kernel<10, 1, 1024, 64, false, 64>"
             big = self.get_option(OPT_LK_TALL_TILES) >= 0 and -(-cols // 64) * -(-rows // 32) * batch >= 512
             return "lk_level_kernel<10, 1, 1024, 32, false, 64>" if big else "lk_level_kernel<10, 1, 512, 16, false, 64>"
         if win != 15:

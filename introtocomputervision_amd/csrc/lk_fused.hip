@@ -1923,6 +1923,9 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             // overhead falls from 3.4x to 2.4x (phases 0-3) and from 2.25x to 1.6x (row pass), which at this
             // window outweighs what one workgroup per CU loses at its barriers (r03, 4 x 1080p: level 0
             // 236 -> 223 us; the same trade LOSES at window 15, see MICV_OPT_LK_TALL_TILES).  -1 = never.
+            // r04: 64x64 tiles, 1024 threads (149 KB of LDS, still one workgroup of 16 waves per CU): region 1.89x and
+            // row pass 1.31x instead of 2.4x / 1.6x at the same occupancy.  MICV_OPT_LK_TALL_TILES = 1 keeps 64x32.
+            if (a.tall_tiles == 0 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 64) * a.batch >= 256) return launch_r<10, 1024, 64>(s, a);
             if (a.tall_tiles >= 0 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 32) * a.batch >= 512) return launch_r<10, 1024, 32>(s, a);
             return launch_r<10, 512, 16>(s, a);
         case 11: return a.narrow ? launch_r<5, 256>(s, a) : launch_r<5, 512>(s, a);

@@ -546,6 +546,28 @@ def test_levels_read_straight_from_level_0_are_bit_exact(mods, rows, cols, level
         ctx.set_option(_capi.OPT_LK_DIRECT_LEVELS, 16)
 
 
+@pytest.mark.parametrize("rows,cols,levels,batch", [(1080, 1920, 4, 1), (540, 960, 3, 4), (1085, 1925, 2, 1), (600, 700, 2, 3)])
+def test_window_21_tile_shapes_are_bit_exact(mods, rows, cols, levels, batch):
+    """Window 21, the reference's default winSize (OpticalFlow.h:10,18): launches of at least one round run 64x64 tiles
+    with 1024 threads (r04: 149 KB of LDS, region 1.89x its outputs instead of 2.4x -- level 0 of 4 x 1080p 216 -> 148 us);
+    MICV_OPT_LK_TALL_TILES = 1 keeps r03's 64x32 / 1024-thread tiles, -1 the 64x16 / 512-thread ones.  Same bits, and the
+    oracle's, on sizes that are not multiples of the tile and with a NaN pixel."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(2100 + i + rows, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    nxt[0, rows // 2, cols // 2] = np.nan
+    outs = []
+    for tall in (0, 1, -1):
+        ctx = _capi.Context(0)
+        ctx.set_option(_capi.OPT_LK_TALL_TILES, tall)
+        outs.append(lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 21, levels, ctx=ctx))
+    for u, v in outs[1:]:
+        assert host(u).tobytes() == host(outs[0][0]).tobytes() and host(v).tobytes() == host(outs[0][1]).tobytes()
+    eu, ev = orc.lk_flow_pyr(prev[batch - 1], nxt[batch - 1], 21, levels)
+    assert np.array_equal(host(outs[0][0][batch - 1]), eu, equal_nan=True) and np.array_equal(host(outs[0][1][batch - 1]), ev, equal_nan=True)
+
+
 @pytest.mark.parametrize("rows,cols,levels,batch", [(1080, 1920, 5, 2), (540, 960, 3, 8), (1080, 1920, 2, 1), (700, 1000, 3, 3), (1090, 1930, 3, 2)])
 def test_32x64_tiles_are_bit_exact(mods, rows, cols, levels, batch):
     """MICV_OPT_LK_TALL_TILES = 2: launches of at least two rounds of the window-15 level kernel on 32x64 tiles
