@@ -62,7 +62,7 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 #define MICV_OPT_LK_CHAIN          8 /* fused LK tile chains: 0 = pairs of tiles only for launches a little over one or two rounds of workgroups (default), 1 = never, n = longest chain (<= 32), -1 = schedule only */
 #define MICV_OPT_LK_SHORT_TILES    9 /* win-15 level kernel, 64x16 tiles: 0 = up to 512 tiles (one round), n = up to n, -1 = never */
 #define MICV_OPT_LK_STREAM         10 /* level kernel as a persistent grid that stages the next tile ahead: 1 = on, 0 = off (default; measured slower) */
-#define MICV_OPT_LK_TALL_TILES     11 /* 1024-thread tiles, one workgroup per CU, for big launches: window 15 on 64x64 tiles only with 1 (measured slower); window 21 on 64x32 tiles by default (0 or 1; measured faster); 2 = window 15 on 32x64 tiles, 512 threads, two workgroups per CU (r04); -1 = never */
+#define MICV_OPT_LK_TALL_TILES     11 /* 1024-thread tiles, one workgroup per CU, for big launches: window 15 on 64x64 tiles only with 1 (measured slower); window 21 on 64x32 tiles by default (0 or 1; measured faster); 2 = window 15 on 32x64 tiles, 512 threads, two workgroups per CU; 3 = window 15 on 64x32 tiles, 1024 threads, eight waves per SIMD (r04 experiments, both measured slower: DESIGN.md section 5); -1 = never */
 #define MICV_OPT_COMPACT_3PASS     12 /* ordered lists (corners, edge points, peak candidates, matches): 0 = one-launch chained scan up to 1 M elements, count / scan / emit launches beyond; 1 = always three launches; -1 = always one */
 #define MICV_OPT_LK_DIRECT_LEVELS  13 /* fused LK: pyramid levels >= n read straight from level 0 with a pixel stride (n = 1: no pyramid-build launch): 0 = off (default: measured faster one pass at a time, slower with two passes in flight), n = 1..15 */
 #define MICV_OPT_COUNT            14

@@ -328,7 +328,7 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
     if (option == MICV_OPT_LK_STREAM)
         MICV_REQUIRE(value >= 0 && value <= 1, "micv_ctx_set_option: streamed launch must be 0 or 1");
     if (option == MICV_OPT_LK_TALL_TILES)
-        MICV_REQUIRE(value >= -1 && value <= 2, "micv_ctx_set_option: tall tiles must be -1, 0, 1 or 2");
+        MICV_REQUIRE(value >= -1 && value <= 3, "micv_ctx_set_option: tall tiles must be -1..3");
     if (option == MICV_OPT_COMPACT_3PASS)
         MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: compaction form must be -1, 0 or 1");
     if (option == MICV_OPT_LK_DIRECT_LEVELS)

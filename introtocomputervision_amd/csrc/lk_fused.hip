@@ -111,6 +111,10 @@ struct LkCfg {
 // Second argument of __launch_bounds__ (waves per SIMD the register allocation must allow): 512-thread
 // tiles run two workgroups per CU, the 1024-thread 64x64 tile one -- four waves per SIMD either way.
 constexpr int lk_waves_per_simd(int nt) { return nt >= 1024 ? 4 : nt / 128; }
+// The plain kernel's bound also knows the window and the tile: window 15 on a 64x32 tile worked by 1024 threads (r04
+// experiment, MICV_OPT_LK_TALL_TILES = 3) keeps the 80 KB of LDS, so TWO such workgroups fit a CU = 8 waves per SIMD,
+// and the register allocation must allow that (64 VGPRs).
+constexpr int lk_waves_per_simd_rt(int r, int nt, int th) { return (r == 7 && nt == 1024 && th == 32) ? 8 : lk_waves_per_simd(nt); }
 
 // ---- phase 4 building blocks ------------------------------------------------------------------
 
@@ -1490,7 +1494,7 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
 }
 
 template <int R, int MODE, int NTV, int THV = 32, bool GATHER = false, int TWV = 64>
-__global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
+__global__ __launch_bounds__(NTV, lk_waves_per_simd_rt(R, NTV, THV)) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
     using C = LkCfg<R, NTV, THV, TWV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int E = C::M > 2 ? C::M : 2;
@@ -1909,6 +1913,9 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
             if (a.tall_tiles == 1 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 64) * a.batch >= 1024) return launch_r<7, 1024, 64>(s, a);
             // MICV_OPT_LK_TALL_TILES = 2: 32x64 tiles, 512 threads, two workgroups per CU (r04; LkCfg).  Launches of
             // at least two rounds, whole frames with a doubling coarse flow (the throughput levels).
+            // MICV_OPT_LK_TALL_TILES = 3 (r04 experiment): 64x32 tiles worked by 1024 threads, two workgroups per CU = eight
+            // waves per SIMD at a 64-VGPR budget (the occupancy lever that needs no third workgroup)
+            if (a.tall_tiles == 3 && (long)cdiv(a.cols, 64) * cdiv(a.rows, 32) * a.batch >= 1024) return launch_r<7, 1024, 32>(s, a);
             if (a.tall_tiles == 2 && a.mode == LK_FLOW_COARSE && a.img_xstride == 1 && a.row_begin == 0 && a.row_end == a.rows &&
                 (long)cdiv(a.cols, 32) * cdiv(a.rows, 64) * a.batch >= 1024)
                 return launch_r<7, 512, 64, false, 32>(s, a);
