@@ -214,21 +214,25 @@ __global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit em
 // contributes popcount(masks[i]) hits -- its set bits in ascending order.  The NMS kernels write one mask per
 // (row, 64-column tile) by wave ballot, so the ordered corner list of a 4K frame is a scan over 130 k words in 32
 // chunks instead of 8.3 M flag bytes in three launches.  emit(pos, i, bit).
-template <typename Emit>
+// J words per thread = 256 J words per chunk: 16 for long lists; 4 keeps the launch wide when the words are few (32 k words
+// of a 1080p edge mask are 8 chunks of 4096 -- eight workgroups on the whole GPU -- but 32 of 1024).
+template <typename Emit, int J = kChunk1 / 256>
 __global__ __launch_bounds__(256) void compact_masks_onepass_kernel(const unsigned long long *__restrict__ masks, Emit emit,
                                                                      int64_t n, int nchunks,
                                                                      unsigned long long *__restrict__ status,
                                                                      unsigned *__restrict__ counters, int64_t cap,
                                                                      int64_t *__restrict__ count) {
-    constexpr int J = kChunk1 / 256;
+    static_assert(J >= 1 && J <= 16, "one (j, wave) slot per lane of the scanning wave");
+    constexpr int CH = 256 * J;
     __shared__ CompactShared sh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) sh.s_chunk = atomicAdd(&counters[0], 1u);
     __syncthreads();
     const int chunk = (int)sh.s_chunk;
-    const int64_t base = (int64_t)chunk * kChunk1;
+    const int64_t base = (int64_t)chunk * CH;
     unsigned long long m[J];
     int before[J];
+    if (J < 16 && threadIdx.x >= 4 * J && threadIdx.x < 64) sh.wcount[threadIdx.x] = 0;  // the slots this chunk size leaves empty
 #pragma unroll
     for (int j = 0; j < J; j++) {  // all loads in flight first
         const int64_t i = base + j * 256 + threadIdx.x;
@@ -260,6 +264,18 @@ __global__ __launch_bounds__(256) void compact_masks_onepass_kernel(const unsign
         }
     }
     compact_chunk_exit(sh, nchunks, status, counters);
+}
+
+// Launches the mask scan with the chunk size that suits the list (above); `nchunks_out` chunks of state are needed.
+inline int compact_masks_chunks(int64_t nwords) { return (int)((nwords + (nwords <= 256 * 1024 ? 1024 : kChunk1) - 1) / (nwords <= 256 * 1024 ? 1024 : kChunk1)); }
+template <typename Emit>
+inline void launch_compact_masks(hipStream_t s, const unsigned long long *masks, Emit emit, int64_t nwords, unsigned long long *status,
+                                 unsigned *counters, int64_t cap, int64_t *count) {
+    const int nchunks = compact_masks_chunks(nwords);
+    if (nwords <= 256 * 1024)
+        compact_masks_onepass_kernel<Emit, 4><<<nchunks, 256, 0, s>>>(masks, emit, nwords, nchunks, status, counters, cap, count);
+    else
+        compact_masks_onepass_kernel<Emit, 16><<<nchunks, 256, 0, s>>>(masks, emit, nwords, nchunks, status, counters, cap, count);
 }
 
 inline size_t compact_scratch_bytes(int64_t n) {

@@ -558,12 +558,11 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
             resp, (int)(rstride / 4), rows, cols, threshold, min_distance, corners,
             (int)(cstride / 4), rowmask, tiles_x);
     MICV_LAUNCH_CHECK();
-    const int nchunks = (int)((nseg + kChunk1 - 1) / kChunk1);
+    const int nchunks = compact_masks_chunks(nseg);
     unsigned long long *status = nullptr;
     unsigned *counters = nullptr;
     if (ctx->opt[MICV_OPT_COMPACT_3PASS] <= 0 && ctx->compact_state(s, nchunks, &status, &counters) == MICV_OK) {
-        compact_masks_onepass_kernel<<<nchunks, 256, 0, s>>>(rowmask, MaskYxEmit{locs_yx, tiles_x}, nseg, nchunks, status, counters, cap,
-                                                             count);
+        launch_compact_masks(s, rowmask, MaskYxEmit{locs_yx, tiles_x}, nseg, status, counters, cap, count);
         MICV_LAUNCH_CHECK();
         return MICV_OK;
     }

@@ -27,6 +27,28 @@ struct MaskPred {
     }
 };
 
+// The ordered point list by row-segment masks (r04, as the corner list in harris.hip): a wave reads one 64-pixel
+// segment of a mask row, its ballot is that segment's 64-bit word, and the list is a chained scan over the words
+// (compact_masks_onepass_kernel) -- 32 k words at 1080p where the byte form scanned 2 M flags in three launches.
+__global__ __launch_bounds__(256) void mask_words_kernel(const uint8_t *__restrict__ mask, size_t stride, int rows, int cols,
+                                                          int tiles_x, unsigned long long *__restrict__ words) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= rows) return;  // (wave-uniform)
+    const bool on = x < cols && mask[(size_t)y * stride + x] != 0;  // IsNonzero, Hough.cu:183-187
+    const unsigned long long w = __ballot(on);
+    if ((threadIdx.x & 63) == 0) words[(size_t)y * tiles_x + blockIdx.x] = w;
+}
+// word i = row i / tiles_x, columns 64 (i % tiles_x) ..: bit b is the point with linear index y * cols + x
+struct MaskIndexEmit {
+    int32_t *out;
+    int tiles_x, cols;
+    __device__ void operator()(int64_t pos, int64_t i, int bit) const {
+        const int y = (int)(i / tiles_x);
+        out[pos] = y * cols + 64 * (int)(i - (int64_t)y * tiles_x) + bit;
+    }
+};
+
 struct TrigTable {
     float c[360], s[360];
 };
@@ -349,15 +371,28 @@ static int hough_points(micv_ctx *ctx, hipStream_t s, const uint8_t *mask, int r
                         size_t mstride, size_t extra_bytes, int32_t **pts, int64_t **npts,
                         char **extra) {
     const int64_t n = (int64_t)rows * cols;
+    const int tiles_x = cdiv(cols, 64);
+    const int64_t nwords = (int64_t)rows * tiles_x;
     void *scratch;
-    MICV_TRY(ctx->reserve(Carver::need(n, 4) + Carver::need(1, 8) + compact_scratch_bytes(n) +
+    MICV_TRY(ctx->reserve(Carver::need(n, 4) + Carver::need(1, 8) + Carver::need(nwords, 8) + compact_scratch_bytes(n) +
                               ((extra_bytes + 255) & ~size_t(255)),
                           &scratch));
     Carver c(scratch);
     *pts = c.take<int32_t>(n);
     *npts = c.take<int64_t>(1);
     *extra = c.take<char>(extra_bytes);
-    return ordered_compact(ctx, s, MaskPred{mask, cols, mstride}, IndexEmit{*pts}, n, n, *npts, c.base + c.off);
+    unsigned long long *words = c.take<unsigned long long>(nwords);
+    const int nchunks = compact_masks_chunks(nwords);
+    unsigned long long *status = nullptr;
+    unsigned *counters = nullptr;
+    if (ctx->opt[MICV_OPT_COMPACT_3PASS] <= 0 && ctx->compact_state(s, nchunks, &status, &counters) == MICV_OK) {
+        mask_words_kernel<<<dim3(tiles_x, cdiv(rows, 4)), 256, 0, s>>>(mask, mstride, rows, cols, tiles_x, words);
+        MICV_LAUNCH_CHECK();
+        launch_compact_masks(s, words, MaskIndexEmit{*pts, tiles_x, cols}, nwords, status, counters, n, *npts);
+        MICV_LAUNCH_CHECK();
+        return MICV_OK;
+    }
+    return ordered_compact3(s, MaskPred{mask, cols, mstride}, IndexEmit{*pts}, n, n, *npts, c.base + c.off);
 }
 
 int micv_hough_lines_dev(micv_ctx *ctx, const uint8_t *mask, int rows, int cols, size_t mstride,
