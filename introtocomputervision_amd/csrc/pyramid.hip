@@ -667,7 +667,17 @@ int micv_gaussian_pyramid_dev(micv_ctx *ctx, const float *src, int rows, int col
     for (int l = 0; l < levels; l++)
         MICV_REQUIRE(dst_levels[l] != nullptr, "micv_gaussian_pyramid: dst_levels[%d] is null", l);
     MICV_HIP(hipSetDevice(ctx->device));
-    return launch_pyr_build(static_cast<hipStream_t>(stream), src, 0, (int)(sstride / 4), rows,
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // level 0 is a copy of the input (Pyramids.cpp:9,18): a 2-D device copy; the levels below it then take the
+    // 16-byte-per-lane build (13 -> ~6 us at 1080p; the one-pixel-per-thread kernel builds level 0 as well otherwise)
+    if (levels > 1 && dst_levels[0] != src) {
+        MICV_HIP(hipMemcpy2DAsync(dst_levels[0], (size_t)cols * 4, src, sstride, (size_t)cols * 4, rows, hipMemcpyDeviceToDevice, s));
+        float *lv[16];
+        for (int l = 0; l < levels; l++) lv[l] = dst_levels[l];
+        lv[0] = nullptr;
+        return launch_pyr_build(s, src, 0, (int)(sstride / 4), rows, cols, levels, lv, 1);
+    }
+    return launch_pyr_build(s, src, 0, (int)(sstride / 4), rows,
                             cols, levels, dst_levels, 1);
 }
 
