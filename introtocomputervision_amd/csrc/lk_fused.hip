@@ -241,11 +241,20 @@ template <typename C>
 __device__ __forceinline__ void load_window_pairs(const float *__restrict__ A, int qy, int c0,
                                                   v2f (&w)[C::WV * 2]) {
     const v4f *a4 = reinterpret_cast<const v4f *>(A + qy * C::GS + c0);
+    // four outputs read W + 3 values: when that leaves the last pair unused (windows 15 and 43) the last load is a
+    // b64.  As a b128 its two dead registers were handed to the address arithmetic that follows the loads, and that
+    // write-after-write made hipcc drain all ten loads (lgkmcnt(0)) before the first product (r04).
+    constexpr int USED_PAIRS = (C::W + 3 + 1) / 2;
 #pragma unroll
     for (int i = 0; i < C::WV; i++) {
-        const v4f v = a4[i];
-        w[2 * i + 0] = (v2f){v.x, v.y};
-        w[2 * i + 1] = (v2f){v.z, v.w};
+        if (2 * i + 1 < USED_PAIRS) {
+            const v4f v = a4[i];
+            w[2 * i + 0] = (v2f){v.x, v.y};
+            w[2 * i + 1] = (v2f){v.z, v.w};
+        } else {
+            w[2 * i + 0] = *reinterpret_cast<const v2f *>(a4 + i);
+            w[2 * i + 1] = (v2f){0.f, 0.f};
+        }
     }
 }
 
@@ -389,9 +398,14 @@ __device__ __forceinline__ void col_pass_partial(const int (&cls)[4], float (&S)
     v2f acc0, acc1;
     lds_wait_upto4<6>(V[0], V[1], V[2], V[3]);
     skew_chain<SlotStride4, W, NP, 0>(acc0, V, g, range_seq<0, 8>{});
+    // the waits are volatile but the FMAs are not: without a fence the scheduler sinks the first chain's steps below
+    // the later waits (ISA: lgkmcnt(6), four FMAs, lgkmcnt(2), lgkmcnt(0), then everything else; with the fences the
+    // level-0 launch is another 0.65 % shorter in every round of the A/B, profiles/r04/lk_ab.txt)
+    __builtin_amdgcn_sched_barrier(0);
     lds_wait_upto4<2>(V[4], V[5], V[6], V[7]);
     skew_chain<SlotStride4, W, NP, 0>(acc0, V, g, range_seq<8, W + 1>{});
     skew_chain<SlotStride4, W, NP, 2>(acc1, V, g, range_seq<0, 14>{});
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[8]), "+v"(V[9]));
     skew_chain<SlotStride4, W, NP, 2>(acc1, V, g, range_seq<14, W + 1>{});
     S[0] = acc0.x;

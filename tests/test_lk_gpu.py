@@ -590,7 +590,22 @@ def test_32x64_tiles_are_bit_exact(mods, rows, cols, levels, batch):
     eu, ev = orc.lk_flow_pyr(prev[batch - 1], nxt[batch - 1], 15, levels)
     assert np.array_equal(host(u[batch - 1]), eu, equal_nan=True) and np.array_equal(host(v[batch - 1]), ev, equal_nan=True)
     with pytest.raises(Exception):
-        ctx.set_option(_capi.OPT_LK_TALL_TILES, 3)
+        ctx.set_option(_capi.OPT_LK_TALL_TILES, 4)  # 3 = the 1024-thread 64x32 experiment, the last valid value
+
+
+@pytest.mark.parametrize("rows,cols,levels,batch", [(1080, 1920, 5, 2), (700, 1000, 3, 3)])
+def test_1024_thread_tiles_are_bit_exact(mods, rows, cols, levels, batch):
+    """MICV_OPT_LK_TALL_TILES = 3: the 64x32 tile with 1024 threads (an r04 experiment kept as an option,
+    profiles/r04/lk_ab.txt).  Same bits as the default launch."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(5200 + i + rows, rows, cols, -2, 3) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    ctx = _capi.Context(0)
+    bu, bv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
+    ctx.set_option(_capi.OPT_LK_TALL_TILES, 3)
+    u, v = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
+    assert host(u).tobytes() == host(bu).tobytes() and host(v).tobytes() == host(bv).tobytes()
 
 
 @pytest.mark.parametrize("rows,cols,levels,batch", [(270, 480, 3, 1), (135, 240, 2, 8), (67, 120, 1, 3), (1080, 1920, 5, 1), (100, 333, 3, 2)])
