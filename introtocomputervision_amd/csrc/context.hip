@@ -333,6 +333,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: compaction form must be -1, 0 or 1");
     if (option == MICV_OPT_LK_DIRECT_LEVELS)
         MICV_REQUIRE(value >= 0 && value <= 15, "micv_ctx_set_option: direct levels must be 0..15");
+    if (option == MICV_OPT_LK_BUILD_OVERLAP)
+        MICV_REQUIRE(value >= -1 && value <= 100, "micv_ctx_set_option: build overlap must be -1 (off), 0 (on) or 1..100 (the top launch's share of level 1, per cent)");
     ctx->opt[option] = value;
     return MICV_OK;
 }

@@ -709,6 +709,11 @@ struct LkChain {
     int ostride;
     bool profile;                      // bracket level launches with events (group 0 only)
     int direct_from = 0;               // levels >= direct_from (>= 1) are read straight from level 0; 0 = none
+    // MICV_OPT_LK_BUILD_OVERLAP: no build launch -- the top level reads level 0 itself and the launches of levels
+    // top .. 2 carry the build of the levels below them as extra workgroups (LkBuildJob, lk_fused.hpp)
+    bool carry_build = false;
+    float *pyr_a = nullptr, *pyr_b = nullptr;  // the arenas of the whole batch (carry_build: nb = batch)
+    int top_pct = 0;                           // share of the level-1 rows the top launch takes, per cent
 };
 
 // Fused path: OpticalFlow.cpp:135-163 for all pairs of the chain, one launch per level.
@@ -726,7 +731,8 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.next = last ? c.next : c.npyr[k];
         a.img_stride = last ? c.stride : C;
         a.img_pair = last ? c.pair_elems : lvl_elems;
-        if (!last && c.direct_from > 0 && k >= c.direct_from) {
+        const bool direct = (c.direct_from > 0 && k >= c.direct_from) || (c.carry_build && k == plan.levels - 1);
+        if (!last && direct) {
             // Pyramids.cu:31 applied k times: L_k(y, x) = L_0(2^k y + 2^k - 1, 2^k x + 2^k - 1) -- the level is
             // level 0 seen through a row stride of 2^k rows and a pixel stride of 2^k (lk_fused.hip, GATHER)
             const size_t o = ((size_t)1 << k) - 1;
@@ -751,6 +757,31 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
         a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
         bool out_in_cur = false;
+        if (c.carry_build && k >= 2) {
+            // launches top .. 2 share the level-1 rows (32-row units): the top one takes top_pct per cent beside the coarse
+            // levels (which the very next launch reads), the others the rest in equal parts
+            const int top = plan.levels - 1, n_launch = top - 1, i = top - k;
+            const int rows1 = plan.rows[1], units = (rows1 + 31) / 32;
+            int u0, u1;
+            if (n_launch == 1) {
+                u0 = 0; u1 = units;
+            } else {
+                const int ut = units * c.top_pct / 100;
+                u0 = i == 0 ? 0 : ut + (int)((long)(units - ut) * (i - 1) / (n_launch - 1));
+                u1 = i == 0 ? ut : ut + (int)((long)(units - ut) * i / (n_launch - 1));
+            }
+            LkBuildJob &j = a.job;
+            j.src_a = c.prev; j.src_b = c.next; j.img_elems = c.pair_elems; j.sstride = c.stride;
+            j.batch = c.nb; j.rows = plan.rows[0]; j.cols = plan.cols[0];
+            j.pyr_a = c.pyr_a; j.pyr_b = c.pyr_b;
+            j.l1_y0 = u0 * 32 < rows1 ? u0 * 32 : rows1;
+            j.l1_y1 = u1 * 32 < rows1 ? u1 * 32 : rows1;
+            j.levels_end = top;  // the top level itself is read from level 0
+            j.l1_units = lk_build_l1_units(j.cols, j.l1_y0, j.l1_y1, j.batch);
+            j.lc_units = (k == top && top >= 3) ? lk_build_coarse_units(j.rows, j.cols, j.batch) : 0;
+            const long total = (long)j.l1_units + j.lc_units;
+            j.blocks = (int)(total < 4096 ? total : 4096);
+        }
         if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
         if (level == 0) {
             a.mode = LK_FLOW_NONE;  // du = dv = 0 (:132-133)
@@ -875,7 +906,33 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
         if ((long long)stride << (levels - 1) > 0x7fffffffLL) direct_from = 0;  // the row stride is an int
     }
     const int build_levels = direct_from > 0 ? (direct_from < levels ? direct_from : levels) : levels;
-    if (build_levels > 1) {
+    // MICV_OPT_LK_BUILD_OVERLAP (r04, default on; window 15, >= 3 levels, 16-byte rows): NO build launch.  The chain
+    // starts at the coarsest level with launches of a few workgroups whose time is latency, and 94 % of the build's
+    // bytes are level 1, which nobody reads before the second-to-last launch.  So the top level reads level 0 itself
+    // (the GATHER form), and the launches of levels top .. 2 carry the build as extra workgroups dispatched behind their
+    // tiles: the top one levels 2 .. top - 1 and a share of level 1, the others the rest of level 1.  A side stream for
+    // the level-1 build was tried first and LOST (one pass 0.3233 -> 0.3357 ms, single pair 0.0817 -> 0.0958: two
+    // cross-stream event waits cost more than the build).
+    // Measured on MI355X (A/B on one box, profiles/r04/build_overlap_ab.txt): single 1080p pair 0.0821 -> 0.0788 ms per
+    // call; 8 pairs, one pass at a time, 0.3260 -> 0.3159 ms; 8 pairs with TWO passes in flight (the bench) 0.2842 ->
+    // 0.2886 ms -- there the build launch (no LDS, 256 threads) already runs in the wave slots the other pass's level-0
+    // tiles leave free, while carried build workgroups hold a level tile's LDS.  So the default (0) carries the build for
+    // single pairs only -- the latency case; 1..100 carries it for any batch.
+    int groups = 1;
+    if (fused && batch >= 2) {
+        // one group by default: with the r02 level kernels a second group buys nothing for a single pass
+        // (0.4217 vs 0.4228 ms) and costs 2.5 % when passes overlap across contexts (bench.py --inflight 2)
+        groups = ctx->opt[MICV_OPT_LK_STREAM_GROUPS] > 0 ? ctx->opt[MICV_OPT_LK_STREAM_GROUPS] : 1;
+        groups = groups > 4 ? 4 : groups;
+        if (groups > batch) groups = batch;
+    }
+    const bool carry_build = fused && groups == 1 && direct_from == 0 && levels >= 3 &&
+                             (ctx->opt[MICV_OPT_LK_BUILD_OVERLAP] > 0 || (ctx->opt[MICV_OPT_LK_BUILD_OVERLAP] == 0 && batch == 1)) &&
+                             lk_fused_supports_direct_levels(win) && !ctx->opt[MICV_OPT_LK_NARROW_TILES] &&
+                             ctx->opt[MICV_OPT_LK_TALL_TILES] <= 0 && !ctx->opt[MICV_OPT_LK_STREAM] &&
+                             (long long)stride << (levels - 1) <= 0x7fffffffLL && (stride & 3) == 0 && (pair_elems & 3) == 0 &&
+                             (cols & 3) == 0 && ((reinterpret_cast<uintptr_t>(prev) | reinterpret_cast<uintptr_t>(next)) & 15) == 0;
+    if (build_levels > 1 && !carry_build) {
         float *pd[16], *nd[16];
         pd[0] = nd[0] = nullptr;
         for (int l = 1; l < levels; l++) {
@@ -907,6 +964,10 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
         c.ostride = ostride;
         c.profile = profile;
         c.direct_from = direct_from;
+        c.carry_build = carry_build;
+        c.pyr_a = ppyr;
+        c.pyr_b = npyr;
+        c.top_pct = ctx->opt[MICV_OPT_LK_BUILD_OVERLAP] > 0 ? ctx->opt[MICV_OPT_LK_BUILD_OVERLAP] : 20;
         return c;
     };
 
@@ -934,14 +995,6 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // are joined on the caller's stream.  A chain's coarse levels are tiny, latency-bound launches;
     // beside another group's launches they fill CUs that would otherwise idle (0.713 -> 0.671 ms per
     // 8-pair step on MI355X).  Groups share nothing but the read-only pyramids.
-    int groups = 1;
-    if (batch >= 2) {
-        // one group by default: with the r02 level kernels a second group buys nothing for a single pass
-        // (0.4217 vs 0.4228 ms) and costs 2.5 % when passes overlap across contexts (bench.py --inflight 2)
-        groups = ctx->opt[MICV_OPT_LK_STREAM_GROUPS] > 0 ? ctx->opt[MICV_OPT_LK_STREAM_GROUPS] : 1;
-        groups = groups > 4 ? 4 : groups;
-        if (groups > batch) groups = batch;
-    }
     if (groups > 1) MICV_TRY(ctx->fork(s, groups - 1));
     int rc = MICV_OK;
     for (int g = 0; g < groups && rc == MICV_OK; g++) {

@@ -1507,11 +1507,78 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
     }
 }
 
+// The extra workgroups of a launch that carries a pyramid-build job (LkBuildJob, lk_fused.hpp).  Plain copies: every
+// thread issues its loads for all its rows first, then stores.
+template <int NT>
+__device__ __forceinline__ void lk_build_block(const LkBuildJob &j, int block, int tid) {
+    constexpr int RPT = 32 / (NT / 64);  // rows per thread of a 32-row unit
+    static_assert(NT % 64 == 0 && 32 % (NT / 64) == 0, "a unit is 32 rows x 64 lanes");
+    const int lane = tid & 63, trow = (tid >> 6) * RPT;
+    const int total = j.lc_units + j.l1_units;
+    for (int u = block; u < total; u += j.blocks) {
+        if (u >= j.lc_units) {
+            // level 1: pixel (y, x) = level 0 (2y + 1, 2x + 1); the float4 at column 4 * x2 holds level-1 columns 2 * x2, 2 * x2 + 1
+            const int v = u - j.lc_units;
+            const int rows1 = j.rows >> 1, cols1 = j.cols >> 1;
+            const int bx = (cols1 + 127) / 128, by = (j.l1_y1 - j.l1_y0 + 31) / 32, per_img = bx * by;
+            const int img = v / per_img, r = v - img * per_img;
+            const int set = img / j.batch, b = img - set * j.batch;
+            const int byi = r / bx, bxi = r - byi * bx;
+            const int x2 = bxi * 64 + lane, y0 = j.l1_y0 + byi * 32 + trow;
+            if (2 * x2 >= cols1) continue;
+            const float *src = (set ? j.src_b : j.src_a) + b * j.img_elems + 4 * x2;
+            float *dst = (set ? j.pyr_b : j.pyr_a) + (size_t)b * rows1 * cols1 + 2 * x2;
+            float4 q[RPT];
+#pragma unroll
+            for (int i = 0; i < RPT; i++)
+                if (y0 + i < j.l1_y1) q[i] = *reinterpret_cast<const float4 *>(src + (size_t)(2 * (y0 + i) + 1) * j.sstride);
+#pragma unroll
+            for (int i = 0; i < RPT; i++)
+                if (y0 + i < j.l1_y1) *reinterpret_cast<float2 *>(dst + (size_t)(y0 + i) * cols1) = make_float2(q[i].y, q[i].w);
+        } else {
+            // level 2: pixel (y, x) = level 0 (4y + 3, 4x + 3); with y and x odd it is also level-3 pixel (y / 2, x / 2), and so on
+            const int rows2 = j.rows >> 2, cols2 = j.cols >> 2;
+            const int bx = (cols2 + 63) / 64, by = (rows2 + 31) / 32, per_img = bx * by;
+            const int img = u / per_img, r = u - img * per_img;
+            const int set = img / j.batch, b = img - set * j.batch;
+            const int byi = r / bx, bxi = r - byi * bx;
+            const int x = bxi * 64 + lane, y0 = byi * 32 + trow;
+            if (x >= cols2) continue;
+            const float *src = (set ? j.src_b : j.src_a) + b * j.img_elems + 4 * x + 3;
+            float *pyr = set ? j.pyr_b : j.pyr_a;
+            const size_t off2 = ((((size_t)(j.rows >> 1) * (j.cols >> 1)) + 63) & ~size_t(63)) * j.batch;  // lvl_off[2] * batch
+            float q[RPT];
+#pragma unroll
+            for (int i = 0; i < RPT; i++)
+                if (y0 + i < rows2) q[i] = src[(size_t)(4 * (y0 + i) + 3) * j.sstride];
+#pragma unroll
+            for (int i = 0; i < RPT; i++) {
+                if (y0 + i >= rows2) continue;
+                int yy = y0 + i, xx = x, ll = 2;
+                size_t off = off2;
+                pyr[off + (size_t)b * rows2 * cols2 + (size_t)yy * cols2 + xx] = q[i];
+                while (ll + 1 < j.levels_end && (yy & 1) && (xx & 1)) {
+                    off += ((((size_t)(j.rows >> ll) * (j.cols >> ll)) + 63) & ~size_t(63)) * j.batch;
+                    yy >>= 1;
+                    xx >>= 1;
+                    ll++;
+                    const int rl = j.rows >> ll, cl = j.cols >> ll;
+                    if (yy < rl && xx < cl) pyr[off + (size_t)b * rl * cl + (size_t)yy * cl + xx] = q[i];
+                }
+            }
+        }
+    }
+}
+
 template <int R, int MODE, int NTV, int THV = 32, bool GATHER = false, int TWV = 64>
 __global__ __launch_bounds__(NTV, lk_waves_per_simd_rt(R, NTV, THV)) void lk_level_kernel(LkLevelArgs a, TapsN<2 * R + 1> g) {
     using C = LkCfg<R, NTV, THV, TWV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int E = C::M > 2 ? C::M : 2;
+    if (blockIdx.y >= a.batch) {  // the launch carries a pyramid-build job: rows of the grid behind the pairs
+        lk_build_block<NTV>(a.job, (blockIdx.y - a.batch) * gridDim.x + blockIdx.x, threadIdx.x);
+        return;
+    }
     int tile_x, tile_y;
     lk_tile_of<C>(a, blockIdx.x, tile_x, tile_y);
     const int rx0 = tile_x * C::TW - C::H, ry0 = tile_y * C::TH + a.y_shift - C::H;
@@ -1533,6 +1600,10 @@ __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_chain_ke
     using C = LkCfg<R, NTV>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int E = C::M > 2 ? C::M : 2;
+    if (a.job.blocks && (int)blockIdx.x >= a.job.first_block) {  // the workgroups behind the schedule: a pyramid-build job
+        lk_build_block<NTV>(a.job, blockIdx.x - a.job.first_block, threadIdx.x);
+        return;
+    }
     const int4 e = sched[blockIdx.x];
     if (e.z <= 0) return;  // padding entry
     const int rx0 = e.x * C::TW - C::H, ry0 = e.y * C::TH - C::H;
@@ -1866,7 +1937,9 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
                         chain_dev = dev;
                     }
                 }
-                lk_level_chain_kernel<R, NTV, GATHER><<<nblocks, C::NT, C::LDS_BYTES, s>>>(a, taps, sched);
+                LkLevelArgs c = a;
+                c.job.first_block = nblocks;
+                lk_level_chain_kernel<R, NTV, GATHER><<<nblocks + c.job.blocks, C::NT, C::LDS_BYTES, s>>>(c, taps, sched);
                 MICV_LAUNCH_CHECK();
                 return MICV_OK;
             }
@@ -1878,7 +1951,13 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     LkLevelArgs b = a;
     b.y_shift = (a.row_begin > 0 && (a.mode == LK_FLOW_NONE || (a.row_begin & 1) == 0)) ? a.row_begin % C::TH : 0;
     const int tile_rows = b.y_shift ? cdiv(a.row_end - a.row_begin, C::TH) : cdiv(a.row_end, C::TH) - a.row_begin / C::TH;
-    const dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
+    dim3 grid(cdiv(a.cols, C::TW) * tile_rows, a.batch);
+    if (b.job.blocks > 0) {  // the build job's workgroups: whole rows of the grid behind the pairs (dispatched after the tiles)
+        long extra_y = cdiv(b.job.blocks, (int)grid.x);
+        if (a.batch + extra_y > 65535) extra_y = 65535 - a.batch;
+        b.job.blocks = (int)(extra_y * grid.x);  // every extra workgroup works; units beyond go round in the stride loop
+        grid.y = a.batch + (unsigned)extra_y;
+    }
     switch (a.mode) {
         case LK_FLOW_NONE:
             if constexpr (TWV == 64) lk_level_kernel<R, 0, NTV, THV, GATHER, TWV><<<grid, C::NT, C::LDS_BYTES, s>>>(b, taps);

@@ -41,7 +41,7 @@ struct PyrLevels {
     int rows[16], cols[16];
     int tiles_before[17];  // prefix sum of 64x4-tiles per level (levels 1..n-1 and level 0 copy)
     int n;
-    int chain;  // levels >= 2 are emitted by the level-1 tiles
+    int chain;  // the lowest level built (>= 1): ITS tiles also emit every deeper level; 0 = every level has its own tiles
     // Row-sharded builds: level l is written for rows [row_lo[l], row_hi[l]) only, and the level-1
     // tiles start at tile row l1_tile0 (full builds: 0 .. rows, 0).
     int row_lo[16], row_hi[16];
@@ -73,11 +73,11 @@ __global__ __launch_bounds__(256) void pyr_build_kernel(const float *__restrict_
     float *d = L.dst[l] + blockIdx.y * (size_t)L.rows[l] * L.cols[l];
     const float v = s[(size_t)((y << l) + sh) * sstride + (x << l) + sh];
     if (y >= L.row_lo[l] && y < L.row_hi[l]) d[(size_t)y * L.cols[l] + x] = v;
-    // Every level is a decimation of the previous one at odd coordinates, so the level-1 tiles
-    // also emit the deeper levels (which then have no tiles of their own): the source is read
-    // once, on its odd rows only.
-    if (l == 1 && L.chain) {
-        int yy = y, xx = x, ll = 1;
+    // Every level is a decimation of the previous one at odd coordinates, so the tiles of the lowest level
+    // built (level 1; level 2 when the level-1 build runs on a stream of its own, lk.hip) also emit the deeper
+    // levels (which then have no tiles of their own): the source is read once.
+    if (L.chain && l == L.chain) {
+        int yy = y, xx = x, ll = l;
         while (ll + 1 < L.n && (yy & 1) && (xx & 1)) {
             yy >>= 1;
             xx >>= 1;
@@ -565,6 +565,9 @@ int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, siz
         if (l1_hi > (rows >> 1)) l1_hi = rows >> 1;
         if (l1_lo >= l1_hi) return MICV_OK;
     }
+    int chain_level = 0;
+    for (int l = levels - 1; l >= 1; l--)
+        if (dst_a[l]) chain_level = l;
     for (int k = 0; k < 2; k++) {
         float *const *dst = k ? dst_b : dst_a;
         L[k].n = levels;
@@ -577,10 +580,10 @@ int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, siz
             L[k].tiles_before[l] = total;
             L[k].row_lo[l] = (row_lo && row_hi) ? row_lo[l] : 0;
             L[k].row_hi[l] = (row_lo && row_hi) ? row_hi[l] : L[k].rows[l];
-            // both sets use the same tiling (a skipped level must be skipped in both); with level 1
-            // present its tiles emit every deeper level
-            L[k].chain = levels > 1 && dst_a[1] != nullptr;
-            if (dst_a[l] && !(L[k].chain && l >= 2)) {
+            // both sets use the same tiling (a skipped level must be skipped in both); the tiles of the lowest
+            // level present emit every deeper level
+            L[k].chain = chain_level;
+            if (dst_a[l] && !(chain_level && l > chain_level)) {
                 if (restricted && l == 1)
                     total += cdiv(L[k].cols[l], 64) * (cdiv(l1_hi, 4) - l1_lo / 4);
                 else
@@ -590,7 +593,7 @@ int launch_pyr_build2(hipStream_t s, const float *src_a, const float *src_b, siz
         L[k].tiles_before[levels] = total;
     }
     if (total == 0) return MICV_OK;
-    const bool vec_ok = L[0].chain && !restricted && dst_a[0] == nullptr && (!dst_b || dst_b[0] == nullptr) &&
+    const bool vec_ok = L[0].chain == 1 && !restricted && dst_a[0] == nullptr && (!dst_b || dst_b[0] == nullptr) &&
                         (sstride & 3) == 0 && (img_elems & 3) == 0 && (cols & 3) == 0 && (L[0].cols[1] & 1) == 0 &&
                         ((reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(src_b)) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(dst_a[1]) & 7) == 0 && (!dst_b || (reinterpret_cast<uintptr_t>(dst_b[1]) & 7) == 0) &&

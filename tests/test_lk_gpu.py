@@ -593,6 +593,45 @@ def test_32x64_tiles_are_bit_exact(mods, rows, cols, levels, batch):
         ctx.set_option(_capi.OPT_LK_TALL_TILES, 4)  # 3 = the 1024-thread 64x32 experiment, the last valid value
 
 
+@pytest.mark.parametrize("rows,cols,levels,batch,pct", [(1080, 1920, 5, 2, 20), (1080, 1920, 5, 1, 50), (540, 960, 3, 1, 0), (272, 484, 4, 3, 1),
+                                                         (300, 332, 3, 2, 100), (96, 132, 5, 1, 0), (1080, 1920, 6, 8, 20), (2160, 3840, 5, 1, 0)])
+def test_carried_pyramid_build_is_bit_exact(mods, rows, cols, levels, batch, pct):
+    """MICV_OPT_LK_BUILD_OVERLAP (0 = single pairs only, n = every batch; window 15, >= 3 levels): no build launch -- the top level reads level 0
+    itself and the launches of levels top .. 2 carry the pyramid build as extra workgroups (LkBuildJob).  Same bits as
+    the single build launch in front (-1) and as the oracle, whatever share of level 1 the top launch takes; repeated
+    calls on one context rewrite the same arena."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(6200 + i + rows, rows, cols, 2, -3) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    ctx = _capi.Context(0)
+    assert ctx.get_option(_capi.OPT_LK_BUILD_OVERLAP) == 0
+    ctx.set_option(_capi.OPT_LK_BUILD_OVERLAP, pct)
+    u = torch.full((batch, rows, cols), float("nan"), device="cuda"); v = torch.full_like(u, float("nan"))
+    for rep in range(3):
+        lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx, out=(u, v))
+    ctx.set_option(_capi.OPT_LK_BUILD_OVERLAP, -1)
+    bu, bv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
+    assert host(u).tobytes() == host(bu).tobytes() and host(v).tobytes() == host(bv).tobytes()
+    if rows * cols * levels <= 1080 * 1920 * 5:
+        eu, ev = orc.lk_flow_pyr(prev[batch - 1], nxt[batch - 1], 15, levels)
+        assert np.array_equal(host(u[batch - 1]), eu, equal_nan=True) and np.array_equal(host(v[batch - 1]), ev, equal_nan=True)
+    with pytest.raises(Exception):
+        ctx.set_option(_capi.OPT_LK_BUILD_OVERLAP, 101)
+
+
+def test_carried_build_leaves_unaligned_inputs_to_the_build_launch(mods):
+    """Rows that are not 16-byte multiples (cols % 4 != 0) or a strided view: the carried build does not apply and the
+    call takes the build launch; results as the oracle's either way."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    for rows, cols in ((131, 203), (270, 482)):
+        p, n = synth.lk_pair(77 + cols, rows, cols, 1, 2)
+        u, v = lk.calcOpticalFlowPyr(dev(p), dev(n), winSize=15, levels=3)
+        eu, ev = orc.lk_flow_pyr(p, n, 15, 3)
+        assert np.array_equal(host(u), eu, equal_nan=True) and np.array_equal(host(v), ev, equal_nan=True)
+
+
 @pytest.mark.parametrize("rows,cols,levels,batch", [(1080, 1920, 5, 2), (700, 1000, 3, 3)])
 def test_1024_thread_tiles_are_bit_exact(mods, rows, cols, levels, batch):
     """MICV_OPT_LK_TALL_TILES = 3: the 64x32 tile with 1024 threads (an r04 experiment kept as an option,
