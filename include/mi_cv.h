@@ -65,7 +65,7 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 #define MICV_OPT_LK_TALL_TILES     11 /* 1024-thread tiles, one workgroup per CU, for big launches: window 15 on 64x64 tiles only with 1 (measured slower); window 21 on 64x32 tiles by default (0 or 1; measured faster); 2 = window 15 on 32x64 tiles, 512 threads, two workgroups per CU; 3 = window 15 on 64x32 tiles, 1024 threads, eight waves per SIMD (r04 experiments, both measured slower: DESIGN.md section 5); -1 = never */
 #define MICV_OPT_COMPACT_3PASS     12 /* ordered lists (corners, edge points, peak candidates, matches): 0 = one-launch chained scan up to 1 M elements, count / scan / emit launches beyond; 1 = always three launches; -1 = always one */
 #define MICV_OPT_LK_DIRECT_LEVELS  13 /* fused LK: pyramid levels >= n read straight from level 0 with a pixel stride (n = 1: no pyramid-build launch): 0 = off (default: measured faster one pass at a time, slower with two passes in flight), n = 1..15 */
-#define MICV_OPT_LK_BUILD_OVERLAP  14 /* fused LK, window 15, >= 3 levels: no pyramid-build launch -- the top level reads level 0 itself and the launches of levels top .. 2 carry the build of the levels below as extra workgroups behind their tiles: 0 = for single pairs only (default: the latency case; with several passes in flight a batch is faster with the build launch), -1 = never, 1..100 = for every batch, the value being the top launch's share of the level-1 rows in per cent (0 uses 20) */
+#define MICV_OPT_LK_BUILD_OVERLAP  14 /* fused LK, window 15, >= 3 levels: no pyramid-build launch -- the top level reads level 0 itself and the launch of every level k >= 2 carries the build of level k - 1 as extra workgroups behind its tiles: 0 = for single pairs only (default: the latency case; with several passes in flight a batch is faster with the build launch), -1 = never, 1 = for every batch */
 #define MICV_OPT_COUNT            15
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
 int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value);

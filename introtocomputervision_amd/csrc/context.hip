@@ -334,7 +334,7 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
     if (option == MICV_OPT_LK_DIRECT_LEVELS)
         MICV_REQUIRE(value >= 0 && value <= 15, "micv_ctx_set_option: direct levels must be 0..15");
     if (option == MICV_OPT_LK_BUILD_OVERLAP)
-        MICV_REQUIRE(value >= -1 && value <= 100, "micv_ctx_set_option: build overlap must be -1 (off), 0 (on) or 1..100 (the top launch's share of level 1, per cent)");
+        MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: build overlap must be -1 (never), 0 (single pairs) or 1 (every batch)");
     ctx->opt[option] = value;
     return MICV_OK;
 }

@@ -709,11 +709,10 @@ struct LkChain {
     int ostride;
     bool profile;                      // bracket level launches with events (group 0 only)
     int direct_from = 0;               // levels >= direct_from (>= 1) are read straight from level 0; 0 = none
-    // MICV_OPT_LK_BUILD_OVERLAP: no build launch -- the top level reads level 0 itself and the launches of levels
-    // top .. 2 carry the build of the levels below them as extra workgroups (LkBuildJob, lk_fused.hpp)
+    // MICV_OPT_LK_BUILD_OVERLAP: no build launch -- the top level reads level 0 itself and the launch of every level
+    // k >= 2 carries the build of level k - 1 as extra workgroups (LkBuildJob, lk_fused.hpp)
     bool carry_build = false;
     float *pyr_a = nullptr, *pyr_b = nullptr;  // the arenas of the whole batch (carry_build: nb = batch)
-    int top_pct = 0;                           // share of the level-1 rows the top launch takes, per cent
 };
 
 // Fused path: OpticalFlow.cpp:135-163 for all pairs of the chain, one launch per level.
@@ -757,30 +756,15 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
         a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
         bool out_in_cur = false;
-        if (c.carry_build && k >= 2) {
-            // launches top .. 2 share the level-1 rows (32-row units): the top one takes top_pct per cent beside the coarse
-            // levels (which the very next launch reads), the others the rest in equal parts
-            const int top = plan.levels - 1, n_launch = top - 1, i = top - k;
-            const int rows1 = plan.rows[1], units = (rows1 + 31) / 32;
-            int u0, u1;
-            if (n_launch == 1) {
-                u0 = 0; u1 = units;
-            } else {
-                const int ut = units * c.top_pct / 100;
-                u0 = i == 0 ? 0 : ut + (int)((long)(units - ut) * (i - 1) / (n_launch - 1));
-                u1 = i == 0 ? ut : ut + (int)((long)(units - ut) * i / (n_launch - 1));
-            }
+        if (c.carry_build && k >= 2) {  // this launch also builds level k - 1, which the next launch reads
             LkBuildJob &j = a.job;
+            j.level = k - 1;
             j.src_a = c.prev; j.src_b = c.next; j.img_elems = c.pair_elems; j.sstride = c.stride;
             j.batch = c.nb; j.rows = plan.rows[0]; j.cols = plan.cols[0];
             j.pyr_a = c.pyr_a; j.pyr_b = c.pyr_b;
-            j.l1_y0 = u0 * 32 < rows1 ? u0 * 32 : rows1;
-            j.l1_y1 = u1 * 32 < rows1 ? u1 * 32 : rows1;
-            j.levels_end = top;  // the top level itself is read from level 0
-            j.l1_units = lk_build_l1_units(j.cols, j.l1_y0, j.l1_y1, j.batch);
-            j.lc_units = (k == top && top >= 3) ? lk_build_coarse_units(j.rows, j.cols, j.batch) : 0;
-            const long total = (long)j.l1_units + j.lc_units;
-            j.blocks = (int)(total < 4096 ? total : 4096);
+            j.dst_off = plan.lvl_off[k - 1] * c.nb;
+            j.units = lk_build_units(j.rows, j.cols, j.level, j.batch);
+            j.blocks = j.units < 4096 ? j.units : 4096;
         }
         if (c.profile) MICV_TRY(ctx->prof_begin(k, c.s));
         if (level == 0) {
@@ -909,15 +893,15 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // MICV_OPT_LK_BUILD_OVERLAP (r04, default on; window 15, >= 3 levels, 16-byte rows): NO build launch.  The chain
     // starts at the coarsest level with launches of a few workgroups whose time is latency, and 94 % of the build's
     // bytes are level 1, which nobody reads before the second-to-last launch.  So the top level reads level 0 itself
-    // (the GATHER form), and the launches of levels top .. 2 carry the build as extra workgroups dispatched behind their
-    // tiles: the top one levels 2 .. top - 1 and a share of level 1, the others the rest of level 1.  A side stream for
+    // (the GATHER form), and the launch of every level k >= 2 carries the build of level k - 1 -- what the NEXT launch
+    // reads -- as extra workgroups dispatched behind its tiles.  A side stream for
     // the level-1 build was tried first and LOST (one pass 0.3233 -> 0.3357 ms, single pair 0.0817 -> 0.0958: two
     // cross-stream event waits cost more than the build).
     // Measured on MI355X (A/B on one box, profiles/r04/build_overlap_ab.txt): single 1080p pair 0.0821 -> 0.0788 ms per
     // call; 8 pairs, one pass at a time, 0.3260 -> 0.3159 ms; 8 pairs with TWO passes in flight (the bench) 0.2842 ->
     // 0.2886 ms -- there the build launch (no LDS, 256 threads) already runs in the wave slots the other pass's level-0
     // tiles leave free, while carried build workgroups hold a level tile's LDS.  So the default (0) carries the build for
-    // single pairs only -- the latency case; 1..100 carries it for any batch.
+    // single pairs only -- the latency case; 1 carries it for any batch.
     int groups = 1;
     if (fused && batch >= 2) {
         // one group by default: with the r02 level kernels a second group buys nothing for a single pass
@@ -967,7 +951,6 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
         c.carry_build = carry_build;
         c.pyr_a = ppyr;
         c.pyr_b = npyr;
-        c.top_pct = ctx->opt[MICV_OPT_LK_BUILD_OVERLAP] > 0 ? ctx->opt[MICV_OPT_LK_BUILD_OVERLAP] : 20;
         return c;
     };
 

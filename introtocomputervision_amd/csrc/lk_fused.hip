@@ -1508,64 +1508,42 @@ __device__ __forceinline__ void lk_tile_of(const LkLevelArgs &a, int bidx, int &
 }
 
 // The extra workgroups of a launch that carries a pyramid-build job (LkBuildJob, lk_fused.hpp).  Plain copies: every
-// thread issues its loads for all its rows first, then stores.
+// thread issues the loads of all its rows first, then stores.
 template <int NT>
 __device__ __forceinline__ void lk_build_block(const LkBuildJob &j, int block, int tid) {
     constexpr int RPT = 32 / (NT / 64);  // rows per thread of a 32-row unit
     static_assert(NT % 64 == 0 && 32 % (NT / 64) == 0, "a unit is 32 rows x 64 lanes");
     const int lane = tid & 63, trow = (tid >> 6) * RPT;
-    const int total = j.lc_units + j.l1_units;
-    for (int u = block; u < total; u += j.blocks) {
-        if (u >= j.lc_units) {
-            // level 1: pixel (y, x) = level 0 (2y + 1, 2x + 1); the float4 at column 4 * x2 holds level-1 columns 2 * x2, 2 * x2 + 1
-            const int v = u - j.lc_units;
-            const int rows1 = j.rows >> 1, cols1 = j.cols >> 1;
-            const int bx = (cols1 + 127) / 128, by = (j.l1_y1 - j.l1_y0 + 31) / 32, per_img = bx * by;
-            const int img = v / per_img, r = v - img * per_img;
-            const int set = img / j.batch, b = img - set * j.batch;
-            const int byi = r / bx, bxi = r - byi * bx;
-            const int x2 = bxi * 64 + lane, y0 = j.l1_y0 + byi * 32 + trow;
-            if (2 * x2 >= cols1) continue;
-            const float *src = (set ? j.src_b : j.src_a) + b * j.img_elems + 4 * x2;
-            float *dst = (set ? j.pyr_b : j.pyr_a) + (size_t)b * rows1 * cols1 + 2 * x2;
+    const int l = j.level, rl = j.rows >> l, cl = j.cols >> l;
+    const int bx = l == 1 ? (cl + 127) / 128 : (cl + 63) / 64, per_img = bx * ((rl + 31) / 32);
+    for (int u = block; u < j.units; u += j.blocks) {
+        const int img = u / per_img, r = u - img * per_img;
+        const int set = img / j.batch, b = img - set * j.batch;
+        const int byi = r / bx, bxi = r - byi * bx;
+        const int y0 = byi * 32 + trow;
+        const float *src = (set ? j.src_b : j.src_a) + b * j.img_elems;
+        float *dst = (set ? j.pyr_b : j.pyr_a) + j.dst_off + (size_t)b * rl * cl;
+        if (l == 1) {
+            // the float4 at level-0 column 4 * x2 of row 2y + 1 holds level-1 columns 2 * x2 and 2 * x2 + 1 (cols % 4 == 0)
+            const int x2 = bxi * 64 + lane;
+            if (2 * x2 >= cl) continue;
             float4 q[RPT];
 #pragma unroll
             for (int i = 0; i < RPT; i++)
-                if (y0 + i < j.l1_y1) q[i] = *reinterpret_cast<const float4 *>(src + (size_t)(2 * (y0 + i) + 1) * j.sstride);
+                if (y0 + i < rl) q[i] = *reinterpret_cast<const float4 *>(src + (size_t)(2 * (y0 + i) + 1) * j.sstride + 4 * x2);
 #pragma unroll
             for (int i = 0; i < RPT; i++)
-                if (y0 + i < j.l1_y1) *reinterpret_cast<float2 *>(dst + (size_t)(y0 + i) * cols1) = make_float2(q[i].y, q[i].w);
+                if (y0 + i < rl) *reinterpret_cast<float2 *>(dst + (size_t)(y0 + i) * cl + 2 * x2) = make_float2(q[i].y, q[i].w);
         } else {
-            // level 2: pixel (y, x) = level 0 (4y + 3, 4x + 3); with y and x odd it is also level-3 pixel (y / 2, x / 2), and so on
-            const int rows2 = j.rows >> 2, cols2 = j.cols >> 2;
-            const int bx = (cols2 + 63) / 64, by = (rows2 + 31) / 32, per_img = bx * by;
-            const int img = u / per_img, r = u - img * per_img;
-            const int set = img / j.batch, b = img - set * j.batch;
-            const int byi = r / bx, bxi = r - byi * bx;
-            const int x = bxi * 64 + lane, y0 = byi * 32 + trow;
-            if (x >= cols2) continue;
-            const float *src = (set ? j.src_b : j.src_a) + b * j.img_elems + 4 * x + 3;
-            float *pyr = set ? j.pyr_b : j.pyr_a;
-            const size_t off2 = ((((size_t)(j.rows >> 1) * (j.cols >> 1)) + 63) & ~size_t(63)) * j.batch;  // lvl_off[2] * batch
+            const int x = bxi * 64 + lane, sh = (1 << l) - 1;
+            if (x >= cl) continue;
             float q[RPT];
 #pragma unroll
             for (int i = 0; i < RPT; i++)
-                if (y0 + i < rows2) q[i] = src[(size_t)(4 * (y0 + i) + 3) * j.sstride];
+                if (y0 + i < rl) q[i] = src[(size_t)(((y0 + i) << l) + sh) * j.sstride + (x << l) + sh];
 #pragma unroll
-            for (int i = 0; i < RPT; i++) {
-                if (y0 + i >= rows2) continue;
-                int yy = y0 + i, xx = x, ll = 2;
-                size_t off = off2;
-                pyr[off + (size_t)b * rows2 * cols2 + (size_t)yy * cols2 + xx] = q[i];
-                while (ll + 1 < j.levels_end && (yy & 1) && (xx & 1)) {
-                    off += ((((size_t)(j.rows >> ll) * (j.cols >> ll)) + 63) & ~size_t(63)) * j.batch;
-                    yy >>= 1;
-                    xx >>= 1;
-                    ll++;
-                    const int rl = j.rows >> ll, cl = j.cols >> ll;
-                    if (yy < rl && xx < cl) pyr[off + (size_t)b * rl * cl + (size_t)yy * cl + xx] = q[i];
-                }
-            }
+            for (int i = 0; i < RPT; i++)
+                if (y0 + i < rl) dst[(size_t)(y0 + i) * cl + x] = q[i];
         }
     }
 }

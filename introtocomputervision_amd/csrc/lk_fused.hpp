@@ -13,21 +13,21 @@ enum LkFlowMode {
 };
 
 // Pyramid-build work carried by a level launch (r04, MICV_OPT_LK_BUILD_OVERLAP): `blocks` extra workgroups behind the
-// launch's tiles copy parts of the pyramids this chain reads LATER (Pyramids.cu:31 -- every level is level 0 at odd
-// coordinates), so the build is not a 20 us launch in front of the latency-bound coarse levels.  A unit = 32 rows x
-// 64 lanes: level-1 units take rows [l1_y0, l1_y1) (a 16-byte load keeps two pixels), coarse units take level 2 and
-// emit every deeper level below `levels_end` from it.  Layout = PyrPlan: level l of pair b at
-// pyr + lvl_off[l] * batch + b * rows_l * cols_l, lvl_off[1] = 0, lvl_off[l + 1] = lvl_off[l] + roundup64(rows_l * cols_l).
+// launch's tiles copy the pyramid level the NEXT launch of the chain reads (Pyramids.cu:31 -- every level is level 0
+// at odd coordinates: L_l(y, x) = L_0(2^l (y + 1) - 1, 2^l (x + 1) - 1)), so the build is not a launch in front of the
+// latency-bound coarse levels.  A unit = 32 rows x 64 lanes of level `level` (level 1: 128 columns, a 16-byte load keeps
+// two pixels).  Layout = PyrPlan: level l of pair b at pyr + lvl_off[l] * batch + b * rows_l * cols_l; `dst_off` is
+// lvl_off[level] * batch.
 struct LkBuildJob {
     int blocks = 0;                // extra workgroups (0 = none); units beyond are taken in a stride loop
     int first_block = 0;           // 1-D (chain) launches: the first extra block index
-    int lc_units = 0, l1_units = 0;
+    int units = 0;
+    int level = 0;                 // the pyramid level built (>= 1)
     const float *src_a = nullptr, *src_b = nullptr;  // level 0 of the two image sets (prev / next), pairs img_elems apart
     size_t img_elems = 0;
     int sstride = 0, batch = 0, rows = 0, cols = 0;  // level-0 geometry
     float *pyr_a = nullptr, *pyr_b = nullptr;        // the two pyramid arenas (levels >= 1)
-    int l1_y0 = 0, l1_y1 = 0;      // level-1 rows of this launch
-    int levels_end = 0;            // coarse units write levels 2 .. levels_end - 1
+    size_t dst_off = 0;
 };
 
 struct LkLevelArgs {
@@ -65,12 +65,10 @@ struct LkLevelArgs {
     LkBuildJob job;
 };
 
-// units of a build job (host side): level-1 rows [y0, y1) / the coarse levels of `batch` pairs, both image sets
-inline int lk_build_l1_units(int cols, int y0, int y1, int batch) {
-    return y1 > y0 ? (((cols >> 1) + 127) / 128) * ((y1 - y0 + 31) / 32) * 2 * batch : 0;
-}
-inline int lk_build_coarse_units(int rows, int cols, int batch) {
-    return (((cols >> 2) + 63) / 64) * (((rows >> 2) + 31) / 32) * 2 * batch;
+// units of a build job (host side): level `level` of `batch` pairs, both image sets
+inline int lk_build_units(int rows, int cols, int level, int batch) {
+    const int r = rows >> level, c = cols >> level;
+    return ((c + (level == 1 ? 127 : 63)) / (level == 1 ? 128 : 64)) * ((r + 31) / 32) * 2 * batch;
 }
 
 bool lk_fused_supports(int win);
