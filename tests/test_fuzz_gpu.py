@@ -319,3 +319,9 @@ def test_fuzz_rowshard_virtual_and_level_options(shape, seed, kind, win, levels,
         ctx.set_option(_capi.OPT_LK_DIRECT_LEVELS, direct)
         du, dv = lk.calcOpticalFlowPyrBatch(dp, dn, win, levels, ctx=ctx)
         assert same(host(du), host(ru)) and same(host(dv), host(rv)), (rows, cols, win, levels, direct)
+        ctx.set_option(_capi.OPT_LK_DIRECT_LEVELS, 0)
+    # the pyramid build carried by the level launches (every batch) / never: same bits as the default
+    for carried in (1, -1):
+        ctx.set_option(_capi.OPT_LK_BUILD_OVERLAP, carried)
+        cu, cv = lk.calcOpticalFlowPyrBatch(dp, dn, win, levels, ctx=ctx)
+        assert same(host(cu), host(ru)) and same(host(cv), host(rv)), (rows, cols, win, levels, batch, carried)
