@@ -594,7 +594,8 @@ def test_32x64_tiles_are_bit_exact(mods, rows, cols, levels, batch):
 
 
 @pytest.mark.parametrize("rows,cols,levels,batch,pct", [(1080, 1920, 5, 2, 1), (1080, 1920, 5, 1, 0), (540, 960, 3, 1, 0), (272, 484, 4, 3, 1),
-                                                         (300, 332, 3, 2, 1), (96, 132, 5, 1, 0), (1080, 1920, 6, 8, 1), (2160, 3840, 5, 1, 0), (1000, 4100, 4, 1, 0)])
+                                                         (300, 332, 3, 2, 1), (96, 132, 5, 1, 0), (1080, 1920, 6, 8, 1), (2160, 3840, 5, 1, 0), (1000, 4100, 4, 1, 0),
+                                                         (2160, 3840, 3, 5, 1)])  # the last: more build units than carried workgroups (stride loop)
 def test_carried_pyramid_build_is_bit_exact(mods, rows, cols, levels, batch, pct):
     """MICV_OPT_LK_BUILD_OVERLAP (0 = single pairs only, n = every batch; window 15, >= 3 levels): no build launch -- the top level reads level 0
     itself and the launches of levels top .. 2 carry the pyramid build as extra workgroups (LkBuildJob).  Same bits as
