@@ -335,6 +335,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= 0 && value <= 15, "micv_ctx_set_option: direct levels must be 0..15");
     if (option == MICV_OPT_LK_BUILD_OVERLAP)
         MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: build overlap must be -1 (never), 0 (single pairs) or 1 (every batch)");
+    if (option == MICV_OPT_LK_SPLIT)
+        MICV_REQUIRE(value >= 0 && value <= 3, "micv_ctx_set_option: split launch must be 0 (never) .. 3");
     ctx->opt[option] = value;
     return MICV_OK;
 }

@@ -713,6 +713,9 @@ struct LkChain {
     // k >= 2 carries the build of level k - 1 as extra workgroups (LkBuildJob, lk_fused.hpp)
     bool carry_build = false;
     float *pyr_a = nullptr, *pyr_b = nullptr;  // the arenas of the whole batch (carry_build: nb = batch)
+    // MICV_OPT_LK_SPLIT (lk_split.hip): the chain's block of padded gradient planes, sized for its largest split level
+    float *grad = nullptr;
+    size_t grad_elems = 0;  // floats available (all pairs of the chain)
 };
 
 // Fused path: OpticalFlow.cpp:135-163 for all pairs of the chain, one launch per level.
@@ -755,6 +758,17 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
         a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
         a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
+        a.split = ctx->opt[MICV_OPT_LK_SPLIT];
+        if (c.grad && !direct) {
+            const LkGradGeom gg = lk_grad_geom(R, C, win);
+            if (gg.pair_elems * c.nb <= c.grad_elems) {
+                a.grad = c.grad;
+                a.grad_pair = gg.pair_elems;
+                a.grad_pitch = gg.pitch;
+                a.grad_rows = gg.rows;
+                a.grad_pad = gg.pad;
+            }
+        }
         bool out_in_cur = false;
         if (c.carry_build && k >= 2) {  // this launch also builds level k - 1, which the next launch reads
             LkBuildJob &j = a.job;
@@ -863,9 +877,21 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // coarse levels are launches of a few workgroups whose time is latency, and the pairs' launches overlap.
     const int gen_groups = fused ? 0 : (batch < 4 ? batch : 4);
     if (!fused) total += (Carver::need(n0, 4) * 3 + Carver::need(lk_generic_scratch(rows, cols), 4)) * gen_groups;
+    // MICV_OPT_LK_SPLIT: the padded gradient planes of the largest level some launch of the chain will split (the
+    // levels run one after the other on the chain's stream and share the block)
+    size_t grad_elems = 0;
+    if (fused && lk_split_supports(win) && ctx->opt[MICV_OPT_LK_SPLIT] > 0)
+        for (int l = 0; l + 1 < levels; l++)  // the coarsest level has no coarse flow
+            if (plan.rows[l] == 2 * plan.rows[l + 1] && plan.cols[l] == 2 * plan.cols[l + 1] &&
+                lk_split_wanted(plan.rows[l], plan.cols[l], batch, win, 1, ctx->opt[MICV_OPT_LK_SPLIT])) {
+                const size_t e = lk_grad_geom(plan.rows[l], plan.cols[l], win).pair_elems * batch;
+                grad_elems = e > grad_elems ? e : grad_elems;
+            }
+    total += Carver::need(grad_elems, 4);
     void *base;
     MICV_TRY(ctx->reserve(total, &base));
     Carver carve(base);
+    float *grad = grad_elems ? carve.take<float>(grad_elems) : nullptr;
     float *ppyr = carve.take<float>(plan.pyr_elems * batch);
     float *npyr = carve.take<float>(plan.pyr_elems * batch);
     float *fu[2] = {carve.take<float>(flow_elems * batch), carve.take<float>(flow_elems * batch)};
@@ -951,6 +977,10 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
         c.carry_build = carry_build;
         c.pyr_a = ppyr;
         c.pyr_b = npyr;
+        if (grad) {  // a group's share of the block: pairs b0 .. b0 + nb of `batch`
+            c.grad = grad + (grad_elems / batch) * b0;
+            c.grad_elems = (grad_elems / batch) * nb;
+        }
         return c;
     };
 

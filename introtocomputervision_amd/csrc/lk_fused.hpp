@@ -63,7 +63,55 @@ struct LkLevelArgs {
     unsigned long long *stamps = nullptr;
     int stop_after = -1;
     LkBuildJob job;
+    // Split launch (r05, MICV_OPT_LK_SPLIT; lk_split.hip): when `grad` is set and the launch qualifies, a pre-pass writes
+    // Ix, Iy, It of every pixel into padded planes -- pixel (y, x) of pair p at grad[p * grad_pair + (y + grad_pad) *
+    // 3 * grad_pitch + plane * grad_pitch + x + grad_pad], the grad_pad cells around the image = BORDER_REFLECT_101
+    // copies -- and the base flow into out_u / out_v; the streaming sums kernel does the rest.
+    float *grad = nullptr;
+    size_t grad_pair = 0;
+    int grad_pitch = 0, grad_rows = 0, grad_pad = 0;
+    int split = 0;  // MICV_OPT_LK_SPLIT
+    int pre_base = 0;  // pre-pass tiles store the base flow into out_u / out_v (LkSumsArgs::base == 1)
+    int pre_warp = 0;  // variant A': pre-pass tiles store the warped image (dense plane at grad) and the base flow only
+    int base_rmw = 0;  // no-flow mode: out_u / out_v hold a base flow to add (second half of an A' split launch)
 };
+
+// Geometry of the padded gradient planes of a rows x cols level for window `win` (host side; floats per pair).
+struct LkGradGeom {
+    int pad, pitch, rows;
+    size_t pair_elems;
+};
+inline LkGradGeom lk_grad_geom(int rows, int cols, int win) {
+    LkGradGeom g;
+    g.pad = win / 2;
+    g.pitch = ((cols + 63) / 64) * 64 + ((2 * g.pad + 2 + 3) & ~3);  // a strip reads 64 + 2 pad (+ 2) columns, 16-byte chunks
+    g.rows = ((rows + 15) & ~15) + 2 * g.pad;                      // blocks of 16 rows + the window's rows below the last
+    g.pair_elems = (size_t)g.rows * 3 * g.pitch;
+    return g;
+}
+bool lk_split_supports(int win);
+// does launch_lk_level_fused split this launch (given a.grad)?  Host side; also used to size the scratch arena.
+bool lk_split_wanted(int rows, int cols, int batch, int win, int mode, int split_opt);
+
+// The streaming sums kernel (lk_split.hip)
+struct LkSumsArgs {
+    const float *grad;
+    size_t grad_pair;
+    int gpitch;
+    int rows, cols, batch;
+    int strips, segs, seg_rows;  // work items = batch * segs * strips
+    float *out_u, *out_v;
+    int out_stride;
+    size_t out_pair;
+    // out = base + flow (OpticalFlow.cpp:161-162): 0 = no base, 1 = out_u / out_v hold it (the pre-pass wrote it),
+    // 2 = 2 * pyrUp of the coarse flow, recomputed for the kernel's own pixels
+    int base;
+    const float *flow_u, *flow_v;
+    int flow_rows, flow_cols;
+    size_t flow_pair;
+};
+void lk_sums_partition(int rows, int cols, int batch, int slots, int *strips, int *segs, int *seg_rows);
+int launch_lk_sums(hipStream_t s, const LkSumsArgs &a, int win);
 
 // units of a build job (host side): level `level` of `batch` pairs, both image sets
 inline int lk_build_units(int rows, int cols, int level, int batch) {

@@ -805,3 +805,31 @@ def test_streamed_launch_with_stream_groups(mods):
         v = torch.full((batch, rows, cols), float("nan"), device="cuda")
         lk.calcOpticalFlowPyrBatch(prev, nxt, 15, levels, ctx=ctx, out=(u, v))
         assert torch.equal(u, ref[0]) and torch.equal(v, ref[1]), rep
+
+
+@pytest.mark.parametrize("rows,cols,levels,batch", [(128, 128, 2, 1), (270, 480, 3, 2), (540, 960, 3, 3), (1080, 1920, 5, 2), (64, 64, 2, 1),
+                                                     (200, 328, 2, 5), (1088, 1924, 2, 1), (66, 1000, 2, 2), (1000, 68, 2, 2), (2160, 3840, 3, 1)])
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_split_level_launch_is_bit_exact(mods, rows, cols, levels, batch, mode):
+    """MICV_OPT_LK_SPLIT (r05, lk_split.hip): a level launch as a pre-pass -- pyrUp + warp + Sobel once per pixel, Ix / Iy / It
+    into padded planes whose ring holds the BORDER_REFLECT_101 copies, base flow into u, v -- plus the streaming
+    window-sum kernel.  1 = every launch that can, 0 = never (the default: the split measured slower):
+    same bits, and the oracle's.  Repeated calls rewrite the same planes."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(8100 + i + rows, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_SPLIT, mode)  # 2: base flow through u, v; 3: variant A' (warped image only)
+    u = torch.full((batch, rows, cols), float("nan"), device="cuda"); v = torch.full_like(u, float("nan"))
+    for rep in range(2):
+        lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx, out=(u, v))
+    ctx.set_option(_capi.OPT_LK_SPLIT, 0)
+    bu, bv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
+    du = host(u).view(np.uint32) != host(bu).view(np.uint32); dv = host(v).view(np.uint32) != host(bv).view(np.uint32)
+    assert not du.any() and not dv.any(), (int(du.sum()), int(dv.sum()), np.argwhere(du | dv)[:8].tolist())
+    if rows * cols * levels <= 1080 * 1920 * 5:
+        eu, ev = orc.lk_flow_pyr(prev[batch - 1], nxt[batch - 1], 15, levels)
+        assert np.array_equal(host(u[batch - 1]), eu, equal_nan=True) and np.array_equal(host(v[batch - 1]), ev, equal_nan=True)
+    with pytest.raises(Exception):
+        ctx.set_option(_capi.OPT_LK_SPLIT, 4)

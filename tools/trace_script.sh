@@ -16,4 +16,4 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:40]:
     print(f'{r["Name"][:100]:100s} calls={int(r["Calls"]):5d} avg_us={float(r["AverageNs"])/1e3:9.2f}')
 PY
-find "$out" -name '*kernel_trace.csv' -size +2M -delete 2>/dev/null
+[ -n "$KEEP_TRACE" ] || find "$out" -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
