@@ -569,6 +569,31 @@ def main(argv=None):
         torch.cuda.synchronize()
         return max_and_all(time.perf_counter() - t0, dev)
 
+    # N > 1, before anything is timed: (1) micv_comm_selftest -- the C ABI's communicator over RCCL, a ring of grouped
+    # ncclSend / ncclRecv of a rank-stamped slab + an int32 all-reduce, verified on the device -- so that a fabric or
+    # ordering failure is reported as such and not as a parity mismatch (rowshard mode: its own communicator, a failure
+    # is fatal; pairs mode: an extra communicator used for nothing else, a failure is recorded, the data path has no
+    # collective to break); (2) in pairs mode every rank's first pair is checked against rank 0's own recomputation of
+    # that rank's seed after the timed runs (`per_rank_parity` below).
+    comm_selftest = None
+    if dist is not None:  # (also at world 1 when the RCCL path is forced: tests/test_rccl_gpu.py)
+        try:
+            if args.mode == "rowshard" and args.next_margin is None:
+                runner.comm.selftest(stream)
+            else:
+                from introtocomputervision_amd import shard as _shard
+                _tc = _shard.MicvComm(ctx, rank, n_gpus, dist=dist)
+                _tc.selftest(stream)
+                _tc.close()
+            comm_selftest = "ok"
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+            comm_selftest = f"FAILED on rank {rank}: {e}"
+            if args.mode == "rowshard":
+                raise
+        gathered = [None] * world
+        dist.all_gather_object(gathered, comm_selftest)
+        comm_selftest = "ok" if all(g == "ok" for g in gathered) else "; ".join(str(g) for g in gathered if g != "ok")
+
     ctx.warmup(stream)
     # Pre-roll (untimed, before the W warm-up steps): the first ~30 ms of work after the device has
     # idled run ~15 % slower (power state ramp; measured 43 vs 50 Gpix/s at W=5, K=20), and W steps are
@@ -649,6 +674,34 @@ def main(argv=None):
     um = float(chk_u.median())
     vm = float(chk_v.median())
     ok = abs(um - 3.0) < 0.25 and abs(vm + 2.0) < 0.25
+
+    # Per-rank parity (N > 1, pairs mode): an exact checksum of every rank's first pair (sums of the flow's bit patterns,
+    # plain and position-weighted, as int64) is gathered; rank 0 recomputes each rank's pair from its seed on its own
+    # GPU and compares -- the SCALE line then carries every rank's result, not rank 0's only.
+    def flow_checksum(fu, fv):
+        out = []
+        for f in (fu, fv):
+            b = f.contiguous().view(torch.int32).to(torch.int64).flatten()
+            w = (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 65521) + 1
+            out += [int(b.sum().item()), int((b * w).sum().item())]
+        return out
+    per_rank_parity = None
+    if dist is not None and args.mode == "pairs":
+        lk.calcOpticalFlowPyrBatch(prev, nxt, WIN, LEVELS, ctx=ctx, out=(u, v), stream=stream)
+        torch.cuda.synchronize()
+        mine = flow_checksum(u[0], v[0])
+        sums = [None] * world
+        dist.all_gather_object(sums, mine)
+        if rank == 0:
+            bad = []
+            for r in range(1, world):
+                pr, nr = synth.lk_pair(0x5EED0005 + r * B, ROWS, COLS, 3, -2)
+                ru, rv = lk.calcOpticalFlowPyrBatch(torch.from_numpy(pr[None]).to(dev), torch.from_numpy(nr[None]).to(dev), WIN, LEVELS, ctx=ctx)
+                torch.cuda.synchronize()
+                if flow_checksum(ru[0], rv[0]) != sums[r]:
+                    bad.append(r)
+            per_rank_parity = {"ranks_checked": world, "mismatching_ranks": bad, "ok": not bad,
+                               "method": "int64 checksums of pair 0's (u, v) bit patterns per rank vs rank 0's recomputation of that rank's seed"}
 
     # Dominant kernel (fused level-0 LK) timed with HIP events on the launch stream, in a
     # second pass of the same K steps (events around every level launch; library hook).
@@ -764,6 +817,8 @@ def main(argv=None):
                                 if args.next_margin is None else f"row-shard{n_gpus} (coarse-flow halo, torch p2p, declared next margin)"),
                 "mode": args.mode,
                 "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                "comm_selftest": comm_selftest,
+                "per_rank_parity": per_rank_parity,
                 "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
                 "flow_check": {"median_u": um, "median_v": vm, "ok": ok},
                 "parity_1080p": None if parity is None else parity["bit_exact"],

@@ -171,6 +171,14 @@ int micv_comm_unique_id(void *id128);
 int micv_comm_create(micv_ctx *ctx, void *nccl_comm, const void *unique_id128, int rank, int world, micv_comm **out);
 int micv_comm_destroy(micv_comm *comm);
 int micv_comm_rank(const micv_comm *comm, int *rank, int *world);
+/* A communicator owns ONE device block (pyramids, per-level flow, exchange slabs) that every sharded call carves anew:
+ * use a communicator from ONE stream at a time (calls on one stream queue up correctly; two streams would race on the
+ * block silently), and with the context of the device it was created on (checked: MICV_EINVAL otherwise). */
+/* Fabric check to run once before timing or trusting sharded results (collective, synchronises `stream`): a ring of
+ * grouped ncclSend / ncclRecv of a rank-stamped 256 KB slab -- the row-shard driver's exchange pattern -- and one int32
+ * sum all-reduce, both verified ON THE DEVICE.  MICV_OK, or MICV_EHIP with micv_last_error() naming the rank, the peer
+ * and the step: a fabric or ordering failure then reads as such, not as a parity mismatch of the flow. */
+int micv_comm_selftest(micv_ctx *ctx, micv_comm *comm, micv_stream stream);
 /* The row plan, host only: rows [row_begin, row_end) of pyramid level `level` that `rank` of `world` computes
  * (the coarsest level is cut evenly, finer levels double the cuts), and optionally the rows of that level it
  * needs to compute the next finer one (its band + halo). */
@@ -208,6 +216,11 @@ int micv_allreduce_sum_i32_dev(micv_ctx *ctx, micv_comm *comm, int32_t *buf, siz
  * Entry i = (tile x, first tile y, tiles in the chain, pair), 0 tiles = padding; tiles are
  * tile_w x tile_h pixels.  *count = entries of the list (also when entries_xycp is NULL or smaller).
  * Every tile of every pair must appear in exactly one entry -- tests/test_capi_and_host.py checks it. */
+/* Diagnostic, no launch: the name (as rocprofv3 prints it, without the `micv::` prefix and the argument list) of the
+ * kernel instantiation(s) the fused path launches for a rows x cols pyramid level of `batch` pairs with a doubling
+ * coarse flow under this context's options -- answered by the launch dispatch itself, so that tools filtering profiler
+ * rows by kernel name cannot drift from it.  cap >= 96. */
+int micv_lk_level_kernel_name(micv_ctx *ctx, int win, int rows, int cols, int batch, char *buf, size_t cap);
 int micv_lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, int32_t *entries_xycp,
                           int64_t capacity, int64_t *count, int *tile_w, int *tile_h);
 

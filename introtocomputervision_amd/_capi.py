@@ -107,6 +107,8 @@ SIGNATURES = {
     "micv_comm_create": (i32, [vp, vp, vp, i32, i32, C.POINTER(vp)]),
     "micv_comm_destroy": (i32, [vp]),
     "micv_comm_rank": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+    "micv_comm_selftest": (i32, [vp, vp, vp]),
+    "micv_lk_level_kernel_name": (i32, [vp, i32, i32, i32, i32, C.c_char_p, sz]),
     "micv_rowshard_band": (i32, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "micv_lk_flow_pyr_rowshard_dev": (i32, [vp, vp, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, vp]),
     "micv_lk_flow_pyr_rowshard_virtual_dev": (i32, [vp, i32, vp, vp, i32, sz, i32, i32, sz, i32, i32, vp, vp, sz, sz, i32, vp]),
@@ -210,28 +212,11 @@ class Context:
 
     def lk_level_kernel_name(self, win=15, rows=1080, cols=1920, batch=8):
         """The level-kernel instantiation launch_lk_level_fused picks for a rows x cols level of `batch` pairs with
-        a doubling coarse flow (mode 1), following csrc/lk_fused.hip's dispatch and this context's options."""
-        r = win // 2
-        if self.get_option(OPT_LK_NARROW_TILES):
-            return f"lk_level_kernel<{r}, 1, 256, 32, false, 64>"
-        if win == 21:
-            if self.get_option(OPT_LK_TALL_TILES) == 0 and -(-cols // 64) * -(-rows // 64) * batch >= 256:
-                return "lk_level_kernel<10, 1, 1024, 64, false, 64>"
-            big = self.get_option(OPT_LK_TALL_TILES) >= 0 and -(-cols // 64) * -(-rows // 32) * batch >= 512
-            return "lk_level_kernel<10, 1, 1024, 32, false, 64>" if big else "lk_level_kernel<10, 1, 512, 16, false, 64>"
-        if win != 15:
-            return f"lk_level_kernel<{r}, 1, 512, 32, false, 64>"
-        short = self.get_option(OPT_LK_SHORT_TILES)
-        if short >= 0 and -(-cols // 64) * -(-rows // 16) * batch <= (short if short > 0 else 512):
-            return "lk_level_kernel<7, 1, 512, 16, false, 64>"
-        if self.get_option(OPT_LK_TALL_TILES) == 2 and -(-cols // 32) * -(-rows // 64) * batch >= 1024:
-            return "lk_level_kernel<7, 1, 512, 64, false, 32>"
-        tall = self.get_option(OPT_LK_TALL_TILES) == 1 and -(-cols // 64) * -(-rows // 64) * batch >= 1024
-        if self.get_option(OPT_LK_STREAM):
-            return "lk_level_stream_kernel<7, 1024, 64>" if tall else "lk_level_stream_kernel<7, 512, 32>"
-        if self.get_option(OPT_LK_CHAIN) > 1 or self.get_option(OPT_LK_CHAIN) < 0:
-            return "lk_level_chain_kernel<7, 512, false>"
-        return "lk_level_kernel<7, 1, 1024, 64, false, 64>" if tall else "lk_level_kernel<7, 1, 512, 32, false, 64>"
+        a doubling coarse flow (mode 1) under this context's options -- asked of the dispatch itself
+        (micv_lk_level_kernel_name: same code path as a launch, nothing launched)."""
+        buf = C.create_string_buffer(160)
+        check(lib.micv_lk_level_kernel_name(self._h, int(win), int(rows), int(cols), int(batch), buf, 160))
+        return buf.value.decode()
 
     def profile(self, on=True):
         check(lib.micv_profile_enable(self._h, 1 if on else 0))

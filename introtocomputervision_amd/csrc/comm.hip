@@ -13,7 +13,26 @@
 // images are static inputs; the flow is the only dynamic exchange).  Results equal the unsharded call bit for
 // bit: the band launches are micv_lk_level_batch_dev, i.e. the same kernels on a row range.
 #include <dlfcn.h>
+// RCCL is dlopen'ed, so its header is only a source of types: a ROCm install without the RCCL development files still
+// builds libmicv.so from the handful of declarations below -- the NCCL 2.x ABI these entry points use, fixed
+// since NCCL 2.0 (-DMICV_NO_RCCL_HEADER forces this branch; tests/test_capi_and_host.py compiles it).  With the header
+// present the static_asserts hold the two in step.
+#if defined(__has_include) && !defined(MICV_NO_RCCL_HEADER)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define MICV_HAVE_RCCL_H 1
+#endif
+#endif
+#ifdef MICV_HAVE_RCCL_H
+static_assert(sizeof(ncclUniqueId) == 128 && (int)ncclSuccess == 0 && (int)ncclInt32 == 2 && (int)ncclFloat32 == 7 && (int)ncclSum == 0,
+              "the local declarations below state the same ABI");
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;  // other values are only ever handed to ncclGetErrorString
+typedef enum { ncclInt32 = 2, ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 #include <cstring>
 #include <mutex>
@@ -253,9 +272,88 @@ int micv_rowshard_band(int rows, int cols, int levels, int world, int win, int r
 
 int micv_allreduce_sum_i32_dev(micv_ctx *ctx, micv_comm *comm, int32_t *buf, size_t count, micv_stream stream) {
     MICV_REQUIRE(ctx && comm && buf, "micv_allreduce_sum_i32: null argument");
+    MICV_REQUIRE(comm->device == ctx->device, "micv_allreduce_sum_i32: communicator and context are on different devices");
     MICV_HIP(hipSetDevice(ctx->device));
     if (count == 0) return MICV_OK;
     MICV_NCCL(rccl()->AllReduce(buf, buf, count, ncclInt32, ncclSum, comm->comm, static_cast<hipStream_t>(stream)));
+    return MICV_OK;
+}
+
+}  // extern "C"
+
+namespace micv {
+// micv_comm_selftest: fill / verify kernels (the check runs on the device; one counter comes back)
+__global__ void comm_stamp_kernel(int32_t *buf, int n, int rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[i] = rank * 1000003 + i;
+}
+__global__ void comm_reduce_fill_kernel(int32_t *buf, int n, int rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[i] = (rank + 1) * (i % 1021 + 1);
+}
+// bad[0]: ring cells that are not `from`'s stamp; bad[1]: all-reduce cells that are not the sum over the ranks
+__global__ void comm_verify_kernel(const int32_t *ring, int n_ring, int from, const int32_t *red, int n_red, int world, unsigned *bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ring && ring[i] != from * 1000003 + i) atomicAdd(&bad[0], 1u);
+    if (i < n_red && red[i] != (world * (world + 1) / 2) * (i % 1021 + 1)) atomicAdd(&bad[1], 1u);
+}
+}  // namespace micv
+
+extern "C" {
+
+int micv_comm_selftest(micv_ctx *ctx, micv_comm *comm, micv_stream stream) {
+    MICV_REQUIRE(ctx && comm, "micv_comm_selftest: null argument");
+    MICV_REQUIRE(comm->device == ctx->device, "micv_comm_selftest: communicator and context are on different devices");
+    const Rccl *r = rccl();
+    if (!r) {
+        set_error("micv_comm_selftest: librccl.so.1 not found");
+        return MICV_EUNSUPPORTED;
+    }
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int N = 1 << 16, NR = 1 << 12;  // 256 KB ring slab (a halo slab of a 1080p batch), 16 KB all-reduce
+    void *base = nullptr;
+    MICV_TRY(comm->reserve((size_t)(2 * N + NR) * 4 + 256, &base));
+    int32_t *snd = static_cast<int32_t *>(base), *rcv = snd + N, *red = rcv + N;
+    unsigned *bad = reinterpret_cast<unsigned *>(red + NR);
+    const int me = comm->rank, W = comm->world, to = (me + 1) % W, from = (me + W - 1) % W;
+    MICV_HIP(hipMemsetAsync(rcv, 0xFF, (size_t)N * 4, s));
+    MICV_HIP(hipMemsetAsync(bad, 0, 8, s));
+    comm_stamp_kernel<<<N / 256, 256, 0, s>>>(snd, N, me);
+    comm_reduce_fill_kernel<<<NR / 256, 256, 0, s>>>(red, NR, me);
+    MICV_LAUNCH_CHECK();
+    if (W > 1) {
+        // the exchange pattern of the row-shard driver: one group, a send and a receive per neighbour, on the launch stream
+        MICV_NCCL(r->GroupStart());
+        const ncclResult_t n1 = r->Send(snd, N, ncclInt32, to, comm->comm, s);
+        const ncclResult_t n2 = n1 == ncclSuccess ? r->Recv(rcv, N, ncclInt32, from, comm->comm, s) : n1;
+        const ncclResult_t n3 = r->GroupEnd();
+        if (n2 != ncclSuccess || n3 != ncclSuccess) {
+            set_error("micv_comm_selftest: rank %d: ring ncclSend -> %d / ncclRecv <- %d failed: %s", me, to, from,
+                      r->GetErrorString(n2 != ncclSuccess ? n2 : n3));
+            return MICV_EHIP;
+        }
+    } else {
+        MICV_HIP(hipMemcpyAsync(rcv, snd, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    }
+    {
+        const ncclResult_t nr = r->AllReduce(red, red, NR, ncclInt32, ncclSum, comm->comm, s);
+        if (nr != ncclSuccess) {
+            set_error("micv_comm_selftest: rank %d: ncclAllReduce failed: %s", me, r->GetErrorString(nr));
+            return MICV_EHIP;
+        }
+    }
+    comm_verify_kernel<<<N / 256, 256, 0, s>>>(rcv, N, from, red, NR, W, bad);
+    MICV_LAUNCH_CHECK();
+    unsigned host_bad[2] = {~0u, ~0u};
+    MICV_HIP(hipMemcpyAsync(host_bad, bad, 8, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    if (host_bad[0] || host_bad[1]) {
+        set_error("micv_comm_selftest: rank %d of %d: %u of %d ring cells from rank %d and %u of %d all-reduce cells are wrong -- "
+                  "the fabric or the stream ordering of RCCL calls is broken; results of sharded calls cannot be trusted",
+                  me, W, host_bad[0], N, from, host_bad[1], NR);
+        return MICV_EHIP;
+    }
     return MICV_OK;
 }
 
@@ -263,6 +361,7 @@ int micv_hough_lines_rowshard_dev(micv_ctx *ctx, micv_comm *comm, const uint8_t 
                                   size_t mstride, int row0, int rows, unsigned rho_bin, unsigned theta_bin,
                                   int32_t *acc, micv_stream stream) {
     MICV_REQUIRE(ctx && comm && acc, "micv_hough_lines_rowshard: null argument");
+    MICV_REQUIRE(comm->device == ctx->device, "micv_hough_lines_rowshard: communicator and context are on different devices");
     int rb = 0, tb = 0;
     MICV_TRY(micv_hough_lines_dims(rows, cols, rho_bin, theta_bin, &rb, &tb));
     // this rank's edge points vote into its private full-size accumulator; integer sums over the ranks are the
@@ -533,13 +632,23 @@ int micv_lk_flow_pyr_rowshard_host(micv_ctx *ctx, micv_comm *comm, const float *
                  "micv_lk_flow_pyr_rowshard_host: bad size / stride");
     MICV_HIP(hipSetDevice(ctx->device));
     const size_t rb = (size_t)cols * 4, n = rb * rows;
-    // frames and full-size outputs on the device (the communicator's block is in use by the driver: own allocations)
-    float *dp = nullptr, *dn = nullptr, *du = nullptr, *dv = nullptr;
+    // frames and full-size outputs on the device: the context's cached blocks, as every other `_host` entry point
+    // (host_api.hip) -- a repeated call of the same shape does no hipMalloc / hipFree (this one did four per
+    // call).  The communicator's own block is in use by the driver.
+    MICV_REQUIRE(comm->device == ctx->device, "micv_lk_flow_pyr_rowshard_host: communicator and context are on different devices");
+    float *dp = static_cast<float *>(ctx->io_acquire(n)), *dn = static_cast<float *>(ctx->io_acquire(n));
+    float *du = static_cast<float *>(ctx->io_acquire(n)), *dv = static_cast<float *>(ctx->io_acquire(n));
     hipStream_t s = nullptr;  // the null stream: every call of this entry point is synchronous, like the reference's
     auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);  // nothing may still use a block that goes back to the cache
         for (float *p : {dp, dn, du, dv})
-            if (p) (void)hipFree(p);
+            if (p) ctx->io_release(p);
     };
+    if (!dp || !dn || !du || !dv) {
+        cleanup();
+        set_error("micv_lk_flow_pyr_rowshard_host: device allocation failed");
+        return MICV_ENOMEM;
+    }
 #define MICV_RS(expr)                 \
     do {                              \
         const int rc_ = (expr);       \
@@ -557,10 +666,6 @@ int micv_lk_flow_pyr_rowshard_host(micv_ctx *ctx, micv_comm *comm, const float *
             return MICV_EHIP;                                                      \
         }                                                                          \
     } while (0)
-    MICV_RS_HIP(hipMalloc(&dp, n));
-    MICV_RS_HIP(hipMalloc(&dn, n));
-    MICV_RS_HIP(hipMalloc(&du, n));
-    MICV_RS_HIP(hipMalloc(&dv, n));
     MICV_RS_HIP(hipMemcpy2DAsync(dp, rb, prev, stride, rb, rows, hipMemcpyHostToDevice, s));
     MICV_RS_HIP(hipMemcpy2DAsync(dn, rb, next, stride, rb, rows, hipMemcpyHostToDevice, s));
     MICV_RS(micv_lk_flow_pyr_rowshard_dev(ctx, comm, dp, dn, 1, 0, rows, cols, rb, win, levels, du, dv, 0, rb, s));

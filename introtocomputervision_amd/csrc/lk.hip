@@ -1201,6 +1201,40 @@ int micv_flow_bound_check_dev(micv_ctx *ctx, const float *v, int batch, size_t p
     return MICV_OK;
 }
 
+int micv_lk_level_kernel_name(micv_ctx *ctx, int win, int rows, int cols, int batch, char *buf, size_t cap) {
+    MICV_REQUIRE(ctx && buf && cap >= 96, "micv_lk_level_kernel_name: null argument or a buffer under 96 bytes");
+    MICV_REQUIRE(rows >= 2 && cols >= 2 && (rows & 1) == 0 && (cols & 1) == 0 && batch >= 1 && lk_fused_supports(win),
+                 "micv_lk_level_kernel_name: even sizes, a batch and a window with a tiled kernel are expected");
+    // the level launch of lk_chain_fused for a level with a doubling coarse flow, aligned dense frames -- with the
+    // pointers never dereferenced: name_out makes launch_lk_level_fused stop where it would launch
+    LkLevelArgs a;
+    float *fake = reinterpret_cast<float *>(uintptr_t(4096));
+    a.rows = rows; a.cols = cols; a.batch = batch; a.win = win;
+    a.prev = a.next = fake; a.img_stride = cols; a.img_pair = (size_t)rows * cols;
+    a.mode = LK_FLOW_COARSE;
+    a.flow_u = a.flow_v = fake; a.flow_rows = rows / 2; a.flow_cols = cols / 2; a.flow_pair = (size_t)(rows / 2) * (cols / 2);
+    a.out_u = a.out_v = fake; a.out_stride = cols; a.out_pair = (size_t)rows * cols;
+    a.add_base = 1; a.row_begin = 0; a.row_end = rows;
+    a.narrow = ctx->opt[MICV_OPT_LK_NARROW_TILES];
+    a.ctx = ctx;
+    a.max_chain = ctx->opt[MICV_OPT_LK_CHAIN];
+    a.short_tiles = ctx->opt[MICV_OPT_LK_SHORT_TILES];
+    a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
+    a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
+    a.split = ctx->opt[MICV_OPT_LK_SPLIT];
+    if (a.split > 0 && lk_split_supports(win)) {
+        const LkGradGeom gg = lk_grad_geom(rows, cols, win);
+        a.grad = fake; a.grad_pair = gg.pair_elems; a.grad_pitch = gg.pitch; a.grad_rows = gg.rows; a.grad_pad = gg.pad;
+    }
+    // (MICV_OPT_LK_DIRECT_LEVELS / MICV_OPT_LK_BUILD_OVERLAP change the staging of the COARSER levels only: level 0
+    // always reads the frames themselves)
+    buf[0] = 0;
+    a.name_out = buf;
+    a.name_cap = cap;
+    MICV_HIP(hipSetDevice(ctx->device));
+    return launch_lk_level_fused(nullptr, a);
+}
+
 int micv_lk_schedule_host(int rows, int cols, int batch, int win, int max_chain, int32_t *entries_xycp,
                           int64_t capacity, int64_t *count, int *tile_w, int *tile_h) {
     MICV_REQUIRE(count && tile_w && tile_h, "micv_lk_schedule_host: null argument");

@@ -28,6 +28,7 @@
 // generic kernels in lk.hip and to the CPU oracle: every body produces the same bits.
 #include "lk_fused.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <utility>
@@ -1463,7 +1464,7 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         for (int i = 0; i < 2 * R + 1; i++) taps.k[i] = t.k[i];
     });
     // Dynamic LDS above 64 KB needs the attribute; set it on every device we launch on.
-    {
+    if (!a.name_out) {
         static thread_local int done_dev = -1;
         int dev = 0;
         MICV_HIP(hipGetDevice(&dev));
@@ -1499,6 +1500,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
         if (a.mode == LK_FLOW_COARSE && a.ctx && a.stream_tiles > 0 &&
             a.max_chain <= 1 && a.max_chain >= 0 && dma_ok && a.row_begin == 0 && a.row_end == a.rows &&
             a.rows == 2 * a.flow_rows && a.cols == 2 * a.flow_cols && a.stamps == nullptr && a.stop_after < 0) {
+            if (a.name_out) {
+                snprintf(a.name_out, a.name_cap, "lk_level_stream_kernel<%d, %d, %d>", R, NTV, THV);
+                return MICV_OK;
+            }
             const int4 *sched = nullptr;
             int nblocks = 0;
             MICV_TRY(get_schedule<C>(a, 1, &sched, &nblocks));
@@ -1562,6 +1567,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
             if (max_chain > 32) max_chain = 32;
             const bool sched_only = a.max_chain < 0;
             if (sched_only) max_chain = 1;  // the schedule kernel with single tiles only
+            if ((max_chain > 1 || sched_only) && a.name_out) {
+                snprintf(a.name_out, a.name_cap, "lk_level_chain_kernel<%d, %d, %s>", R, NTV, GATHER ? "true" : "false");
+                return MICV_OK;
+            }
             if (max_chain > 1 || sched_only) {
                 const int4 *sched = nullptr;
                 int nblocks = 0;
@@ -1587,6 +1596,10 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     // Band launches (row-sharded execution) tile from row_begin, not from the multiple of TH below it: a
     // 135-row band is 5 tile rows instead of 6.  pyrUp pairs fine rows (2m, 2m+1) per coarse row, so the
     // modes with a base flow need an even origin (the row-shard plan's cuts are even on those levels).
+    if (a.name_out) {
+        snprintf(a.name_out, a.name_cap, "lk_level_kernel<%d, %d, %d, %d, %s, %d>", R, a.mode, NTV, THV, GATHER ? "true" : "false", TWV);
+        return MICV_OK;
+    }
     LkLevelArgs b = a;
     b.y_shift = (a.row_begin > 0 && (a.mode == LK_FLOW_NONE || (a.row_begin & 1) == 0)) ? a.row_begin % C::TH : 0;
     const int tile_rows = b.y_shift ? cdiv(a.row_end - a.row_begin, C::TH) : cdiv(a.row_end, C::TH) - a.row_begin / C::TH;
@@ -1687,7 +1700,14 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
         ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0 &&
         lk_split_wanted(a.rows, a.cols, a.batch, a.win, a.mode, a.split)) {
         const LkGradGeom gg = lk_grad_geom(a.rows, a.cols, a.win);
-        if (gg.pad == a.grad_pad && gg.pitch == a.grad_pitch && gg.rows <= a.grad_rows && a.win == 15) return launch_split<7>(s, a);
+        if (gg.pad == a.grad_pad && gg.pitch == a.grad_pitch && gg.rows <= a.grad_rows && a.win == 15) {
+            if (a.name_out) {
+                snprintf(a.name_out, a.name_cap, a.split == 3 ? "lk_grad_kernel<3, 512, 32> + lk_level_kernel<7, 0, 512, 32, false, 64>"
+                                                              : "lk_grad_kernel<3, 512, 32> + lk_sums_stream_kernel<7>");
+                return MICV_OK;
+            }
+            return launch_split<7>(s, a);
+        }
     }
     switch (a.win) {
         case 15: {

@@ -72,6 +72,11 @@ struct LkLevelArgs {
     int grad_pitch = 0, grad_rows = 0, grad_pad = 0;
     int split = 0;  // MICV_OPT_LK_SPLIT
     int pre_base = 0;  // pre-pass tiles store the base flow into out_u / out_v (LkSumsArgs::base == 1)
+    // Diagnostic (micv_lk_level_kernel_name): when set, launch_lk_level_fused launches NOTHING and writes the name of the
+    // kernel instantiation it would have launched -- the dispatch has one definition, so tools that filter profiler rows
+    // by kernel name cannot drift from it
+    char *name_out = nullptr;
+    size_t name_cap = 0;
     int pre_warp = 0;  // variant A': pre-pass tiles store the warped image (dense plane at grad) and the base flow only
     int base_rmw = 0;  // no-flow mode: out_u / out_v hold a base flow to add (second half of an A' split launch)
 };

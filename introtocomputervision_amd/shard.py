@@ -543,6 +543,15 @@ class MicvComm:
         except Exception:
             pass
 
+    def selftest(self, stream=None):
+        """micv_comm_selftest: ring send / receive of a rank-stamped slab + an int32 all-reduce, verified on the device.
+        Collective; raises MicvError naming rank, peer and step when the fabric or the call ordering is broken."""
+        import torch
+
+        from ._capi import check, lib
+        s = stream if stream is not None else torch.cuda.current_stream(self.ctx.device).cuda_stream
+        check(lib.micv_comm_selftest(self.ctx.handle, self.handle, s))
+
     def allreduce_sum_i32(self, t, stream=None):
         """In-place int32 sum over the ranks (the Hough accumulator merge) on `stream` / the current stream."""
         import torch

@@ -106,6 +106,7 @@ inline void init_comm(const void *unique_id, int rank, int world) {
     micv_comm *c = nullptr;
     check(micv_comm_create(context(), nullptr, unique_id, rank, world, &c));
     comm_slot() = c;
+    check(micv_comm_selftest(context(), c, nullptr));  // a broken fabric is reported here, not as a wrong flow later
 }
 inline void close_comm() {
     if (comm_slot()) micv_comm_destroy(comm_slot());
@@ -162,9 +163,11 @@ inline void warp(const Mat &src, const Mat &du, const Mat &dv, Mat &dst) {
     dst = out;
 }
 
-// `levels` exposes the depth the reference hard-codes (pyrDepth = 4, OpticalFlow.cpp:127).
-inline void calcOpticalFlowPyr(const Mat &prevImg, const Mat &nextImg, Mat &u, Mat &v,
-                               const size_t winSize = 21, const size_t levels = 4) {
+// An extension, not a reference function: the pyramid depth the reference hard-codes (pyrDepth = 4,
+// OpticalFlow.cpp:127) as a parameter.  lk::calcOpticalFlowPyr below has the reference's exact type
+// (tests/cpp/shim_signatures.cpp) and calls this with 4.
+inline void calcOpticalFlowPyrLevels(const Mat &prevImg, const Mat &nextImg, Mat &u, Mat &v,
+                                     const size_t winSize, const size_t levels) {
     micv_shim::require(prevImg.rows == nextImg.rows && prevImg.cols == nextImg.cols,
                        "lk::calcOpticalFlowPyr: size mismatch");
     Mat uu(prevImg.rows, prevImg.cols, micv_shim::F32), vv(prevImg.rows, prevImg.cols, micv_shim::F32);
@@ -194,6 +197,10 @@ inline void calcOpticalFlowPyr(const Mat &prevImg, const Mat &nextImg, Mat &u, M
                                                vv.ptr<float>(), uu.step));
     u = uu;  // :165-166
     v = vv;
+}
+// ps5_cpp/include/OpticalFlow.h:14-18
+inline void calcOpticalFlowPyr(const Mat &prevImg, const Mat &nextImg, Mat &u, Mat &v, const size_t winSize = 21) {
+    calcOpticalFlowPyrLevels(prevImg, nextImg, u, v, winSize, 4);
 }
 }  // namespace lk
 

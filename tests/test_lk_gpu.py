@@ -833,3 +833,31 @@ def test_split_level_launch_is_bit_exact(mods, rows, cols, levels, batch, mode):
         assert np.array_equal(host(u[batch - 1]), eu, equal_nan=True) and np.array_equal(host(v[batch - 1]), ev, equal_nan=True)
     with pytest.raises(Exception):
         ctx.set_option(_capi.OPT_LK_SPLIT, 4)
+
+
+def test_level_kernel_name_comes_from_the_dispatch(mods):
+    """micv_lk_level_kernel_name: the launch dispatch answers (name_out: same code path, nothing launched), so the names
+    bench.py / the PMC tools filter profiler rows by follow every option -- the Python mirror it replaces had drifted
+    (TALL_TILES = 3, the gather forms)."""
+    from introtocomputervision_amd import _capi
+    ctx = _capi.Context(0)
+    assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_level_kernel<7, 1, 512, 32, false, 64>"
+    assert ctx.lk_level_kernel_name(15, 270, 480, 1) == "lk_level_kernel<7, 1, 512, 16, false, 64>"
+    assert ctx.lk_level_kernel_name(21, 1080, 1920, 8) == "lk_level_kernel<10, 1, 1024, 64, false, 64>"
+    assert ctx.lk_level_kernel_name(7, 1080, 1920, 8) == "lk_level_kernel<3, 1, 512, 32, false, 64>"
+    ctx.set_option(_capi.OPT_LK_TALL_TILES, 3)
+    assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_level_kernel<7, 1, 1024, 32, false, 64>"
+    ctx.set_option(_capi.OPT_LK_TALL_TILES, 2)
+    assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_level_kernel<7, 1, 512, 64, false, 32>"
+    ctx.set_option(_capi.OPT_LK_TALL_TILES, 0)
+    ctx.set_option(_capi.OPT_LK_CHAIN, 2)
+    assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_level_chain_kernel<7, 512, false>"
+    ctx.set_option(_capi.OPT_LK_CHAIN, 0)
+    ctx.set_option(_capi.OPT_LK_STREAM, 1)
+    assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_level_stream_kernel<7, 512, 32>"
+    ctx.set_option(_capi.OPT_LK_STREAM, 0)
+    ctx.set_option(_capi.OPT_LK_SPLIT, 1)
+    assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_grad_kernel<3, 512, 32> + lk_sums_stream_kernel<7>"
+    ctx.set_option(_capi.OPT_LK_SPLIT, 0)
+    ctx.set_option(_capi.OPT_LK_NARROW_TILES, 1)
+    assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_level_kernel<7, 1, 256, 32, false, 64>"
