@@ -253,9 +253,20 @@ def secondary_block(ctx, stream, torch, np):
         Rr = harris.getCornerResponse(gx, gy, hp["window_size"], hp["gaussian_sigma"], hp["alpha"], ctx=ctx, cpu_arithmetic=cpu_arith)
         _, locs = harris.refineCorners(Rr, hp["response_threshold"], hp["min_distance"], ctx=ctx)
         return Rr, locs
-    ms = wall(c1)
+    ms3 = wall(c1)
     Rg, lg = c1()
     Rc, lc = c1(True)
+
+    # the same chain as ONE call (micv_harris_corners_dev, r05): Sobel inside the response kernel's tile, R in context
+    # scratch, only the list leaves the device -- image in (4 B), R out and back in (4 + 4 B)
+    def c1_chain(cpu_arith=False, **kw):
+        return harris.cornersFromImage(dimg, hp["sobel_kernel_size"], hp["window_size"], hp["gaussian_sigma"], hp["alpha"],
+                                       hp["response_threshold"], hp["min_distance"], ctx=ctx, cpu_arithmetic=cpu_arith,
+                                       want_gradients=False, **kw)
+    ms = wall(c1_chain)
+    f_g, f_c = c1_chain(want_response=True), c1_chain(True, want_response=True)
+    chain_same = bool(torch.equal(f_g["response"], Rg) and torch.equal(f_g["locs"], lg) and
+                      f_c["response"].cpu().numpy().tobytes() == Rc.cpu().numpy().tobytes() and torch.equal(f_c["locs"], lc))
     ogx, ogy = orc.sobel(img, hp["sobel_kernel_size"], 1.0)
     eR = orc.harris_response(ogx, ogy, hp["window_size"], hp["gaussian_sigma"], hp["alpha"])
     _, el = orc.harris_refine(eR, hp["response_threshold"], hp["min_distance"])
@@ -263,14 +274,18 @@ def secondary_block(ctx, stream, torch, np):
     _, elc = orc.harris_refine(eRc, hp["response_threshold"], hp["min_distance"])
     out["C1_harris"] = {
         "workload": "640x480 greyscale checkerboard, config/ps4.yaml harris_trans (sobel 3, window 5, sigma 1.5, alpha 0.04, "
-                    "threshold 5e8, minDistance 5): getGradients -> getCornerResponse -> refineCorners, corner count read back",
+                    "threshold 5e8, minDistance 5): getGradients -> getCornerResponse -> refineCorners as one call "
+                    "(micv_harris_corners_dev: image -> R -> ordered list), corner count read back",
         "ms": ms, "Mpix_per_s": 480 * 640 / ms / 1e3, "corners": int(len(lg)),
-        "algorithmic_bytes_per_px": 32, "frac_of_hbm_peak": 480 * 640 * 32 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "bound": "latency (three launches + one read-back on 0.3 Mpx)",
+        "three_separate_calls_ms": ms3,
+        "algorithmic_bytes_per_px": 12, "frac_of_hbm_peak": 480 * 640 * 12 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "bound": "latency (two launches + one read-back on 0.3 Mpx)",
         "reference_gtx1080_ms": {"cornerResponseKernel": 0.80, "refineCornersKernel": 0.59},
         "check": {"vs": "oracle at full size, gpu:: and cpu:: arithmetic",
                   "bit_exact": bool(np.array_equal(Rg.cpu().numpy(), eR) and np.array_equal(lg.cpu().numpy(), el)
-                                    and Rc.cpu().numpy().tobytes() == eRc.tobytes() and np.array_equal(lc.cpu().numpy(), elc))},
+                                    and Rc.cpu().numpy().tobytes() == eRc.tobytes() and np.array_equal(lc.cpu().numpy(), elc)
+                                    and chain_same),
+                  "one_call_equals_three_calls": chain_same},
     }
     # ---- C5: 4K Harris + descriptors + LK refine ------------------------------------------------------------
     def c5_frames(rows, cols):
@@ -280,9 +295,8 @@ def secondary_block(ctx, stream, torch, np):
         return p, np.ascontiguousarray(np.roll(p, shift=(-2, 3), axis=(0, 1)))
 
     def c5(P, N):
-        gx, gy = harris.getGradients(P, 3, ctx=ctx)
-        Rr = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04, ctx=ctx)
-        _, locs = harris.refineCorners(Rr, 5e8, 5, capacity=1 << 20, ctx=ctx)
+        h = harris.cornersFromImage(P, 3, 5, 1.5, 0.04, 5e8, 5, capacity=1 << 20, ctx=ctx)  # gradients kept: the keypoints read them
+        gx, gy, locs = h["gx"], h["gy"], h["locs"]
         kp = harris.getKeypoints(gx, gy, locs, 10, ctx=ctx)
         desc = harris.computeDescriptors(gx, gy, kp, ctx=ctx)
         u_, v_ = lk.calcOpticalFlowPyr(P, N, WIN, LEVELS, ctx=ctx)
@@ -308,9 +322,9 @@ def secondary_block(ctx, stream, torch, np):
     gdesc = harris.computeDescriptors(dev(ogx), dev(ogy), dev(ekp), ctx=ctx).cpu().numpy() if len(ekp) else edesc
     ok = ok and bool(np.array_equal(gdesc, edesc))
     px = 2160 * 3840
-    bpp = algorithmic_bytes_pair(2160, 3840, LEVELS) / px + 12 + 12 + 9   # LK + Sobel pair + response + NMS
+    bpp = algorithmic_bytes_pair(2160, 3840, LEVELS) / px + 4 + 8 + 4 + 4   # LK + image in, gradients out, R out, R back in (NMS)
     out["C5_4k_chain"] = {
-        "workload": "3840x2160 textured checkerboard pair: Harris (sobel 3, window 5) -> ordered corner list -> keypoints -> "
+        "workload": "3840x2160 textured checkerboard pair: Harris (sobel 3, window 5; one call, image -> gradients + R -> ordered corner list) -> keypoints -> "
                     "4x4x8 descriptors -> 5-level LK (win 15) sampled at the corners; one corner-count read-back",
         "ms": ms, "Mpix_per_s": px / ms / 1e3, "corners": n_corners,
         "algorithmic_bytes_per_px": bpp, "frac_of_hbm_peak": px * bpp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

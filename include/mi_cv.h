@@ -355,6 +355,24 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
 int micv_harris_refine_host(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,
                             double threshold, int min_distance, float *corners, size_t cstride,
                             int32_t *locs_yx, int64_t cap, int64_t *count);
+
+/* The ps4 caller's chain as ONE device call (harrisHelper, ps4_cpp/src/Solution.cpp:77-124: harris::getGradients ->
+ * getCornerResponse -> refineCorners): image -> [gradients] -> R -> ordered corner list.  With a 3x3 Sobel and a window
+ * of 3 / 5 / 7 the gradients are formed inside the response kernel's LDS tile (image in, R out: 8 B per pixel instead of
+ * 12 + 12, two launches instead of three); other sizes run the three launches of the separate entry points.  Same bits
+ * as micv_sobel_dev(scale 1) + micv_harris_response_ex_dev + micv_harris_refine_dev either way.
+ * Optional outputs (NULL = not wanted): gx / gy (both or neither; sift::getKeypoints reads them), resp (R; context
+ * scratch otherwise), corners (the sparse map harris::refineCorners also returns).  locs_yx / cap / count as
+ * micv_harris_refine_dev; flags as micv_harris_response_ex_dev. */
+int micv_harris_corners_dev(micv_ctx *ctx, const float *img, int rows, int cols, size_t stride, int sobel_ksize, int win,
+                            double sigma, float alpha, int flags, double threshold, int min_distance, float *gx, float *gy,
+                            size_t gstride, float *resp, size_t rstride, float *corners, size_t cstride, int32_t *locs_yx,
+                            int64_t cap, int64_t *count, micv_stream stream);
+int micv_harris_corners_host(micv_ctx *ctx, const float *img, int rows, int cols, size_t stride, int sobel_ksize, int win,
+                             double sigma, float alpha, int flags, double threshold, int min_distance, float *gx, float *gy,
+                             size_t gstride, float *resp, size_t rstride, float *corners, size_t cstride, int32_t *locs_yx,
+                             int64_t cap, int64_t *count);
+
 /* sift::getAnglesFromGradients, ps4_cpp/lib/Descriptors.cpp:7-25 (a11). */
 int micv_sift_angles_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
                          size_t gstride, float *angles, size_t astride, micv_stream stream);

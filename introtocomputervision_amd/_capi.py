@@ -119,6 +119,8 @@ SIGNATURES = {
     "micv_harris_response_ex_host": (i32, [vp, vp, vp, i32, i32, sz, i32, f64, f32, i32, vp, sz]),
     "micv_harris_refine_dev": (i32, [vp, vp, i32, i32, sz, f64, i32, vp, sz, vp, i64, vp, vp]),
     "micv_harris_refine_host": (i32, [vp, vp, i32, i32, sz, f64, i32, vp, sz, vp, i64, vp]),
+    "micv_harris_corners_dev": (i32, [vp, vp, i32, i32, sz, i32, i32, f64, f32, i32, f64, i32, vp, vp, sz, vp, sz, vp, sz, vp, i64, vp, vp]),
+    "micv_harris_corners_host": (i32, [vp, vp, i32, i32, sz, i32, i32, f64, f32, i32, f64, i32, vp, vp, sz, vp, sz, vp, sz, vp, i64, vp]),
     "micv_sift_angles_dev": (i32, [vp, vp, vp, i32, i32, sz, vp, sz, vp]),
     "micv_sift_angles_host": (i32, [vp, vp, vp, i32, i32, sz, vp, sz]),
     "micv_sift_keypoints_dev": (i32, [vp, vp, vp, i32, i32, sz, vp, i64, f32, vp, vp]),

@@ -90,56 +90,14 @@ struct HarrisW {
 typedef float hv4f __attribute__((ext_vector_type(4)));
 typedef float hv2f __attribute__((ext_vector_type(2)));
 
-template <int R, int TH, bool CPU = false>
-__global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
-    const float *__restrict__ gx, const float *__restrict__ gy, int gstride, int rows, int cols,
-    HarrisW<R> hw, float alpha, float *__restrict__ resp, int rstride, int vec_ok) {
-    // LDS column = global column - (x0 - 4): the 72 columns x0 - 4 .. x0 + 67 are 18 aligned float4 of the
-    // image, written whole (the window of output column c starts at LDS column c + 4 - R)
-    constexpr int W = 2 * R + 1, TW = 64, NT = 16 * TH, RH = TH + 2 * R, PS = 80, SH = 4 - R, V4 = (TW + 8) / 4;
-    constexpr int NV = (SH + 4 + 2 * R + 3) / 4;  // float4 per window row, from the thread's own column group
-    static_assert(R >= 1 && R <= 4 && 60 + 4 * NV <= PS, "window reads stay inside a plane row");
-    __shared__ __attribute__((aligned(16))) float XX[RH * PS], XY[RH * PS], YY[RH * PS];
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    constexpr int NB = (RH * V4 + NT - 1) / NT;
-    hv4f vx[NB], vy[NB];
-    if (vec_ok && x0 >= 4 && x0 + TW + 4 <= cols) {
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const int i = threadIdx.x + k * NT < RH * V4 ? threadIdx.x + k * NT : RH * V4 - 1;
-            const int ly = i / V4, m = i - ly * V4;
-            const int yy = clampi(y0 - R + ly, 0, rows - 1);
-            const size_t o = (size_t)yy * gstride + (x0 - 4 + 4 * m);
-            vx[k] = *reinterpret_cast<const hv4f *>(gx + o);
-            vy[k] = *reinterpret_cast<const hv4f *>(gy + o);
-        }
-    } else {
-        // tiles at the left / right edge (and unaligned images): clamped scalar loads, same slots
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const int i = threadIdx.x + k * NT < RH * V4 ? threadIdx.x + k * NT : RH * V4 - 1;
-            const int ly = i / V4, m = i - ly * V4;
-            const int yy = clampi(y0 - R + ly, 0, rows - 1);
-            const float *rx = gx + (size_t)yy * gstride, *ry_ = gy + (size_t)yy * gstride;
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int xx = clampi(x0 - 4 + 4 * m + e, 0, cols - 1);
-                vx[k][e] = rx[xx];
-                vy[k][e] = ry_[xx];
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        const int i = threadIdx.x + k * NT;
-        if (i < RH * V4) {
-            const int ly = i / V4, m = i - ly * V4;
-            *reinterpret_cast<hv4f *>(XX + ly * PS + 4 * m) = vx[k] * vx[k];
-            *reinterpret_cast<hv4f *>(XY + ly * PS + 4 * m) = vx[k] * vy[k];
-            *reinterpret_cast<hv4f *>(YY + ly * PS + 4 * m) = vy[k] * vy[k];
-        }
-    }
-    __syncthreads();
+// The window sums and R of a tile whose three product planes are in LDS (PS floats per row, LDS column = global
+// column - (x0 - 4)): shared by the kernel that stages gradients from HBM and the one that forms them from the image.
+template <int R, int TH, bool CPU>
+__device__ __forceinline__ void harris_tile_accumulate(const float *XX, const float *XY, const float *YY, const HarrisW<R> &hw,
+                                                       float alpha, float *__restrict__ resp, int rstride, int rows, int cols,
+                                                       int x0, int y0, int vec_ok) {
+    constexpr int W = 2 * R + 1, PS = 80, SH = 4 - R;
+    constexpr int NV = (SH + 4 + 2 * R + 3) / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ry = 4 * wave + (lane & 3), c0 = 4 * (lane >> 2);
     // [field][output pair]
@@ -202,6 +160,59 @@ __global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
     }
 }
 
+template <int R, int TH, bool CPU = false>
+__global__ __launch_bounds__(16 * TH) void harris_response_tiled_kernel(
+    const float *__restrict__ gx, const float *__restrict__ gy, int gstride, int rows, int cols,
+    HarrisW<R> hw, float alpha, float *__restrict__ resp, int rstride, int vec_ok) {
+    // LDS column = global column - (x0 - 4): the 72 columns x0 - 4 .. x0 + 67 are 18 aligned float4 of the
+    // image, written whole (the window of output column c starts at LDS column c + 4 - R)
+    constexpr int TW = 64, NT = 16 * TH, RH = TH + 2 * R, PS = 80, SH = 4 - R, V4 = (TW + 8) / 4;
+    constexpr int NV = (SH + 4 + 2 * R + 3) / 4;  // float4 per window row, from the thread's own column group
+    static_assert(R >= 1 && R <= 4 && 60 + 4 * NV <= PS, "window reads stay inside a plane row");
+    __shared__ __attribute__((aligned(16))) float XX[RH * PS], XY[RH * PS], YY[RH * PS];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    constexpr int NB = (RH * V4 + NT - 1) / NT;
+    hv4f vx[NB], vy[NB];
+    if (vec_ok && x0 >= 4 && x0 + TW + 4 <= cols) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * NT < RH * V4 ? threadIdx.x + k * NT : RH * V4 - 1;
+            const int ly = i / V4, m = i - ly * V4;
+            const int yy = clampi(y0 - R + ly, 0, rows - 1);
+            const size_t o = (size_t)yy * gstride + (x0 - 4 + 4 * m);
+            vx[k] = *reinterpret_cast<const hv4f *>(gx + o);
+            vy[k] = *reinterpret_cast<const hv4f *>(gy + o);
+        }
+    } else {
+        // tiles at the left / right edge (and unaligned images): clamped scalar loads, same slots
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int i = threadIdx.x + k * NT < RH * V4 ? threadIdx.x + k * NT : RH * V4 - 1;
+            const int ly = i / V4, m = i - ly * V4;
+            const int yy = clampi(y0 - R + ly, 0, rows - 1);
+            const float *rx = gx + (size_t)yy * gstride, *ry_ = gy + (size_t)yy * gstride;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int xx = clampi(x0 - 4 + 4 * m + e, 0, cols - 1);
+                vx[k][e] = rx[xx];
+                vy[k][e] = ry_[xx];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int i = threadIdx.x + k * NT;
+        if (i < RH * V4) {
+            const int ly = i / V4, m = i - ly * V4;
+            *reinterpret_cast<hv4f *>(XX + ly * PS + 4 * m) = vx[k] * vx[k];
+            *reinterpret_cast<hv4f *>(XY + ly * PS + 4 * m) = vx[k] * vy[k];
+            *reinterpret_cast<hv4f *>(YY + ly * PS + 4 * m) = vy[k] * vy[k];
+        }
+    }
+    __syncthreads();
+    harris_tile_accumulate<R, TH, CPU>(XX, XY, YY, hw, alpha, resp, rstride, rows, cols, x0, y0, vec_ok);
+}
+
 template <int R, bool CPU>
 static void launch_harris_tiled(hipStream_t s, const float *gx, const float *gy, int gstride, int rows,
                                 int cols, const Taps &g, float alpha, float *resp, int rstride) {
@@ -217,6 +228,151 @@ static void launch_harris_tiled(hipStream_t s, const float *gx, const float *gy,
     else
         harris_response_tiled_kernel<R, 16, CPU><<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, 0, s>>>(
             gx, gy, gstride, rows, cols, hw, alpha, resp, rstride, vec_ok);
+}
+
+// ---- image -> R in one launch (r05; the ps4 caller's chain, ps4_cpp/src/Solution.cpp:77-124) -------------------
+// harris::getGradients (3x3 Sobel, scale 1, BORDER_REFLECT_101; Harris.cpp:14-41) computed IN the response kernel's
+// tile: the image tile (+R for the window, +1 for the Sobel) goes to LDS with the reflection resolved while loading,
+// the Sobel pair runs as sobel_fused_kernel<3> runs it (row pass of both filters into LDS, column pass: the same fmaf
+// chains from +0 with the float row-pass value in between -- same bits as micv_sobel_dev), the products Ix^2, IxIy,
+// Iy^2 go straight into the three planes harris_tile_accumulate reads.  A plane cell outside the image is the
+// gradient at the CLAMPED coordinate (Harris.cpp:73-76), i.e. the Sobel of the edge pixel -- formed here from the
+// staged neighbourhood of that pixel, not by reflecting the gradient.  8 B per pixel of HBM traffic (image in, R out)
+// instead of 12 + 12; the gradients are written as well when the caller wants them (sift::getKeypoints does).
+struct Sobel3 {
+    float row_dx[3], col_dx[3], row_dy[3], col_dy[3];
+};
+
+template <int R, int TH, bool CPU>
+__global__ __launch_bounds__(16 * TH) void harris_image_response_kernel(const float *__restrict__ img, int istride, int rows, int cols,
+                                                                         Sobel3 t, HarrisW<R> hw, float alpha, float *__restrict__ resp,
+                                                                         int rstride, float *__restrict__ gxo, float *__restrict__ gyo,
+                                                                         int gstride, int vec_ok, int img_vec_ok) {
+    constexpr int TW = 64, NT = 16 * TH, RH = TH + 2 * R, PS = 80, PC = TW + 8;  // plane columns x0 - 4 .. x0 + 67
+    // LDS: the three product planes and nothing else -- the same 34.5 KB (window 5, 64x32 tile) as the kernel that reads
+    // gradients from HBM, i.e. the same four workgroups per CU (a staged image tile + row-pass planes took 56 KB = two
+    // workgroups per CU and the launch 43-49 us at 4K; the image is read through L1 / L2 instead)
+    __shared__ __attribute__((aligned(16))) float lds[3 * RH * PS];
+    float *XX = lds, *XY = lds + RH * PS, *YY = lds + 2 * RH * PS;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const hv2f rdx0 = {t.row_dx[0], t.row_dx[0]}, rdx1 = {t.row_dx[1], t.row_dx[1]}, rdx2 = {t.row_dx[2], t.row_dx[2]};
+    const hv2f rdy0 = {t.row_dy[0], t.row_dy[0]}, rdy1 = {t.row_dy[1], t.row_dy[1]}, rdy2 = {t.row_dy[2], t.row_dy[2]};
+    const hv2f cdx0 = {t.col_dx[0], t.col_dx[0]}, cdx1 = {t.col_dx[1], t.col_dx[1]}, cdx2 = {t.col_dx[2], t.col_dx[2]};
+    const hv2f cdy0 = {t.col_dy[0], t.col_dy[0]}, cdy1 = {t.col_dy[1], t.col_dy[1]}, cdy2 = {t.col_dy[2], t.col_dy[2]};
+    const hv2f zero = {0.f, 0.f};
+    // Marching jobs: two adjacent plane columns x SEG rows per thread, a three-row register window of row-pass values
+    // (packed f32: both columns per instruction), products straight into the planes.  The row pass of both filters and
+    // the column pass are sobel_fused_kernel<3>'s fmaf chains from +0 with the float row-pass value in between.
+    constexpr int SEG = 3, NSEG = (RH + SEG - 1) / SEG, NJ = (PC / 2) * NSEG;
+    const bool interior = img_vec_ok && x0 >= 8 && x0 + TW + 8 <= cols && y0 - R - 1 >= 0 && y0 + TH + R + 1 <= rows;
+    for (int n = threadIdx.x; n < NJ; n += NT) {
+        const int seg = n / (PC / 2), lx = 2 * (n - seg * (PC / 2));
+        const int q0 = seg * SEG;
+        // the job's image values: rows q0 - 1 .. q0 + SEG of the plane rows' centres, columns lx - 1 .. lx + 2 of the
+        // pair's -- every load issued before the first use
+        hv2f va[SEG + 2], vb[SEG + 2], vc[SEG + 2];
+        if (interior) {
+            const float *sp = img + (size_t)(y0 - R + q0 - 1) * istride + (x0 - 4 + lx - 1);  // (odd column: 4-byte aligned pairs)
+#pragma unroll
+            for (int k = 0; k < SEG + 2; k++) {
+                const float *rp = sp + (size_t)k * istride;
+                const float v0 = rp[0];
+                const hv2f v12 = *reinterpret_cast<const hv2f *>(rp + 1);
+                const float v3 = rp[3];
+                va[k] = (hv2f){v0, v12.x};
+                vb[k] = v12;
+                vc[k] = (hv2f){v12.y, v3};
+            }
+        } else {
+            // border tiles: a plane cell outside the image is the gradient at the CLAMPED coordinate, whose own 3x3
+            // neighbourhood is read with BORDER_REFLECT_101 -- per column of the pair, since the two may clamp to the
+            // same pixel.  Rows: plane row q's centre is clamp(y0 - R + q); window slot k serves rows q0 - 1 + k only
+            // when no clamp intervenes, so every plane row takes its own three image rows below instead.
+#pragma unroll
+            for (int k = 0; k < SEG + 2; k++) va[k] = vb[k] = vc[k] = zero;
+        }
+        hv2f ax[3], ay[3];
+        auto rowpass_v = [&](hv2f a_, hv2f b_, hv2f c_, int slot) {
+            ax[slot] = __builtin_elementwise_fma(c_, rdx2, __builtin_elementwise_fma(b_, rdx1, __builtin_elementwise_fma(a_, rdx0, zero)));
+            ay[slot] = __builtin_elementwise_fma(c_, rdy2, __builtin_elementwise_fma(b_, rdy1, __builtin_elementwise_fma(a_, rdy0, zero)));
+        };
+        auto finish = [&](int q, int s_top, int s_mid, int s_new) {
+            const hv2f gxv = __builtin_elementwise_fma(ax[s_new], cdx2, __builtin_elementwise_fma(ax[s_mid], cdx1, __builtin_elementwise_fma(ax[s_top], cdx0, zero)));
+            const hv2f gyv = __builtin_elementwise_fma(ay[s_new], cdy2, __builtin_elementwise_fma(ay[s_mid], cdy1, __builtin_elementwise_fma(ay[s_top], cdy0, zero)));
+            *reinterpret_cast<hv2f *>(XX + q * PS + lx) = gxv * gxv;
+            *reinterpret_cast<hv2f *>(XY + q * PS + lx) = gxv * gyv;
+            *reinterpret_cast<hv2f *>(YY + q * PS + lx) = gyv * gyv;
+            const int gy_ = y0 - R + q, gx_ = x0 - 4 + lx;
+            if (gxo && q >= R && q < R + TH && lx >= 4 && lx < TW + 4 && gy_ < rows) {
+                const size_t o = (size_t)gy_ * gstride + gx_;
+                if (interior) {
+                    *reinterpret_cast<hv2f *>(gxo + o) = gxv;
+                    *reinterpret_cast<hv2f *>(gyo + o) = gyv;
+                } else {
+                    if (gx_ < cols) { gxo[o] = gxv.x; gyo[o] = gyv.x; }
+                    if (gx_ + 1 < cols) { gxo[o + 1] = gxv.y; gyo[o + 1] = gyv.y; }
+                }
+            }
+        };
+        if (interior) {
+            rowpass_v(va[0], vb[0], vc[0], 0);
+            rowpass_v(va[1], vb[1], vc[1], 1);
+#pragma unroll
+            for (int j = 0; j < SEG; j++) {
+                if (q0 + j < RH) {
+                    rowpass_v(va[j + 2], vb[j + 2], vc[j + 2], (j + 2) % 3);
+                    finish(q0 + j, j % 3, (j + 1) % 3, (j + 2) % 3);
+                }
+            }
+        } else {
+            const int cxa = clampi(x0 - 4 + lx, 0, cols - 1), cxb = clampi(x0 - 4 + lx + 1, 0, cols - 1);
+            const int xa[3] = {reflect101(cxa - 1, cols), cxa, reflect101(cxa + 1, cols)};
+            const int xb[3] = {reflect101(cxb - 1, cols), cxb, reflect101(cxb + 1, cols)};
+            for (int j = 0; j < SEG; j++) {
+                const int q = q0 + j;
+                if (q >= RH) break;
+                const int cy = clampi(y0 - R + q, 0, rows - 1);
+                const int ys[3] = {reflect101(cy - 1, rows), cy, reflect101(cy + 1, rows)};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float *rp = img + (size_t)ys[k] * istride;
+                    rowpass_v((hv2f){rp[xa[0]], rp[xb[0]]}, (hv2f){rp[xa[1]], rp[xb[1]]}, (hv2f){rp[xa[2]], rp[xb[2]]}, k);
+                }
+                finish(q, 0, 1, 2);
+            }
+        }
+    }
+    __syncthreads();
+    harris_tile_accumulate<R, TH, CPU>(XX, XY, YY, hw, alpha, resp, rstride, rows, cols, x0, y0, vec_ok);
+}
+
+template <int R, bool CPU>
+static void launch_harris_image(hipStream_t s, const float *img, int istride, int rows, int cols, const Taps &g, float alpha,
+                                float *resp, int rstride, float *gx, float *gy, int gstride) {
+    HarrisW<R> hw;
+    for (int wy = 0; wy <= 2 * R; wy++)
+        for (int wx = 0; wx <= 2 * R; wx++) hw.w[wy * (2 * R + 1) + wx] = g.k[wy] * g.k[wx];
+    Taps d, m;
+    sobel_taps(3, 1, &d);
+    sobel_taps(3, 0, &m);
+    Sobel3 t;
+    for (int i = 0; i < 3; i++) {  // filters.hip, launch_sobel_fused with scale 1 (harris::getGradients)
+        t.row_dx[i] = d.k[i];
+        t.col_dx[i] = m.k[i];
+        t.row_dy[i] = m.k[i];
+        t.col_dy[i] = d.k[i];
+    }
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(resp) | reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0 &&
+                       (rstride & 3) == 0 && (gstride & 3) == 0;
+    // the marching body stores gradient pairs (8 B) and loads the image by float4
+    const int img_vec_ok = (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (istride & 3) == 0 &&
+                           ((reinterpret_cast<uintptr_t>(gx) | reinterpret_cast<uintptr_t>(gy)) & 7) == 0 && (gstride & 1) == 0;
+    if ((size_t)cdiv(cols, 64) * cdiv(rows, 32) >= 1024)
+        harris_image_response_kernel<R, 32, CPU><<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 512, 0, s>>>(
+            img, istride, rows, cols, t, hw, alpha, resp, rstride, gx, gy, gstride, vec_ok, img_vec_ok);
+    else
+        harris_image_response_kernel<R, 16, CPU><<<dim3(cdiv(cols, 64), cdiv(rows, 16)), 256, 0, s>>>(
+            img, istride, rows, cols, t, hw, alpha, resp, rstride, gx, gy, gstride, vec_ok, img_vec_ok);
 }
 
 // ---- a10: threshold + non-maximum suppression ----------------------------------------------
@@ -250,7 +406,7 @@ __global__ __launch_bounds__(256) void harris_nms_kernel(const float *__restrict
                 }
             }
         }
-        corners[(size_t)y * cstride + x] = keep ? v : 0.f;
+        if (corners) corners[(size_t)y * cstride + x] = keep ? v : 0.f;
     }
     // a wave = 64 consecutive cells of one row: its ballot is that row segment's mask (compact.hpp)
     const unsigned long long m = __ballot(keep);
@@ -367,7 +523,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
                 if (y < rows) {  // (wave-uniform)
                     const float pv = T[(ry0 + j + DT) * TS + c + DT];
                     const bool keep = x < cols && (double)pv >= threshold && pv == M[j] && N[j] == 1;
-                    if (x < cols) corners[(size_t)y * cstride + x] = keep ? pv : 0.f;
+                    if (corners && x < cols) corners[(size_t)y * cstride + x] = keep ? pv : 0.f;
                     const unsigned long long m = __ballot(keep);  // the row segment's mask (compact.hpp)
                     if (c == 0) rowmask[(size_t)y * tiles_x + blockIdx.x] = m;
                 }
@@ -397,7 +553,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         for (int k = 0; k <= 2 * d; k++) N += RM[(ry + k) * TW + c] == M ? RN[(ry + k) * TW + c] : 0;
         const float v = T[(ry + d) * TS + c + d];
         const bool keep = x < cols && (double)v >= threshold && v == M && N == 1;
-        if (x < cols) corners[(size_t)y * cstride + x] = keep ? v : 0.f;
+        if (corners && x < cols) corners[(size_t)y * cstride + x] = keep ? v : 0.f;
         const unsigned long long m = __ballot(keep);
         if (c == 0) rowmask[(size_t)y * tiles_x + blockIdx.x] = m;
     }
@@ -511,26 +667,25 @@ int micv_harris_response_dev(micv_ctx *ctx, const float *gx, const float *gy, in
     return micv_harris_response_ex_dev(ctx, gx, gy, rows, cols, gstride, win, sigma, alpha, 0, resp, rstride, stream);
 }
 
-int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,
-                           double threshold, int min_distance, float *corners, size_t cstride,
-                           int32_t *locs_yx, int64_t cap, int64_t *count, micv_stream stream) {
-    MICV_REQUIRE(ctx && resp && corners && count, "micv_harris_refine: null argument");
-    MICV_REQUIRE(locs_yx || cap == 0, "micv_harris_refine: locs_yx is null");
-    MICV_REQUIRE(rows > 0 && cols > 0 && (int64_t)rows * cols < ((int64_t)1 << 31),
-                 "micv_harris_refine: bad size %dx%d", rows, cols);
-    MICV_REQUIRE(min_distance >= 0 && cap >= 0, "micv_harris_refine: bad min_distance / cap");
-    MICV_REQUIRE(stride_ok(rstride, cols, 4) && stride_ok(cstride, cols, 4),
-                 "micv_harris_refine: bad stride");
-    MICV_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
+}  // extern "C"
+
+namespace micv {
+static size_t harris_refine_scratch_bytes(int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols, nseg = (int64_t)rows * cdiv(cols, 64);
+    return Carver::need(nseg, 8) + Carver::need(n, 1) + compact_scratch_bytes(n);
+}
+
+// harris::refineCorners on a response already on the device; `scratch` = harris_refine_scratch_bytes() of context
+// scratch.  corners (the sparse map) may be null.
+static int harris_refine_run(micv_ctx *ctx, hipStream_t s, const float *resp, int rows, int cols, size_t rstride, double threshold,
+                             int min_distance, float *corners, size_t cstride, int32_t *locs_yx, int64_t cap, int64_t *count,
+                             void *scratch) {
     const int64_t n = (int64_t)rows * cols;
     // The NMS kernels leave one 64-bit mask per (row, 64-column tile) -- a wave is exactly such a row segment, its
     // ballot the mask -- and the ordered list is a chained scan over those words (compact_masks_onepass_kernel):
     // 130 k words in 32 chunks at 4K, where the flag-byte form scanned 8.3 M bytes in three launches.
     const int tiles_x = cdiv(cols, 64);
     const int64_t nseg = (int64_t)rows * tiles_x;
-    void *scratch;
-    MICV_TRY(ctx->reserve(Carver::need(nseg, 8) + Carver::need(n, 1) + compact_scratch_bytes(n), &scratch));
     Carver c(scratch);
     unsigned long long *rowmask = c.take<unsigned long long>(nseg);
     const bool force_scan = ctx->opt[MICV_OPT_NMS_SCAN] != 0;
@@ -572,6 +727,91 @@ int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols,
     MICV_LAUNCH_CHECK();
     // (y, x) written directly, Harris.cu:314-318 (Conv1Dto2D)
     return ordered_compact3(s, FlagPred{flag}, YxEmit{locs_yx, cols}, n, cap, count, c.base + c.off);
+}
+}  // namespace micv
+
+extern "C" {
+
+int micv_harris_refine_dev(micv_ctx *ctx, const float *resp, int rows, int cols, size_t rstride,
+                           double threshold, int min_distance, float *corners, size_t cstride,
+                           int32_t *locs_yx, int64_t cap, int64_t *count, micv_stream stream) {
+    MICV_REQUIRE(ctx && resp && corners && count, "micv_harris_refine: null argument");
+    MICV_REQUIRE(locs_yx || cap == 0, "micv_harris_refine: locs_yx is null");
+    MICV_REQUIRE(rows > 0 && cols > 0 && (int64_t)rows * cols < ((int64_t)1 << 31),
+                 "micv_harris_refine: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(min_distance >= 0 && cap >= 0, "micv_harris_refine: bad min_distance / cap");
+    MICV_REQUIRE(stride_ok(rstride, cols, 4) && stride_ok(cstride, cols, 4),
+                 "micv_harris_refine: bad stride");
+    MICV_HIP(hipSetDevice(ctx->device));
+    void *scratch;
+    MICV_TRY(ctx->reserve(harris_refine_scratch_bytes(rows, cols), &scratch));
+    return harris_refine_run(ctx, static_cast<hipStream_t>(stream), resp, rows, cols, rstride, threshold, min_distance, corners, cstride,
+                             locs_yx, cap, count, scratch);
+}
+
+int micv_harris_corners_dev(micv_ctx *ctx, const float *img, int rows, int cols, size_t stride, int sobel_ksize, int win,
+                            double sigma, float alpha, int flags, double threshold, int min_distance, float *gx, float *gy,
+                            size_t gstride, float *resp, size_t rstride, float *corners, size_t cstride, int32_t *locs_yx,
+                            int64_t cap, int64_t *count, micv_stream stream) {
+    MICV_REQUIRE(ctx && img && count, "micv_harris_corners: null argument");
+    MICV_REQUIRE((gx == nullptr) == (gy == nullptr), "micv_harris_corners: give both gradient outputs or neither");
+    MICV_REQUIRE(locs_yx || cap == 0, "micv_harris_corners: locs_yx is null");
+    MICV_REQUIRE(rows > 0 && cols > 0 && (int64_t)rows * cols < ((int64_t)1 << 31), "micv_harris_corners: bad size %dx%d", rows, cols);
+    MICV_REQUIRE(win >= 1 && (win & 1) && win <= kMaxWin, "micv_harris_corners: window %d must be odd and <= %d", win, kMaxWin);
+    MICV_REQUIRE(sigma > 0 && min_distance >= 0 && cap >= 0, "micv_harris_corners: bad sigma / min_distance / cap");
+    MICV_REQUIRE(stride_ok(stride, cols, 4) && (!gx || stride_ok(gstride, cols, 4)) && (!resp || stride_ok(rstride, cols, 4)) &&
+                     (!corners || stride_ok(cstride, cols, 4)),
+                 "micv_harris_corners: bad stride");
+    MICV_REQUIRE((flags & ~MICV_HARRIS_CPU) == 0, "micv_harris_corners: unknown flags %#x", flags);
+    Taps probe;
+    MICV_REQUIRE(sobel_taps(sobel_ksize, 1, &probe) >= 0, "micv_harris_corners: Sobel size %d not supported", sobel_ksize);
+    MICV_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int r = win / 2;
+    const bool cpu = (flags & MICV_HARRIS_CPU) != 0;
+    const bool fused = sobel_ksize == 3 && r >= 1 && r <= 3 && !ctx->opt[MICV_OPT_HARRIS_GENERIC] && !ctx->opt[MICV_OPT_SOBEL_GENERIC];
+    // one reservation for everything the chain needs: R when the caller does not keep it, the gradient planes and the
+    // Sobel temporaries of the three-launch form, the list's scan state
+    const size_t n = (size_t)rows * cols;
+    const size_t need_r = resp ? 0 : Carver::need(n, 4);
+    const size_t need_g = (fused || gx) ? 0 : 2 * Carver::need(n, 4);
+    const size_t need_t = fused ? 0 : Carver::need(2 * n, 4);
+    void *scratch;
+    MICV_TRY(ctx->reserve(need_r + need_g + need_t + harris_refine_scratch_bytes(rows, cols), &scratch));
+    Carver c(scratch);
+    float *R_ = resp;
+    size_t rs = rstride;
+    if (!R_) {
+        R_ = c.take<float>(n);
+        rs = (size_t)cols * 4;
+    }
+    Taps g;
+    gaussian_taps(win, sigma, &g);  // cv::getGaussianKernel(win, sigma, CV_32F), Harris.cpp:61
+    if (fused) {
+        const int is = (int)(stride / 4), gs = gx ? (int)(gstride / 4) : 0, rsi = (int)(rs / 4);
+#define MICV_HI(RR)                                                                                               \
+    (cpu ? launch_harris_image<RR, true> : launch_harris_image<RR, false>)(s, img, is, rows, cols, g, alpha, R_, rsi, gx, gy, gs)
+        if (r == 1) MICV_HI(1);
+        if (r == 2) MICV_HI(2);
+        if (r == 3) MICV_HI(3);
+#undef MICV_HI
+        MICV_LAUNCH_CHECK();
+    } else {
+        // other Sobel sizes / windows: the three launches of the separate entry points, same scratch
+        float *dgx = gx, *dgy = gy;
+        size_t gsb = gstride;
+        if (!dgx) {
+            dgx = c.take<float>(n);
+            dgy = c.take<float>(n);
+            gsb = (size_t)cols * 4;
+        }
+        float *tmp = c.take<float>(2 * n);
+        MICV_TRY(sobel_dev(s, img, rows, cols, (int)(stride / 4), sobel_ksize, 1.f, dgx, dgy, (int)(gsb / 4), tmp,
+                           ctx->opt[MICV_OPT_SOBEL_GENERIC] != 0));
+        // (micv_harris_response_ex_dev takes no scratch)
+        MICV_TRY(micv_harris_response_ex_dev(ctx, dgx, dgy, rows, cols, gsb, win, sigma, alpha, flags, R_, rs, stream));
+    }
+    return harris_refine_run(ctx, s, R_, rows, cols, rs, threshold, min_distance, corners, cstride, locs_yx, cap, count, c.base + c.off);
 }
 
 int micv_sift_angles_dev(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,

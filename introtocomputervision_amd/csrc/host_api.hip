@@ -358,6 +358,41 @@ int micv_harris_refine_host(micv_ctx *ctx, const float *resp, int rows, int cols
     return MICV_OK;
 }
 
+int micv_harris_corners_host(micv_ctx *ctx, const float *img, int rows, int cols, size_t stride, int sobel_ksize, int win,
+                             double sigma, float alpha, int flags, double threshold, int min_distance, float *gx, float *gy,
+                             size_t gstride, float *resp, size_t rstride, float *corners, size_t cstride, int32_t *locs_yx,
+                             int64_t cap, int64_t *count) {
+    HOST_PROLOGUE("micv_harris_corners_host");
+    MICV_REQUIRE(img && count && rows > 0 && cols > 0 && cap >= 0 && (locs_yx || cap == 0), "micv_harris_corners_host: bad argument");
+    MICV_REQUIRE((gx == nullptr) == (gy == nullptr), "micv_harris_corners_host: give both gradient outputs or neither");
+    MICV_REQUIRE(stride_ok(stride, cols, 4) && (!gx || stride_ok(gstride, cols, 4)) && (!resp || stride_ok(rstride, cols, 4)) &&
+                     (!corners || stride_ok(cstride, cols, 4)),
+                 "micv_harris_corners_host: bad stride");
+    const size_t rb = (size_t)cols * 4, n = rb * rows;
+    // one upload, every requested field downloaded: what three _host calls move three times
+    DevBuf di(n), dgx(gx ? n : 0), dgy(gy ? n : 0), dr(resp ? n : 0), dc(corners ? n : 0), dl((size_t)cap * 8), dn(8);
+    MICV_ALLOC_OK(di); MICV_ALLOC_OK(dl); MICV_ALLOC_OK(dn);
+    if (gx) { MICV_ALLOC_OK(dgx); MICV_ALLOC_OK(dgy); }
+    if (resp) MICV_ALLOC_OK(dr);
+    if (corners) MICV_ALLOC_OK(dc);
+    MICV_TRY(up2d(di.p, img, stride, rb, rows, s));
+    MICV_TIMED("harrisCornersChain",
+               micv_harris_corners_dev(ctx, di.as<float>(), rows, cols, rb, sobel_ksize, win, sigma, alpha, flags, threshold, min_distance,
+                                       gx ? dgx.as<float>() : nullptr, gy ? dgy.as<float>() : nullptr, rb, resp ? dr.as<float>() : nullptr, rb,
+                                       corners ? dc.as<float>() : nullptr, rb, dl.as<int32_t>(), cap, dn.as<int64_t>(), s));
+    if (gx) {
+        MICV_TRY(down2d(gx, gstride, dgx.p, rb, rows, s));
+        MICV_TRY(down2d(gy, gstride, dgy.p, rb, rows, s));
+    }
+    if (resp) MICV_TRY(down2d(resp, rstride, dr.p, rb, rows, s));
+    if (corners) MICV_TRY(down2d(corners, cstride, dc.p, rb, rows, s));
+    MICV_HIP(hipMemcpyAsync(count, dn.p, 8, hipMemcpyDeviceToHost, s));
+    MICV_HIP(hipStreamSynchronize(s));
+    const int64_t take = *count < cap ? *count : cap;
+    if (take > 0) MICV_HIP(hipMemcpy(locs_yx, dl.p, (size_t)take * 8, hipMemcpyDeviceToHost));
+    return MICV_OK;
+}
+
 int micv_sift_angles_host(micv_ctx *ctx, const float *gx, const float *gy, int rows, int cols,
                           size_t gstride, float *angles, size_t astride) {
     HOST_PROLOGUE("micv_sift_angles_host");

@@ -90,6 +90,60 @@ def refineCorners(cornerResponse, threshold, minDistance, capacity=None, ctx=Non
     return corners, locs[:min(cnt.value, cap)]
 
 
+def cornersFromImage(img, sobelSize=3, windowSize=5, gaussianSigma=1.5, harrisScore=0.04, threshold=5e8, minDistance=5,
+                     capacity=None, ctx=None, cpu_arithmetic=False, want_gradients=True, want_response=False,
+                     want_corners=False, lazy=False):
+    """The ps4 caller's chain (harrisHelper, ps4_cpp/src/Solution.cpp:77-124: harris::getGradients -> getCornerResponse
+    -> refineCorners) as ONE call (micv_harris_corners_dev / _host): with a 3x3 Sobel and windows 3 / 5 / 7 the gradients
+    are formed inside the response kernel's tile.  Same bits as the three separate calls.
+    Returns a dict: "locs" ([n, 2] int32 (y, x), row-major order), and as requested "gx", "gy", "response", "corners";
+    device input with lazy=True: "locs" has `capacity` rows and "count" is a device word (no host synchronisation)."""
+    B.check2d(img, np.float32, name="img")
+    rows, cols = img.shape
+    cap = int(capacity) if capacity is not None else rows * cols
+    c = _ctx_for(img, ctx)
+    flags = HARRIS_CPU if cpu_arithmetic else 0
+    gx = B.empty_like_shape(img, (rows, cols)) if want_gradients else None
+    gy = B.empty_like_shape(img, (rows, cols)) if want_gradients else None
+    resp = B.empty_like_shape(img, (rows, cols)) if want_response else None
+    corners = B.empty_like_shape(img, (rows, cols)) if want_corners else None
+    rb = cols * 4
+
+    def p(a):
+        return B.ptr(a) if a is not None else None
+
+    def sb(a):
+        return B.stride_bytes(a) if a is not None else rb
+    out = {}
+    if B.is_dev(img):
+        import torch
+        locs = torch.empty((cap, 2), dtype=torch.int32, device=img.device)
+        cnt = torch.zeros((1,), dtype=torch.int64, device=img.device) if lazy else B.pinned_count(img)
+        check(lib.micv_harris_corners_dev(c.handle, B.ptr(img), rows, cols, B.stride_bytes(img), int(sobelSize), int(windowSize),
+                                          float(gaussianSigma), float(harrisScore), flags, float(threshold), int(minDistance),
+                                          p(gx), p(gy), sb(gx), p(resp), sb(resp), p(corners), sb(corners), locs.data_ptr(), cap,
+                                          cnt.data_ptr(), B.stream_of(img)))
+        if lazy:
+            out["locs"], out["count"] = locs, cnt
+        else:
+            out["locs"] = locs[:min(B.read_count(cnt, img), cap)]
+    else:
+        locs = np.empty((cap, 2), np.int32)
+        cnt = i64(0)
+        check(lib.micv_harris_corners_host(c.handle, B.ptr(img), rows, cols, B.stride_bytes(img), int(sobelSize), int(windowSize),
+                                           float(gaussianSigma), float(harrisScore), flags, float(threshold), int(minDistance),
+                                           p(gx), p(gy), sb(gx), p(resp), sb(resp), p(corners), sb(corners), locs.ctypes.data, cap,
+                                           C.byref(cnt)))
+        out["locs"] = locs[:min(cnt.value, cap)]
+    if want_gradients:
+        out["gx"], out["gy"] = gx, gy
+    if want_response:
+        out["response"] = resp
+    if want_corners:
+        out["corners"] = corners
+    return out
+
+
 # The reference's two namespaces, for code that spells them out.
 class cpu:  # noqa: N801
     getCornerResponse = staticmethod(getCornerResponse)

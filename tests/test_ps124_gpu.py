@@ -517,3 +517,58 @@ def test_pitched_views_all_families(M):
     vm.copy_(dev(mask))
     assert np.array_equal(host(hough.houghLinesAccumulate(vm, 1, 1)), orc.hough_lines(mask, 1, 1))
     assert np.array_equal(host(hough.houghCirclesAccumulate(vm, 10)), orc.hough_circles(mask, 10))
+
+
+@pytest.mark.parametrize("rows,cols", [(480, 640), (64, 64), (33, 129), (97, 61), (1, 70), (70, 1), (2, 2), (131, 200), (2160, 3840), (300, 1283)])
+@pytest.mark.parametrize("win,cpu", [(5, False), (3, False), (7, True), (5, True)])
+def test_harris_corners_chain_is_the_three_calls(M, rows, cols, win, cpu):
+    """micv_harris_corners_dev (r05): image -> [gradients] -> R -> ordered list, the Sobel formed inside the response
+    kernel's LDS tile (ps4_cpp/src/Solution.cpp:77-124 as one call).  Every output -- gradients, R, the sparse map, the
+    list -- equals the three separate calls bit for bit (NaN-poisoned outputs first), on sizes around / below the tile,
+    borders, an unaligned width and 4K; C1's size also against the oracle."""
+    harris, stereo, hough, synth = M
+    img = synth.smooth_noise(11 + rows, rows, cols) * np.float32(37.0) if rows * cols < 3000000 else synth.checkerboard(rows, cols, square=40, seed=3)
+    d = dev(img)
+    thr = 1e6
+    gx, gy = harris.getGradients(d, 3)
+    R = harris.getCornerResponse(gx, gy, win, 1.5, 0.04, cpu_arithmetic=cpu)
+    corners, locs = harris.refineCorners(R, thr, 5)
+    out = harris.cornersFromImage(d, 3, win, 1.5, 0.04, thr, 5, cpu_arithmetic=cpu, want_gradients=True, want_response=True, want_corners=True)
+    assert host(out["gx"]).tobytes() == host(gx).tobytes() and host(out["gy"]).tobytes() == host(gy).tobytes()
+    assert host(out["response"]).tobytes() == host(R).tobytes()
+    assert host(out["corners"]).tobytes() == host(corners).tobytes()
+    assert np.array_equal(host(out["locs"]), host(locs))
+    # nothing but the list: R lives in context scratch, no gradient / map stores
+    lean = harris.cornersFromImage(d, 3, win, 1.5, 0.04, thr, 5, cpu_arithmetic=cpu, want_gradients=False)
+    assert np.array_equal(host(lean["locs"]), host(locs)) and set(lean) == {"locs"}
+    if rows * cols <= 480 * 640:
+        egx, egy = orc.sobel(img, 3, 1.0)
+        eR = orc.harris_response_ex(egx, egy, win, 1.5, 0.04, orc.HARRIS_CPU) if cpu else orc.harris_response(egx, egy, win, 1.5, 0.04)
+        assert np.array_equal(host(out["response"]), eR, equal_nan=True)
+        assert np.array_equal(host(out["locs"]), orc.harris_refine(eR, thr, 5)[1])
+
+
+def test_harris_corners_chain_other_sizes_host_form_and_views(M):
+    """Sobel 5 / window 9 take the three launches inside the same call; the host form (one upload) and a pitched device
+    view give the same list."""
+    harris, stereo, hough, synth = M
+    img = synth.checkerboard(240, 320, square=40, seed=5)
+    for ks, win in ((5, 5), (3, 9), (7, 3)):
+        gx, gy = harris.getGradients(dev(img), ks)
+        R = harris.getCornerResponse(gx, gy, win, 1.5, 0.04)
+        _, locs = harris.refineCorners(R, 5e8, 5)
+        out = harris.cornersFromImage(dev(img), ks, win, 1.5, 0.04, 5e8, 5, want_response=True)
+        assert host(out["response"]).tobytes() == host(R).tobytes() and np.array_equal(host(out["locs"]), host(locs))
+        assert host(out["gx"]).tobytes() == host(gx).tobytes()
+    gx, gy = harris.getGradients(dev(img), 3)
+    R = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04)
+    _, locs = harris.refineCorners(R, 5e8, 5)
+    h = harris.cornersFromImage(img, 3, 5, 1.5, 0.04, 5e8, 5, want_response=True, want_corners=True)
+    assert np.array_equal(h["locs"], host(locs)) and h["response"].tobytes() == host(R).tobytes() and len(h["locs"]) > 10
+    big = torch.zeros((250, 336), device="cuda")
+    view = big[5:245, 8:328]
+    view.copy_(dev(img))
+    v = harris.cornersFromImage(view, 3, 5, 1.5, 0.04, 5e8, 5, want_gradients=False)
+    assert np.array_equal(host(v["locs"]), host(locs))
+    with pytest.raises(Exception):
+        harris.cornersFromImage(dev(img), 4, 5, 1.5, 0.04, 5e8, 5)

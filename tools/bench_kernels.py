@@ -61,6 +61,11 @@ for rows, cols in ((2160, 3840), (480, 640)):
     line(f"sobel3 pair {cols}x{rows}", ms_s, rows * cols, 12)
     line(f"harris response 5x5 {cols}x{rows} (ref 480x640: 0.80 ms GTX1080)", ms_r, rows * cols, 12)
     line(f"harris NMS + ordered list {cols}x{rows} (ref 480x640: 0.59 ms)", ms_n, rows * cols, 8)
+    # r05: image -> R in ONE launch (Sobel inside the response kernel's tile), and the whole chain as one call
+    ms_f = timeit(lambda: harris.cornersFromImage(img, 3, 5, 1.5, 0.04, 3e38, 5, capacity=1 << 16, ctx=ctx, want_gradients=False, lazy=True))
+    line(f"harris image -> R -> (empty) list, one call, no gradient outputs {cols}x{rows}", ms_f, rows * cols, 12)
+    ms_fg = timeit(lambda: harris.cornersFromImage(img, 3, 5, 1.5, 0.04, 5e8, 5, capacity=1 << 16, ctx=ctx, want_gradients=True, lazy=True))
+    line(f"harris image -> gradients + R -> list, one call {cols}x{rows}", ms_fg, rows * cols, 20)
     ms_l = timeit(lambda: harris.refineCorners(Rr, 5e8, 5, capacity=1 << 16, ctx=ctx, lazy=True))
     line(f"harris NMS + ordered list {cols}x{rows}, count left on the device (lazy)", ms_l, rows * cols, 8)
     kp_ = harris.getKeypoints(gx, gy, harris.refineCorners(Rr, 5e8, 5, capacity=1 << 16, ctx=ctx)[1], 10, ctx=ctx)
