@@ -62,3 +62,29 @@ def test_mhi_gpu_matches_oracle(rows, cols, ksize, sigma, thr):
     hh = np.random.default_rng(1).integers(0, 256, (rows, cols)).astype(np.uint8)
     mhi.calcMotionHistory(hh, exp, 25)
     assert np.array_equal(hh, eh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cols", [(1080, 1920), (53, 64), (52, 70), (1, 300), (300, 1), (5, 5), (7, 129), (105, 58), (200, 6), (64, 1000)])
+@pytest.mark.parametrize("thr", [1, 0, 40])
+def test_mhi_bit_plane_open_on_noise_and_edges(rows, cols, thr):
+    """r05: frameDifference = a ballot-mask launch + a bit-plane 7x7 open (mhi.hip).  Random frames make masks that are
+    dense, ragged and alive right at the borders -- where the reflected padding of BOTH morphology passes matters -- on
+    widths that are not multiples of 64, images smaller than the structuring element, one-row / one-column images,
+    a threshold of 0 (everything set) and pitched device views.  Byte-exact against the oracle."""
+    import torch
+    from introtocomputervision_amd import mhi
+    rng = np.random.default_rng(rows * 7919 + cols + thr)
+    f1 = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+    f2 = np.clip(f1.astype(np.int32) + rng.integers(-60, 90, (rows, cols)) * (rng.random((rows, cols)) < 0.6), 0, 255).astype(np.uint8)
+    for ksize, sigma in ((3, 1.0), ((5, 1), 1.5)):
+        exp = orc.mhi_frame_difference(f1, f2, thr, ksize, sigma)
+        got = mhi.frameDifference(torch.from_numpy(f1).cuda(), torch.from_numpy(f2).cuda(), thr, ksize, sigma)
+        assert np.array_equal(got.cpu().numpy(), exp), (ksize, int((got.cpu().numpy() != exp).sum()))
+    big1 = torch.zeros((rows + 4, cols + 9), dtype=torch.uint8, device="cuda"); big2 = torch.zeros_like(big1)
+    v1, v2 = big1[2:2 + rows, 5:5 + cols], big2[2:2 + rows, 5:5 + cols]
+    v1.copy_(torch.from_numpy(f1)); v2.copy_(torch.from_numpy(f2))
+    exp = orc.mhi_frame_difference(f1, f2, thr, 3, 1.0)
+    assert np.array_equal(mhi.frameDifference(v1, v2, thr, 3, 1.0).cpu().numpy(), exp)
+    if 0 < thr < 40 and rows * cols > 2000:
+        assert 0 < exp.sum() < exp.size  # the case exercises both values
