@@ -164,6 +164,42 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
     const int d_lo = MODE == ST_SSD_SERIAL ? -(xo + R) : a.min_d;
     const int d_hi = MODE == ST_SSD_SERIAL ? a.cols - 1 + R - xo : a.max_d;
 
+    // The strip of `right` (and, for NCC, of the window-energy field) a chunk of disparities slides over is PREFETCHED:
+    // its global loads are issued into registers before the previous chunk's search loop and written to LDS after it,
+    // so the memory round trip runs under ~8 k instructions of arithmetic instead of in front of them (r05: the wave has
+    // nothing else to overlap it with -- SQ_WAIT_ANY was 35 % of the NCC kernel's wave cycles, profiles/r05/stereo_ncc.txt).
+    // NCC only (0.388 -> 0.326 ms at C3); SSD, whose chunks are twice as long and whose loads are a third of NCC's per
+    // disparity, LOSES with it (0.2265 -> 0.265 ms: 40 more live registers), so it keeps staging in front of the loop.
+#ifndef MICV_STEREO_PF
+#define MICV_STEREO_PF 2
+#endif
+    constexpr int PF = MODE == ST_NCC ? MICV_STEREO_PF : 0;  // 0 = no prefetch, 1 = the right strip, 2 = + the energy strip
+    constexpr int NH = (ST_SPAN + 63) / 64;
+    float pre_r[PF >= 1 ? STEPS : 1][NH], pre_e[PF >= 2 && ESTEPS > 0 ? ESTEPS : 1][NH];
+    auto load_r = [&](int d0, int s, int h) {
+        const int yy = clampi(ys - R + s, 0, a.rows - 1), i = lane + 64 * h;
+        return a.right[(size_t)yy * a.stride + clampi(x_base + d0 + (i < ST_SPAN ? i : ST_SPAN - 1), 0, a.cols - 1)];
+    };
+    auto load_e = [&](int d0, int j, int h) {
+        const int i = lane + 64 * h;
+        return a.energy[(size_t)(ys + j < a.rows ? ys + j : a.rows - 1) * a.e_width +
+                        clampi(x_base + d0 + (i < ST_SPAN ? i : ST_SPAN - 1) - a.s_lo, 0, a.e_width - 1)];
+    };
+    auto prefetch = [&](int d0) {
+        if constexpr (PF >= 1) {
+#pragma unroll
+            for (int s = 0; s < STEPS; s++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) pre_r[s][h] = load_r(d0, s, h);
+        }
+        if constexpr (PF >= 2 && MODE == ST_NCC) {
+#pragma unroll
+            for (int j = 0; j < ESTEPS; j++)
+#pragma unroll
+                for (int h = 0; h < NH; h++) pre_e[j][h] = load_e(d0, j, h);
+        }
+    };
+    if (PF > 0) prefetch(a.min_d);
     for (int d0 = a.min_d; d0 <= a.max_d; d0 += ST_DCH) {
         // Stage the strip of `right` this chunk of disparities slides over: column i of the strip
         // is image column clamp(x_base + d0 + i) (clamp-to-edge), rows as for Lv.  Every later
@@ -172,13 +208,11 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
         NccRange pix = pix_l, en;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
-            const int yy = clampi(ys - R + s, 0, a.rows - 1);
-            const float *rr = a.right + (size_t)yy * a.stride;
 #pragma unroll
-            for (int h = 0; h < (ST_SPAN + 63) / 64; h++) {
+            for (int h = 0; h < NH; h++) {
                 const int i = lane + 64 * h;
                 if (ST_SPAN % 64 == 0 || i < ST_SPAN) {
-                    const float v = rr[clampi(x_base + d0 + i, 0, a.cols - 1)];
+                    const float v = PF >= 1 ? pre_r[PF >= 1 ? s : 0][h] : load_r(d0, s, h);
                     Rs[s * ST_SPAN + i] = v;
                     if (MODE == ST_NCC) pix.add(v);
                 }
@@ -187,18 +221,18 @@ __global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
         if (MODE == ST_NCC) {
 #pragma unroll
             for (int j = 0; j < RPW; j++) {
-                const float *er = a.energy + (size_t)(ys + j < a.rows ? ys + j : a.rows - 1) * a.e_width;
 #pragma unroll
-                for (int h = 0; h < (ST_SPAN + 63) / 64; h++) {
+                for (int h = 0; h < NH; h++) {
                     const int i = lane + 64 * h;
                     if (ST_SPAN % 64 == 0 || i < ST_SPAN) {
-                        const float v = er[clampi(x_base + d0 + i - a.s_lo, 0, a.e_width - 1)];
+                        const float v = pre_e[j][h];
                         Es[j * ST_SPAN + i] = v;
                         en.add(v);
                     }
                 }
             }
         }
+        if (PF > 0 && d0 + ST_DCH <= a.max_d) prefetch(d0 + ST_DCH);  // the next chunk's loads fly under this chunk's search
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int d1 = d0 + ST_DCH - 1 < a.max_d ? d0 + ST_DCH - 1 : a.max_d;
