@@ -1,16 +1,35 @@
-import sys, time, json
-sys.path.insert(0, '.')
-import numpy as np, torch
-from introtocomputervision_amd import lk, synth, _capi
-p, n = synth.lk_pair(0x5EED0005, 1080, 1920, 3, -2)
-dp, dn = torch.from_numpy(np.stack([p]*4)).cuda(), torch.from_numpy(np.stack([n]*4)).cuda()
-out = (torch.empty_like(dp), torch.empty_like(dp))
+#!/usr/bin/env python3
+"""5-level pyramidal LK on 1080p pairs per window size (config/ps5.yaml uses 43, 7, 15; the reference's default winSize
+is 21) and per batch size: one JSON line per (window, pairs).  python tools/win_bench.py [pairs ...]   (default 1 4 8)"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from introtocomputervision_amd import _capi, lk, synth
+
+batches = [int(a) for a in sys.argv[1:]] or [1, 4, 8]
 ctx = _capi.Context(0)
-import sys as _s
-if len(_s.argv) > 1: ctx.set_option(_capi.OPT_LK_SHORT_TILES, int(_s.argv[1]))
-for win in (7, 11, 15, 21, 43):
-    for _ in range(3): lk.calcOpticalFlowPyrBatch(dp, dn, win, 5, ctx=ctx, out=out)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(20): lk.calcOpticalFlowPyrBatch(dp, dn, win, 5, ctx=ctx, out=out)
-    torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 20 * 1e3
-    print(json.dumps({"win": win, "ms_per_4_pairs": round(ms, 3), "Gpix_s": round(4 * 1080 * 1920 / ms / 1e6, 1)}))
+for B in batches:
+    pn = [synth.lk_pair(0x5EED0005 + i, 1080, 1920, 3, -2) for i in range(B)]
+    dp = torch.from_numpy(np.stack([p for p, _ in pn])).cuda()
+    dn = torch.from_numpy(np.stack([n for _, n in pn])).cuda()
+    out = (torch.empty_like(dp), torch.empty_like(dp))
+    for win in (7, 11, 15, 21, 43):
+        t_end = time.perf_counter() + 0.15  # clock pre-roll
+        while time.perf_counter() < t_end:
+            lk.calcOpticalFlowPyrBatch(dp, dn, win, 5, ctx=ctx, out=out)
+            torch.cuda.synchronize()
+        reps = 30
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            lk.calcOpticalFlowPyrBatch(dp, dn, win, 5, ctx=ctx, out=out)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t) / reps * 1e3
+        print(json.dumps({"win": win, "pairs": B, "ms_per_call": round(ms, 4), "Gpix_s": round(B * 1080 * 1920 / ms / 1e6, 1),
+                          "level0_kernel": ctx.lk_level_kernel_name(win, 1080, 1920, B) if win in (7, 11, 15, 21) else "generic (two launches per level)"}), flush=True)
