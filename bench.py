@@ -594,12 +594,28 @@ def main(argv=None):
         try:
             if args.mode == "rowshard" and args.next_margin is None:
                 runner.comm.selftest(stream)
+                comm_selftest = "ok"
             else:
+                # pairs mode: the communicator is diagnostic only, so it must not be able to take the measurement down
+                # with it -- it runs on a helper thread with a deadline (ctypes releases the GIL; a rank stuck inside
+                # ncclCommInitRank because a peer failed early is left behind, the bench goes on and says so)
+                import threading
                 from introtocomputervision_amd import shard as _shard
-                _tc = _shard.MicvComm(ctx, rank, n_gpus, dist=dist)
-                _tc.selftest(stream)
-                _tc.close()
-            comm_selftest = "ok"
+                box = {}
+
+                def _run():
+                    try:
+                        torch.cuda.set_device(dev)
+                        _tc = _shard.MicvComm(ctx, rank, n_gpus, dist=dist)
+                        _tc.selftest(stream)
+                        _tc.close()
+                        box["r"] = "ok"
+                    except Exception as e:  # noqa: BLE001
+                        box["r"] = f"FAILED on rank {rank}: {e}"
+                th = threading.Thread(target=_run, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("MICV_BENCH_SELFTEST_TIMEOUT_S", "90")))
+                comm_selftest = box.get("r", f"TIMEOUT on rank {rank} (no answer from micv_comm_create / micv_comm_selftest)")
         except Exception as e:  # noqa: BLE001 -- reported in the JSON line
             comm_selftest = f"FAILED on rank {rank}: {e}"
             if args.mode == "rowshard":

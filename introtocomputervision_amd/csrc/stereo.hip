@@ -104,7 +104,12 @@ __global__ __launch_bounds__(256) void stereo_energy_kernel(StereoArgs a, float 
 }
 
 template <int R, int MODE, int RPW, int ST_DCH = ST_DCH_DEFAULT>
-__global__ __launch_bounds__(256) void stereo_kernel(StereoArgs a) {
+// Register budget: LDS allows three workgroups per CU = three waves per SIMD, so the SSD forms may take 170 VGPRs instead
+// of the 128 the default heuristic aims at (r05 A/B on one box: 0.2246-0.2267 -> 0.2176-0.2208 ms at C3); NCC with its
+// prefetched strips keeps the default budget -- it then takes 243 VGPRs = two waves per SIMD, 0.326 ms; capped at 170 it spills
+// (0.389 ms), told "two waves" it allocates 179 and schedules worse (0.417 ms).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == ST_NCC ? 1 : 3, MODE == ST_NCC ? 8 : 3)))
+void stereo_kernel(StereoArgs a) {
     constexpr int W = 2 * R + 1, STEPS = RPW + 2 * R, OUTW = 64 - 2 * R, ST_SPAN = 64 + ST_DCH;
     extern __shared__ float st_lds[];
     const int lane = threadIdx.x & 63;

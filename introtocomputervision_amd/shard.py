@@ -508,15 +508,24 @@ class MicvComm:
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
         if unique_id is None:
             buf = (C.c_char * MICV_COMM_ID_BYTES)()
-            if rank == 0:
-                check(lib.micv_comm_unique_id(buf))
             if world > 1:
                 if dist is None:
                     raise ValueError("world > 1 needs torch.distributed (or a unique_id) to share the RCCL unique id")
-                box = [bytes(buf.raw)]
+                # rank 0 ALWAYS broadcasts -- the id, or why there is none -- so that a failure on rank 0 does not leave
+                # the other ranks waiting in the broadcast
+                box = [None]
+                if rank == 0:
+                    try:
+                        check(lib.micv_comm_unique_id(buf))
+                        box = [bytes(buf.raw)]
+                    except Exception as e:  # noqa: BLE001
+                        box = [f"rank 0 could not make an RCCL unique id: {e}"]
                 dist.broadcast_object_list(box, src=0)
-                unique_id = box[0]
+                if not isinstance(box[0], (bytes, bytearray)):
+                    raise RuntimeError(str(box[0]))
+                unique_id = bytes(box[0])
             else:
+                check(lib.micv_comm_unique_id(buf))
                 unique_id = bytes(buf.raw)
         if len(unique_id) != MICV_COMM_ID_BYTES:
             raise ValueError(f"an RCCL unique id has {MICV_COMM_ID_BYTES} bytes")
