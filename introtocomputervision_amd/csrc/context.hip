@@ -337,6 +337,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: build overlap must be -1 (never), 0 (single pairs) or 1 (every batch)");
     if (option == MICV_OPT_LK_SPLIT)
         MICV_REQUIRE(value >= 0 && value <= 3, "micv_ctx_set_option: split launch must be 0 (never) .. 3");
+    if (option == MICV_OPT_LK_STRIP)
+        MICV_REQUIRE(value >= 0 && value <= 8192 + 4096 && (value & 8191) <= 4096, "micv_ctx_set_option: strip segments must be 0 (off) .. 4096 blocks of 16 rows (+ 8192: launches of 4096 tiles or more only)");
     ctx->opt[option] = value;
     return MICV_OK;
 }

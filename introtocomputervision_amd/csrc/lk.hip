@@ -759,6 +759,7 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
         a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
         a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
         a.split = ctx->opt[MICV_OPT_LK_SPLIT];
+        a.strip = ctx->opt[MICV_OPT_LK_STRIP];
         if (c.grad && !direct) {
             const LkGradGeom gg = lk_grad_geom(R, C, win);
             if (gg.pair_elems * c.nb <= c.grad_elems) {
@@ -1222,6 +1223,7 @@ int micv_lk_level_kernel_name(micv_ctx *ctx, int win, int rows, int cols, int ba
     a.stream_tiles = ctx->opt[MICV_OPT_LK_STREAM];
     a.tall_tiles = ctx->opt[MICV_OPT_LK_TALL_TILES];
     a.split = ctx->opt[MICV_OPT_LK_SPLIT];
+    a.strip = ctx->opt[MICV_OPT_LK_STRIP];
     if (a.split > 0 && lk_split_supports(win)) {
         const LkGradGeom gg = lk_grad_geom(rows, cols, win);
         a.grad = fake; a.grad_pair = gg.pair_elems; a.grad_pitch = gg.pitch; a.grad_rows = gg.rows; a.grad_pad = gg.pad;

@@ -191,6 +191,8 @@ __device__ __forceinline__ void dma_coarse(const LkLevelArgs &a, int pair, int c
     }
 }
 
+#include "lk_strip.hpp"  // the streaming interior body (r05): needs dma_rows / dma_coarse above
+
 // What a streamed tile hands back to the loop that runs it: the entry it took the next ticket for,
 // and whether that tile's `next` window and coarse block are already on their way into LDS.
 struct LkStreamLink {
@@ -1224,6 +1226,58 @@ __global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_grad_kernel(Lk
         lk_tile<R, LK_FLOW_COARSE, false, NTV, false, THV, false, false, false, false, 64, true>(a, g, lds, tile_x, tile_y, blockIdx.y);
 }
 
+// Strip launch (r05, lk_strip.hpp): the interior tiles of the level as streamed strips, the border tiles as tiles, one
+// launch.  Workgroups [0, items) take the strip items -- numbered strip-fastest, dealt to the XCDs in contiguous runs
+// (neighbouring strips share 32 of their 96 window columns) -- the rest take the border tiles (top rows, bottom rows,
+// side columns); the long items are dispatched first and the short border tiles fill in behind them.
+struct LkStripPlan {
+    int items, strips, segs, seg_rows;  // per launch: items = batch * segs * strips
+    int ix0, iw, iy0, ih;               // the interior tile rectangle (64x32 tiles)
+    int tiles_x, tiles_y, border;       // border tiles per pair
+};
+
+template <int R, int NTV>
+__global__ __launch_bounds__(NTV, lk_waves_per_simd(NTV)) void lk_level_strip_kernel(LkLevelArgs a, TapsN<2 * R + 1> g, LkStripPlan p) {
+    using C = LkCfg<R, NTV>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int b = blockIdx.x;
+    if (b < p.items) {
+        const int per = p.items >> 3, rem = p.items & 7;
+        const int xcd = b & 7, idx = b >> 3;
+        // (when items is not a multiple of 8 the last run is short: workgroups past it on their XCD take the tail)
+        int item = xcd * per + (xcd < rem ? xcd : rem) + idx;
+        if (idx >= per + (xcd < rem ? 1 : 0)) return;  // cannot happen: the grid has exactly `items` strip workgroups
+        const int strip = item % p.strips, t = item / p.strips;
+        const int seg = t % p.segs, pair = t / p.segs;
+        const int x0 = (p.ix0 + strip) * C::TW;
+        const int s0 = p.iy0 * C::TH + seg * p.seg_rows;
+        const int end = (p.iy0 + p.ih) * C::TH;
+        const int s1 = s0 + p.seg_rows < end ? s0 + p.seg_rows : end;
+        lk_strip<R>(a, g, lds, x0, s0, s1, pair);
+        return;
+    }
+    b -= p.items;
+    const int pair = b / p.border;
+    b -= pair * p.border;
+    int tile_x, tile_y;
+    const int iy1 = p.iy0 + p.ih, n_top = p.iy0 * p.tiles_x, n_bot = (p.tiles_y - iy1) * p.tiles_x, side = p.tiles_x - p.iw;
+    if (b < n_top) {
+        tile_y = b / p.tiles_x;
+        tile_x = b - tile_y * p.tiles_x;
+    } else if (b < n_top + n_bot) {
+        b -= n_top;
+        tile_y = b / p.tiles_x;
+        tile_x = b - tile_y * p.tiles_x;
+        tile_y += iy1;
+    } else {
+        b -= n_top + n_bot;
+        const int r = b / side, c = b - r * side;
+        tile_y = p.iy0 + r;
+        tile_x = c < p.ix0 ? c : c + p.iw;
+    }
+    lk_tile<R, LK_FLOW_COARSE, false, NTV>(a, g, lds, tile_x, tile_y, pair);
+}
+
 // Chain launch: workgroup b runs the `count` vertically adjacent tiles of sched[b] (tile_x, first
 // tile_y, count, pair), carrying the gradient rows from one tile to the next.  A 1-D grid: the
 // host-built schedule already contains the batch, the XCD-aware placement and the order of issue.
@@ -1635,6 +1689,58 @@ static int launch_r(hipStream_t s, const LkLevelArgs &a) {
     return MICV_OK;
 }
 
+// The strip launch (MICV_OPT_LK_STRIP): whole frames with a doubling coarse flow whose images the LDS-DMA can address, and
+// at least one interior tile row and column.  blocks = rows of a segment / 16 (0 = the default).
+template <int R>
+static int launch_strip(hipStream_t s, const LkLevelArgs &a, int blocks) {
+    using C = LkCfg<R, 512>;
+    using SC = StripCfg<R>;
+    static_assert(SC::LDS_BYTES <= C::LDS_BYTES, "a strip workgroup fits the tile body's LDS");
+    constexpr int E = C::M > 2 ? C::M : 2, FX = C::TW + C::H + E, FY = C::TH + C::H + E;
+    LkStripPlan p;
+    p.tiles_x = cdiv(a.cols, C::TW);
+    p.tiles_y = cdiv(a.rows, C::TH);
+    p.ix0 = (C::H + E + C::TW - 1) / C::TW;
+    int ix1 = a.cols >= FX ? (a.cols - FX) / C::TW + 1 : 0;
+    p.iy0 = (C::H + E + C::TH - 1) / C::TH;
+    int iy1 = a.rows >= FY ? (a.rows - FY) / C::TH + 1 : 0;
+    ix1 = ix1 < p.tiles_x ? ix1 : p.tiles_x;
+    iy1 = iy1 < p.tiles_y ? iy1 : p.tiles_y;
+    p.iw = ix1 - p.ix0;
+    p.ih = iy1 - p.iy0;
+    if (p.iw < 1 || p.ih < 1) return MICV_EUNSUPPORTED;
+    // the warm-up block above a segment reads 16 rows above the first interior tile row: inside the image by the interior
+    // predicate (tile + halo + margin = 16 rows) -- and the strip body assumes R + 1 = H
+    if (p.iy0 * C::TH < SC::B + SC::M) return MICV_EUNSUPPORTED;
+    p.strips = p.iw;
+    p.seg_rows = (blocks > 0 ? blocks : 16) * SC::B;
+    p.segs = cdiv(p.ih * C::TH, p.seg_rows);
+    p.items = p.strips * p.segs * a.batch;
+    p.border = p.tiles_x * p.tiles_y - p.iw * p.ih;
+    static TapsN<2 * R + 1> taps;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        Taps t;
+        gaussian_taps(2 * R + 1, (double)((float)(2 * R + 1) / 3.f), &t);  // OpticalFlow.cpp:73
+        for (int i = 0; i < 2 * R + 1; i++) taps.k[i] = t.k[i];
+    });
+    static thread_local int done_dev = -1;
+    int dev = 0;
+    MICV_HIP(hipGetDevice(&dev));
+    if (done_dev != dev) {
+        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_level_strip_kernel<R, 512>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES));
+        done_dev = dev;
+    }
+    LkLevelArgs b = a;
+    b.y_shift = 0;
+    b.job.blocks = 0;
+    const long grid = (long)p.items + (long)p.border * a.batch;
+    lk_level_strip_kernel<R, 512><<<(unsigned)grid, 512, C::LDS_BYTES, s>>>(b, taps, p);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
 // The split launch: pre-pass (phases 0-3 once per pixel + 1-px... see lk_grad_kernel) then the streaming sums kernel.
 template <int RS>
 static int launch_split(hipStream_t s, const LkLevelArgs &a) {
@@ -1694,6 +1800,20 @@ int launch_lk_level_fused(hipStream_t s, const LkLevelArgs &a_in) {
 #else
     a.stamps = nullptr;
 #endif
+    // Strip launch (r05, MICV_OPT_LK_STRIP; off by default: -15 % instructions, the same time -- DESIGN.md section 5): the
+    // interior as streamed strips, window 15
+    if (a.strip > 0 && a.win == 15 && a.row_begin == 0 && a.row_end == a.rows && a.img_xstride == 1 && a.job.blocks == 0 &&
+        a.stamps == nullptr && a.stop_after < 0 && a.mode == LK_FLOW_COARSE && a.rows == 2 * a.flow_rows && a.cols == 2 * a.flow_cols &&
+        (a.img_stride & 3) == 0 && (a.img_pair & 3) == 0 && !a.narrow &&
+        ((reinterpret_cast<uintptr_t>(a.prev) | reinterpret_cast<uintptr_t>(a.next)) & 15) == 0 &&
+        a.strip > 0 && (!(a.strip & 8192) || (long)cdiv(a.cols, 64) * cdiv(a.rows, 32) * a.batch >= 4096)) {
+        if (a.name_out) {
+            snprintf(a.name_out, a.name_cap, "lk_level_strip_kernel<7, 512>");
+            return MICV_OK;
+        }
+        const int rc = launch_strip<7>(s, a, a.strip & 8191);
+        if (rc != MICV_EUNSUPPORTED) return rc;  // (no interior rectangle: the tile launch below)
+    }
     // Split launch (r05): pre-pass + streaming sums, for whole-frame launches with a doubling coarse flow whose caller
     // provided the gradient planes
     if (a.grad && a.row_begin == 0 && a.row_end == a.rows && a.img_xstride == 1 && a.job.blocks == 0 && a.stamps == nullptr &&

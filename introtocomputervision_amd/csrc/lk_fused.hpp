@@ -71,6 +71,7 @@ struct LkLevelArgs {
     size_t grad_pair = 0;
     int grad_pitch = 0, grad_rows = 0, grad_pad = 0;
     int split = 0;  // MICV_OPT_LK_SPLIT
+    int strip = 0;  // MICV_OPT_LK_STRIP: 0 = off, n > 0 = the interior as streamed strips, segments of n blocks of 16 rows
     int pre_base = 0;  // pre-pass tiles store the base flow into out_u / out_v (LkSumsArgs::base == 1)
     // Diagnostic (micv_lk_level_kernel_name): when set, launch_lk_level_fused launches NOTHING and writes the name of the
     // kernel instantiation it would have launched -- the dispatch has one definition, so tools that filter profiler rows

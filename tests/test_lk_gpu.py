@@ -861,3 +861,29 @@ def test_level_kernel_name_comes_from_the_dispatch(mods):
     ctx.set_option(_capi.OPT_LK_SPLIT, 0)
     ctx.set_option(_capi.OPT_LK_NARROW_TILES, 1)
     assert ctx.lk_level_kernel_name(15, 1080, 1920, 8) == "lk_level_kernel<7, 1, 256, 32, false, 64>"
+
+
+@pytest.mark.parametrize("rows,cols,levels,batch,blocks", [(270, 480, 2, 1, 4), (540, 960, 3, 3, 16), (1080, 1920, 5, 2, 16), (1080, 1920, 2, 1, 7),
+                                                            (200, 328, 2, 5, 2), (1088, 1924, 2, 1, 64), (160, 1000, 2, 2, 1), (1000, 164, 2, 2, 3),
+                                                            (2160, 3840, 3, 1, 16), (128, 128, 2, 1, 16)])
+def test_strip_launch_is_bit_exact(mods, rows, cols, levels, batch, blocks):
+    """MICV_OPT_LK_STRIP (r05, lk_strip.hpp): the interior tiles of a level as strips streamed down in blocks of 16 rows
+    (carried row-pass rows of the five fields, carried warped rows), the border tiles as tiles, one launch.  Same bits as
+    the tile launch and the oracle for every segment length, incl. segments that are not whole, one-strip and one-segment
+    interiors, and images too small to have an interior (the tile launch then runs)."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth, _capi
+    pairs = [synth.lk_pair(9100 + i + rows, rows, cols, 3, -2) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs]); nxt = np.stack([n for _, n in pairs])
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_STRIP, blocks)
+    u = torch.full((batch, rows, cols), float("nan"), device="cuda"); v = torch.full_like(u, float("nan"))
+    for rep in range(2):
+        lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx, out=(u, v))
+    ctx.set_option(_capi.OPT_LK_STRIP, 0)
+    bu, bv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 15, levels, ctx=ctx)
+    du = host(u).view(np.uint32) != host(bu).view(np.uint32); dv = host(v).view(np.uint32) != host(bv).view(np.uint32)
+    assert not du.any() and not dv.any(), (int(du.sum()), int(dv.sum()), np.argwhere(du | dv)[:8].tolist())
+    if rows * cols * levels <= 1080 * 1920 * 5:
+        eu, ev = orc.lk_flow_pyr(prev[batch - 1], nxt[batch - 1], 15, levels)
+        assert np.array_equal(host(u[batch - 1]), eu, equal_nan=True) and np.array_equal(host(v[batch - 1]), ev, equal_nan=True)
