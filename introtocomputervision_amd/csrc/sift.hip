@@ -183,26 +183,33 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
     const SiftGeom g = sift_geometry(kps + 4 * k, rows, cols);
     for (int t = lane; t < COPIES * SHIST; t += 64) hist[t] = 0ull;
     const int side = 2 * g.radius + 1;
-    const long long total = g.valid ? (long long)side * side : 0;
 
     // sweep 1: a bound on every contribution, 2 * max(|gx|, |gy|) over the window's bounding square
     // inside the image interior (no rotation, no square root: ~8 instructions per sample)
     float bound = 0.f;
     {
-        const int first = 64 * sub + lane;
-        int i = -g.radius + first / side, j = -g.radius + first % side;
-        for (long long s = first; s < total; s += 64 * WPK) {
-            while (j > g.radius) {
-                j -= side;
-                i++;
+        // a wave takes whole rows of the square: lane = column (two columns per lane when the side exceeds 64, more in a
+        // loop), four rows' loads in flight per step -- the row-major "sample s of side^2" walk cost an index carry and
+        // two dependent loads per sample (3.6 k of the kernel's 30 k instructions per keypoint at size 10)
+        const int c_lo = g.px - g.radius > 1 ? g.px - g.radius : 1, c_hi = g.px + g.radius < cols - 2 ? g.px + g.radius : cols - 2;
+        const int r_lo = g.py - g.radius > 1 ? g.py - g.radius : 1, r_hi = g.py + g.radius < rows - 2 ? g.py + g.radius : rows - 2;
+        if (g.valid && c_lo <= c_hi) {
+            for (int r = r_lo + 4 * sub; r <= r_hi; r += 4 * WPK) {
+                for (int c = c_lo + lane; c <= c_hi; c += 64) {
+                    float ax[4], ay[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int rr = r + k <= r_hi ? r + k : r_hi;  // (a repeated row does not change a max)
+                        ax[k] = fabsf(gx[(size_t)rr * gstride + c]);
+                        ay[k] = fabsf(gy[(size_t)rr * gstride + c]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float m = ax[k] > ay[k] ? ax[k] : ay[k];
+                        bound = m > bound ? m : bound;  // NaN gradients never raise the bound
+                    }
+                }
             }
-            const int r = g.py + i, c = g.px + j;
-            if (r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
-                const float ax = fabsf(gx[(size_t)r * gstride + c]), ay = fabsf(gy[(size_t)r * gstride + c]);
-                const float m = ax > ay ? ax : ay;
-                bound = m > bound ? m : bound;  // NaN gradients never raise the bound
-            }
-            j += 64 * WPK;
         }
     }
 #pragma unroll
@@ -241,22 +248,62 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
         const int nb = (side + 7) >> 3;
         const int nblk = g.valid ? nb * nb : 0;
         const int ly = lane >> 3, lx = lane & 7;
-        for (int blk = sub * U; blk < nblk; blk += U * WPK) {
+        // Blocks that cannot hold an accepted sample are dropped BEFORE their 64 per-sample tests (r05): rbin and cbin are
+        // monotone in i and in j separately (a float product of a fixed factor is monotone, so is a float sum in each
+        // operand), so over a block they lie between their values at the block's four corners; if that range misses
+        // (-1, SD) for either coordinate no sample of the block passes sift_test.  One lane = one block here: 64 blocks
+        // per pass, the survivors as a bit mask the wave then walks.  Exact, not a heuristic: nothing that contributes is
+        // skipped (about 30 % of the blocks of a size-10 window go).
+        for (int base = 0; base < nblk; base += 64) {
+            const int blk_l = base + lane;
+            bool maybe = false;
+            if (blk_l < nblk) {
+                const int bi_l = blk_l / nb, bj_l = blk_l - bi_l * nb;
+                const int i0 = -g.radius + 8 * bi_l, j0 = -g.radius + 8 * bj_l;
+                const int i1 = i0 + 7 < g.radius ? i0 + 7 : g.radius, j1 = j0 + 7 < g.radius ? j0 + 7 : g.radius;
+                float rmin = INFINITY, rmax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = (k & 2) ? i1 : i0, j = (k & 1) ? j1 : j0;
+                    const float c_rot = (float)j * g.cos_t - (float)i * g.sin_t;  // sift_test's own expressions
+                    const float r_rot = (float)j * g.sin_t + (float)i * g.cos_t;
+                    const float rb = r_rot + (float)(SD / 2) - 0.5f, cb = c_rot + (float)(SD / 2) - 0.5f;
+                    rmin = fminf(rmin, rb); rmax = fmaxf(rmax, rb);
+                    cmin = fminf(cmin, cb); cmax = fmaxf(cmax, cb);
+                }
+                // (NaN geometry cannot occur: g.valid; the comparisons are the negation of sift_test's, on the extremes)
+                maybe = rmax > -1.f && rmin < (float)SD && cmax > -1.f && cmin < (float)SD;
+            }
+            unsigned long long todo = __ballot(maybe);
+            // this wave's share of the surviving blocks: every WPK-th one, U at a time
+            int seen = 0;
+            while (todo) {
+                int blks[U];
+                int nu = 0;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    blks[u] = -1;
+                    while (todo && nu == u) {
+                        const int bit = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        if ((seen++ % WPK) == sub) {
+                            blks[u] = base + bit;
+                            nu++;
+                        }
+                    }
+                }
+                if (nu == 0) break;
             float rbin[U], cbin[U], dx[U], dy[U], w[U];
             bool ok[U];
-            int bi = blk / nb, bj = blk - bi * nb;
 #pragma unroll
             for (int u = 0; u < U; u++) {
+                const int bi = blks[u] >= 0 ? blks[u] / nb : 0, bj = blks[u] >= 0 ? blks[u] - bi * nb : 0;
                 const int i = -g.radius + 8 * bi + ly, j = -g.radius + 8 * bj + lx;
-                ok[u] = blk + u < nblk && i <= g.radius && j <= g.radius &&
+                ok[u] = blks[u] >= 0 && i <= g.radius && j <= g.radius &&
                         sift_test(rows, cols, g, i, j, rbin[u], cbin[u], w[u]);
                 const size_t off = ok[u] ? (size_t)(g.py + i) * gstride + (g.px + j) : 0;
                 dx[u] = gx[off];
                 dy[u] = -gy[off];  // SIFT's dy is "up minus down"
-                if (++bj == nb) {
-                    bj = 0;
-                    bi++;
-                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -308,6 +355,7 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
                 atomicAdd(&hist[idx + (SD + 3) * (SN + 2)], MICV_FX(v110));
                 atomicAdd(&hist[idx + (SD + 3) * (SN + 2) + 1], MICV_FX(v111));
 #undef MICV_FX
+            }
             }
         }
     }
