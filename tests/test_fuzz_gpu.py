@@ -325,3 +325,28 @@ def test_fuzz_rowshard_virtual_and_level_options(shape, seed, kind, win, levels,
         ctx.set_option(_capi.OPT_LK_BUILD_OVERLAP, carried)
         cu, cv = lk.calcOpticalFlowPyrBatch(dp, dn, win, levels, ctx=ctx)
         assert same(host(cu), host(ru)) and same(host(cv), host(rv)), (rows, cols, win, levels, batch, carried)
+
+
+@settings(max_examples=25 * SCALE, **COMMON)
+@given(st.tuples(st.integers(64, 420), st.integers(64, 560)), seed, kind, st.integers(2, 3), st.integers(1, 3), st.integers(1, 9),
+       st.integers(1, 3))
+def test_fuzz_split_and_strip_launches(shape, seed, kind, levels, batch, blocks, split):
+    """r05: the two other divisions of a level launch -- MICV_OPT_LK_SPLIT (pre-pass + streaming sums, three forms) and
+    MICV_OPT_LK_STRIP (the interior as streamed strips) -- on random even shapes, textures with NaN / inf / flat regions,
+    against the tile launch and the oracle.  Shapes without an interior tile fall back to the tile launch inside the call."""
+    from introtocomputervision_amd import lk, _capi
+    rows, cols = shape[0] & ~3, shape[1] & ~3   # (doubling coarse flow on the finest level; 16-byte rows)
+    prev = np.stack([image(seed + i, rows, cols, kind) for i in range(batch)])
+    nxt = np.stack([np.roll(p, (2, -1), (0, 1)) for p in prev])
+    ctx = _capi.Context(0)
+    dp, dn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
+    ru, rv = lk.calcOpticalFlowPyrBatch(dp, dn, 15, levels, ctx=ctx)
+    eu, ev = orc.lk_flow_pyr(prev[0], nxt[0], 15, levels)
+    assert same(host(ru[0]), eu) and same(host(rv[0]), ev)
+    ctx.set_option(_capi.OPT_LK_STRIP, blocks)
+    su, sv = lk.calcOpticalFlowPyrBatch(dp, dn, 15, levels, ctx=ctx)
+    assert same(host(su), host(ru)) and same(host(sv), host(rv)), ("strip", rows, cols, levels, batch, blocks)
+    ctx.set_option(_capi.OPT_LK_STRIP, 0)
+    ctx.set_option(_capi.OPT_LK_SPLIT, split)
+    pu, pv = lk.calcOpticalFlowPyrBatch(dp, dn, 15, levels, ctx=ctx)
+    assert same(host(pu), host(ru)) and same(host(pv), host(rv)), ("split", rows, cols, levels, batch, split)
