@@ -231,10 +231,14 @@ extern "C" int micv_generate_edge_dev(micv_ctx *ctx, const uint8_t *src, int row
     // memory the kernels write directly (no copy back); word kBatch is stored by a one-thread kernel behind the
     // batch, and the host polls it instead of paying a stream synchronisation.
     volatile int *flags = static_cast<volatile int *>(ctx->pinned);
-    const int max_rounds = (int)(tiles_x * cdiv(rows, 62)) + 2;  // a path crosses each tile at most once per round
+    // The loop ends when a round promotes nothing.  The cap is only a guard against a runaway: a chain of candidates may
+    // cross tile boundaries as often as it has pixels (a round carries it through ONE tile visit at least), so the cap is
+    // the pixel count -- r04's "tiles + 2" (one visit per tile) was too small for winding chains on dense candidate maps
+    // and left them unpromoted (found by the r05 fuzz soak: 70 x 107 noise, sigma 2.1, low threshold 0).
+    const long long max_rounds = (long long)rows * cols + 8;
     constexpr int kBatch = 3;
     const dim3 hgrid(tiles_x, cdiv(rows + 1, 62));
-    for (int round = 0; round < max_rounds; round += kBatch) {
+    for (long long round = 0; round < max_rounds; round += kBatch) {
         for (int b = 0; b <= kBatch; b++) flags[b] = 0;
         for (int b = 0; b < kBatch; b++) {
             canny_hyst_bits_kernel<<<hgrid, 64, 0, s>>>(weak, strong, rows, tiles_x, const_cast<int *>(flags) + b);

@@ -96,7 +96,7 @@ __device__ __forceinline__ void strip_pyrup(const float *Cf, int cx0, int cy0, i
 template <int R>
 __device__ __forceinline__ void strip_block_front(const LkLevelArgs &a, const TapsN<2 * R + 1> &g, float *lds,
                                                   const float *__restrict__ prev, const float *__restrict__ next, int pair,
-                                                  int x0, int y, int cbuf, bool stage_next, int tid) {
+                                                  int x0, int y, int cbuf, bool stage_next, bool do_move, int tid) {
     using C = StripCfg<R>;
     float *F0 = lds, *P = F0 + C::FIELD_F, *Wb = P + C::P_F, *X = Wb + C::W_F, *Cf0 = X + C::X_F;
     float *Nx = X, *Gb = X, *Cf = Cf0 + cbuf * C::CS_F;
@@ -106,7 +106,21 @@ __device__ __forceinline__ void strip_block_front(const LkLevelArgs &a, const Ta
         int nx0s = x0 - H - M, ny0s = y;
         asm("" : "+s"(nx0s), "+s"(ny0s));
         const int cx0 = (x0 - H) / 2 - 1, cy0 = y / 2 - 1;
-        for (int n = tid; n < RW * (B / MR); n += C::NT) {
+        // The march has jobs for five of the eight waves; the other three carry the previous block's last 2R row-pass rows
+        // of the five fields to the front of their buffers meanwhile (nobody reads rows 0 .. 2R - 1 before this block's
+        // column pass, nobody writes rows 2R .. before its row pass) -- the move is off the critical path and the
+        // barrier that used to precede it is gone.
+        constexpr int NJ = RW * (B / MR);
+        static_assert(NJ <= 5 * 64 && C::NT == 512, "march jobs on waves 0-4, the carry on waves 5-7");
+        if (do_move && tid >= 5 * 64) {
+            constexpr int MV4 = C::QC * C::RBS / 4, FS4 = C::GH * C::RBS / 4;
+            v4f *f4 = reinterpret_cast<v4f *>(F0);
+            for (int i = tid - 5 * 64; i < C::NF * MV4; i += C::NT - 5 * 64) {
+                const int f = i / MV4, k = i - f * MV4;
+                f4[f * FS4 + k] = f4[f * FS4 + B * C::RBS / 4 + k];
+            }
+        }
+        for (int n = tid; n < NJ; n += C::NT) {
             const int rg = n / RW, lx = n - rg * RW;
             const int gx = x0 - H + lx, gy0 = y + (R + 1) + MR * rg;
             v2f huv[MR], buv[MR];
@@ -220,16 +234,8 @@ __device__ __forceinline__ void lk_strip(const LkLevelArgs &a, const TapsN<2 * R
     strip_stage<C>(a, prev, next, pair, x0, s0 - B, P, X, Cf0, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    strip_block_front<R>(a, g, lds, prev, next, pair, x0, s0 - B, cbuf, true, tid);
-    {   // field rows B .. B + QC - 1 -> 0 .. QC - 1
-        constexpr int MV4 = C::QC * C::RBS / 4, FS4 = C::GH * C::RBS / 4;
-        v4f *f4 = reinterpret_cast<v4f *>(F0);
-        for (int i = tid; i < C::NF * MV4; i += C::NT) {
-            const int f = i / MV4, k = i - f * MV4;
-            f4[f * FS4 + k] = f4[f * FS4 + B * C::RBS / 4 + k];
-        }
-    }
-    cbuf ^= 1;
+    strip_block_front<R>(a, g, lds, prev, next, pair, x0, s0 - B, cbuf, true, false, tid);
+    cbuf ^= 1;  // (its field rows B .. B + QC - 1 move to the front during the first block's march)
 
     float ru[RPT], rv[RPT];
     int ry = -1;
@@ -247,7 +253,7 @@ __device__ __forceinline__ void lk_strip(const LkLevelArgs &a, const TapsN<2 * R
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's staging has landed (every wave's own part)
         __syncthreads();                                   // ... all of it; the carried rows are in place
         flush();  // the previous block's results drain under this block's arithmetic
-        strip_block_front<R>(a, g, lds, prev, next, pair, x0, y, cbuf, y + B < s1, tid);
+        strip_block_front<R>(a, g, lds, prev, next, pair, x0, y, cbuf, y + B < s1, true, tid);
         float S[C::NF][RPT];
         col_pass<C, 0>(cls, S[0], g);
         col_pass<C, 1>(cls, S[1], g);
@@ -258,15 +264,8 @@ __device__ __forceinline__ void lk_strip(const LkLevelArgs &a, const TapsN<2 * R
         // what the march computed for rows y + 8 .. would need 8 KB more LDS)
         v2f huv[RPT], buv[RPT];
         if (a.add_base) strip_pyrup<C, RPT>(Cf0 + cbuf * C::CS_F, (x0 - C::H) / 2 - 1, y / 2 - 1, gx, y + r0, huv, buv);
-        __syncthreads();  // every column pass has read its rows; every pyrUp its coarse block
-        if (y + B < s1) {
-            constexpr int MV4 = C::QC * C::RBS / 4, FS4 = C::GH * C::RBS / 4;
-            v4f *f4 = reinterpret_cast<v4f *>(F0);
-            for (int i = tid; i < C::NF * MV4; i += C::NT) {
-                const int f = i / MV4, k = i - f * MV4;
-                f4[f * FS4 + k] = f4[f * FS4 + B * C::RBS / 4 + k];
-            }
-        }
+        // (no barrier here: the next writer of the field buffers is the carry in the next block's march, behind the
+        // barrier at the loop's top; the coarse buffer this pyrUp read is restaged two row passes from now)
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
             float uu, vv;

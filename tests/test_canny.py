@@ -126,3 +126,23 @@ def test_hysteresis_borders_and_random_fields():
     for _ in range(3):
         got = hough.generateEdge(wide[:, 5:5 + cols], 5, 1.4, 20, 60)
         assert np.array_equal(got.cpu().numpy(), oracle_edges(noisy, 5, 1.4, 20, 60))
+
+
+@pytest.mark.gpu
+def test_hysteresis_rounds_are_not_capped_by_the_tile_count():
+    """Found by the r05 fuzz soak (random draws): 70 x 107 byte noise, Gaussian 31 / sigma 2.125, thresholds 0 / 102.  With a
+    low threshold of 0 every NMS maximum is a candidate and the chains wind across the 64 x 62 hysteresis tiles' boundaries
+    more often than there are tiles; r04 capped the rounds at "tiles + 2" and left 23 pixels unpromoted (every run: the r04
+    build fails this case 200 times of 200).  The loop now runs until a round promotes nothing."""
+    import ctypes as C
+    import torch
+    from introtocomputervision_amd import hough
+    rows, cols, seed, gs, sigma, lo, hi = 70, 107, 147, 31, 2.125, 0, 102
+    img = np.random.default_rng(seed).integers(0, 256, (rows, cols)).astype(np.uint8)
+    fn = orc._sig("orc_generate_edge", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_double, C.c_double,
+                                                 C.c_double, C.c_void_p, C.c_size_t])
+    exp = np.empty((rows, cols), np.uint8)
+    assert fn(img.ctypes.data, rows, cols, cols, gs, float(sigma), float(lo), float(hi), exp.ctypes.data, cols) == 0
+    got = hough.generateEdge(torch.from_numpy(img).cuda(), gs, float(sigma), lo, hi).cpu().numpy()
+    assert np.array_equal(got, exp), int((got != exp).sum())
+    assert (exp > 0).sum() > 300

@@ -350,3 +350,47 @@ def test_fuzz_split_and_strip_launches(shape, seed, kind, levels, batch, blocks,
     ctx.set_option(_capi.OPT_LK_SPLIT, split)
     pu, pv = lk.calcOpticalFlowPyrBatch(dp, dn, 15, levels, ctx=ctx)
     assert same(host(pu), host(ru)) and same(host(pv), host(rv)), ("split", rows, cols, levels, batch, split)
+
+
+@settings(max_examples=60 * SCALE, **COMMON)
+@given(shape, pad, seed, st.integers(0, 3), st.sampled_from([3, 5, 7, 9]), st.sampled_from([3, 3, 5]), st.integers(0, 8), st.booleans(),
+       st.floats(0.0, 1.0))
+def test_fuzz_harris_corners_chain(shape, pad, seed, kind, window, ksize, min_dist, cpu, thr_q):
+    """micv_harris_corners_dev (r05) against the three separate calls on random shapes / pitches / textures (incl. NaN and
+    inf), both arithmetics, thresholds from "everything" to "nothing": gradients, R, the sparse map and the list."""
+    from introtocomputervision_amd import harris
+    rows, cols = shape
+    img = image(seed, rows, cols, kind)
+    d = dev(img, pad)
+    gx, gy = harris.getGradients(d, ksize)
+    R = harris.getCornerResponse(gx, gy, window, 1.5, 0.04, cpu_arithmetic=cpu)
+    finite = host(R)[np.isfinite(host(R))]
+    thr = float(np.quantile(finite, thr_q)) if finite.size else 0.0
+    corners, locs = harris.refineCorners(R, thr, min_dist)
+    out = harris.cornersFromImage(d, ksize, window, 1.5, 0.04, thr, min_dist, cpu_arithmetic=cpu, want_response=True, want_corners=True)
+    assert same(host(out["gx"]), host(gx)) and same(host(out["gy"]), host(gy)), (rows, cols, pad, ksize)
+    assert same(host(out["response"]), host(R)), (rows, cols, pad, window, cpu)
+    assert same(host(out["corners"]), host(corners)) and np.array_equal(host(out["locs"]), host(locs)), (rows, cols, thr, min_dist)
+
+
+@settings(max_examples=60 * SCALE, **COMMON)
+@given(shape, pad, seed, st.sampled_from([1, 3, 5, 9, 31]), st.sampled_from([1, 3, 7]), st.floats(0.4, 8.0), st.integers(0, 60), st.integers(0, 2))
+def test_fuzz_mhi_frame_difference(shape, pad, seed, kw, kh, sigma, thr, kind):
+    """mhi::frameDifference on bit planes (r05) on random byte frames: dense, sparse and blocky masks, any blur size pair,
+    widths around the 64-column words, images smaller than the 7x7 element -- byte-exact against the oracle."""
+    from introtocomputervision_amd import mhi
+    rows, cols = shape
+    rng = np.random.default_rng(seed)
+    f1 = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+    if kind == 0:
+        f2 = rng.integers(0, 256, (rows, cols)).astype(np.uint8)
+    elif kind == 1:  # sparse motion
+        f2 = f1.copy()
+        m = rng.random((rows, cols)) < 0.08
+        f2[m] = np.clip(f2[m].astype(np.int32) + 90, 0, 255).astype(np.uint8)
+    else:  # a moving block
+        f2 = f1.copy()
+        f2[rows // 4: rows // 4 + max(1, rows // 3), cols // 5: cols // 5 + max(1, cols // 2)] = 255
+    exp = orc.mhi_frame_difference(f1, f2, thr, (kw, kh), sigma)
+    got = mhi.frameDifference(dev(f1, pad), dev(f2, pad), thr, (kw, kh), sigma)
+    assert same(host(got), exp), (rows, cols, pad, kw, kh, thr, kind)
