@@ -394,3 +394,29 @@ def test_fuzz_mhi_frame_difference(shape, pad, seed, kw, kh, sigma, thr, kind):
     exp = orc.mhi_frame_difference(f1, f2, thr, (kw, kh), sigma)
     got = mhi.frameDifference(dev(f1, pad), dev(f2, pad), thr, (kw, kh), sigma)
     assert same(host(got), exp), (rows, cols, pad, kw, kh, thr, kind)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(st.tuples(st.integers(33, 560), st.integers(33, 700)), seed, kind, st.sampled_from([7, 11, 15, 15, 21]), st.integers(1, 4), st.integers(1, 9),
+       st.lists(st.tuples(st.sampled_from(["OPT_LK_STREAM_GROUPS", "OPT_LK_NARROW_TILES", "OPT_LK_CHAIN", "OPT_LK_SHORT_TILES", "OPT_LK_STREAM",
+                                            "OPT_LK_TALL_TILES", "OPT_LK_DIRECT_LEVELS", "OPT_LK_BUILD_OVERLAP", "OPT_LK_SPLIT", "OPT_LK_STRIP",
+                                            "OPT_LK_FORCE_GENERIC"]), st.integers(0, 5)), min_size=1, max_size=4))
+def test_fuzz_lk_option_combinations(shape, seed, kind, win, levels, batch, opts):
+    """"None of these changes a result" (mi_cv.h) for COMBINATIONS of the execution options on random shapes and batches:
+    the deterministic tests take the options one at a time."""
+    from introtocomputervision_amd import lk, _capi
+    rows, cols = shape
+    levels = max(1, min(levels, int(np.log2(max(1, min(rows, cols)))) - 1))
+    legal = {"OPT_LK_STREAM_GROUPS": [0, 1, 2, 3, 4, 2], "OPT_LK_NARROW_TILES": [0, 1, 1, 0, 1, 0], "OPT_LK_CHAIN": [0, 1, 2, 4, -1, 32],
+             "OPT_LK_SHORT_TILES": [0, -1, 64, 2000, 100000, 0], "OPT_LK_STREAM": [0, 1, 1, 0, 1, 0], "OPT_LK_TALL_TILES": [0, 1, 2, 3, -1, 1],
+             "OPT_LK_DIRECT_LEVELS": [0, 1, 2, 3, 1, 0], "OPT_LK_BUILD_OVERLAP": [0, 1, -1, 1, -1, 0], "OPT_LK_SPLIT": [0, 1, 2, 3, 1, 2],
+             "OPT_LK_STRIP": [0, 1, 3, 16, 8195, 2], "OPT_LK_FORCE_GENERIC": [0, 1, 2, 3, 0, 0]}
+    prev = np.stack([image(seed + i, rows, cols, kind) for i in range(batch)])
+    nxt = np.stack([np.roll(p, (1, -2), (0, 1)) for p in prev])
+    dp, dn = torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda()
+    ru, rv = lk.calcOpticalFlowPyrBatch(dp, dn, win, levels, ctx=_capi.Context(0))
+    ctx = _capi.Context(0)
+    for name, i in opts:
+        ctx.set_option(getattr(_capi, name), legal[name][i])
+    ou, ov = lk.calcOpticalFlowPyrBatch(dp, dn, win, levels, ctx=ctx)
+    assert same(host(ou), host(ru)) and same(host(ov), host(rv)), (rows, cols, win, levels, batch, [(n, legal[n][i]) for n, i in opts])
