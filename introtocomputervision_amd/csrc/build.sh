@@ -29,3 +29,17 @@ done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
 echo "built $out"
+# MICV_AUDIT=1: after building, run the ISA audit of the hand-placed LDS loads (tools/audit_asm_loads.py: every load has
+# its wait before its first use; no compiler-placed LDS / scalar-memory operation inside a COUNTED wait's window).  When
+# it fails -- a compiler upgrade that reloads taps inside a counted window would give wrong window sums, not a build
+# error -- the two files that use counted waits are rebuilt with the single-wait column pass (-DMICV_LK_COL_FULLWAIT,
+# ~1 % slower) and audited again.  (The CPU test suite runs the same audit; this is for builds that ship without it.)
+if [[ -n "${MICV_AUDIT:-}" && -z "${MICV_AUDIT_DONE:-}" ]]; then
+  audit="$here/../../tools/audit_asm_loads.py"
+  if ! python3 "$audit" ${EXTRA_HIPCC_FLAGS:-}; then
+    echo "audit failed: rebuilding lk_fused / lk_split with -DMICV_LK_COL_FULLWAIT"
+    rm -f "$obj/lk_fused.o" "$obj/lk_split.o"
+    MICV_AUDIT_DONE=1 EXTRA_HIPCC_FLAGS="${EXTRA_HIPCC_FLAGS:-} -DMICV_LK_COL_FULLWAIT" bash "$here/build.sh"
+    python3 "$audit" ${EXTRA_HIPCC_FLAGS:-} -DMICV_LK_COL_FULLWAIT
+  fi
+fi
