@@ -424,3 +424,36 @@ def test_fuzz_lk_option_combinations(shape, seed, kind, win, levels, batch, opts
         ctx.set_option(getattr(_capi, name), legal[name][i])
     ou, ov = lk.calcOpticalFlowPyrBatch(dp, dn, win, levels, ctx=ctx)
     assert same(host(ou), host(ru)) and same(host(ov), host(rv)), (rows, cols, win, levels, batch, [(n, legal[n][i]) for n, i in opts])
+
+
+@settings(max_examples=60 * SCALE, **COMMON)
+@given(st.integers(1, 700), st.integers(2, 1500), st.integers(1, 160), seed, st.integers(0, 2), st.floats(0.3, 1.0))  # (k = 2 needs two train rows: the C ABI says so)
+def test_fuzz_bf_knn2_and_ratio(nq, nt, dim, seed, kind, ratio):
+    """BFMatcher knn2 + ratio test (match.hip; its chunk staging is prefetched since r05) on random set sizes and
+    dimensions around the 64 x 128 x 32 tile, with duplicated train rows (ties: the lower index wins) and clustered
+    descriptors (near-ties): indices and distances bit-exact against the oracle."""
+    import ctypes as C
+    from introtocomputervision_amd import match
+    vp, i32, i64, sz, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_double
+    knn = orc._sig("orc_bf_knn2", None, [vp, i32, sz, vp, i32, sz, i32, vp, vp])
+    ratf = orc._sig("orc_bf_ratio_filter", i64, [vp, vp, i32, f64, vp, vp, i64])
+    rng = np.random.default_rng(seed)
+    if kind == 0:
+        t = rng.integers(0, 256, (nt, dim)).astype(np.float32)
+    elif kind == 1:  # clustered: many near-ties
+        t = (rng.integers(0, 4, (nt, dim)) * 64).astype(np.float32) + rng.integers(0, 2, (nt, dim)).astype(np.float32)
+    else:
+        t = rng.standard_normal((nt, dim)).astype(np.float32) * 100
+    if nt > 3:
+        t[nt // 2] = t[0]  # exact duplicate rows
+    q = (t[rng.integers(0, nt, nq)] + (rng.integers(-3, 4, (nq, dim)).astype(np.float32) if kind < 2 else 0)).astype(np.float32)
+    q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+    eidx = np.empty((nq, 2), np.int32); edist = np.empty((nq, 2), np.float32)
+    knn(q.ctypes.data, nq, dim, t.ctypes.data, nt, dim, dim, eidx.ctypes.data, edist.ctypes.data)
+    idx, dist = match.knnMatch2(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+    assert np.array_equal(host(idx), eidx), (nq, nt, dim, kind)
+    assert same(host(dist), edist), (nq, nt, dim, kind)
+    em = np.empty((nq, 2), np.int32); ed = np.empty(nq, np.float32)
+    n = ratf(eidx.ctypes.data, edist.ctypes.data, nq, float(ratio), em.ctypes.data, ed.ctypes.data, nq)
+    m, d = match.ratioTest(idx, dist, float(ratio))
+    assert np.array_equal(host(m), em[:n]) and same(host(d), ed[:n]), (nq, nt, dim, ratio)
