@@ -457,3 +457,86 @@ def test_fuzz_bf_knn2_and_ratio(nq, nt, dim, seed, kind, ratio):
     n = ratf(eidx.ctypes.data, edist.ctypes.data, nq, float(ratio), em.ctypes.data, ed.ctypes.data, nq)
     m, d = match.ratioTest(idx, dist, float(ratio))
     assert np.array_equal(host(m), em[:n]) and same(host(d), ed[:n]), (nq, nt, dim, ratio)
+
+
+@settings(max_examples=60 * SCALE, **COMMON)
+@given(shape, seed, st.sampled_from([1, 3, 4]), st.booleans(), st.integers(1, 5))
+def test_fuzz_to_gray_and_laplacian_pyramid(shape, seed, cn, as_float, levels):
+    """Pyramids.cpp:9-15 (colour branch) and Solution.cpp:187-200 (Laplacian levels) on random shapes,
+    channel counts and element types; the host and the device entry point of toGray both."""
+    from introtocomputervision_amd import pyr
+    rows, cols = shape
+    rng = np.random.default_rng(seed)
+    full = (rows, cols) if cn == 1 else (rows, cols, cn)
+    img = rng.integers(0, 256, full, dtype=np.uint8)
+    if as_float:
+        img = (img.astype(np.float32) * np.float32(1.0 / 3) - np.float32(20)).astype(np.float32)
+    want = orc.to_gray(img)
+    assert same(pyr.toGray(img), want)
+    grey = pyr.toGray(torch.from_numpy(img).cuda())
+    assert same(host(grey), want)
+    if cn == 3 and not as_float:
+        assert same(host(pyr.rgb8ToGray(torch.from_numpy(img).cuda())), orc.rgb8_to_gray(img))
+    levels = max(1, min(levels, int(np.log2(min(rows, cols))) + 1))
+    g = orc.gaussian_pyramid(want, levels)
+    for l, lap in enumerate(pyr.makeLaplacianPyramid(grey, levels)):
+        e = g[l]
+        if l < levels - 1:
+            up = orc.pyr_up(g[l + 1])
+            if up.shape[0] < e.shape[0] or up.shape[1] < e.shape[1]:  # odd sizes: Solution.cpp:194-196
+                up = orc.resize_linear(up, *e.shape)
+            e = e - up
+        assert same(host(lap), e)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(st.tuples(st.integers(16, 130), st.integers(8, 200)), seed, st.integers(1, 8), st.integers(0, 7), st.integers(-30, 5),
+       st.integers(0, 30), st.sampled_from([3, 5]), st.sampled_from([3, 5, 7]), st.integers(0, 6), st.floats(0.0, 0.15))
+def test_fuzz_virtual_shards_of_stereo_harris_hough(shape, seed, world, rad, min_d, span, ksize, window, min_dist, density):
+    """Row shards (band + static halo) of stereo, the Harris chain and the Hough vote on one GPU, as 1..8
+    virtual ranks, against the unsharded device call; ragged cuts and bands thinner than the halo included."""
+    from introtocomputervision_amd import harris, hough, shard_ops as so, stereo, synth
+    from introtocomputervision_amd._capi import Context
+    rows, cols = shape
+    world = min(world, rows)
+    ctx = Context(0)
+    fns = so.gpu_fns(ctx)
+    rng = np.random.default_rng(seed)
+    left, right, _ = synth.stereo_pair(seed % 1000, rows, cols)
+    dl, dr = dev(left), dev(right)
+    max_d = min_d + span
+    for fn, whole in ((fns.ssd(rad, min_d, max_d), stereo.disparitySSD(dl, dr, rad, min_d, max_d, ctx=ctx)),
+                      (fns.ncorr(rad, min_d, max_d), stereo.disparityNCorr(dl, dr, rad, min_d, max_d, ctx=ctx))):
+        parts = []
+        for g in range(world):
+            band, held = so.band_with_halo(rows, world, g, rad)
+            parts.append(so.stereo_sharded(dl[held[0]:held[1]], dr[held[0]:held[1]], band, held, fn))
+        assert torch.equal(torch.cat(parts), whole)
+
+    img = image(seed, rows, cols, 1)
+    di = dev(img)
+    gx, gy = harris.getGradients(di, ksize, ctx=ctx)
+    resp = harris.getCornerResponse(gx, gy, window, 1.5, 0.04, ctx=ctx)
+    thr = float(np.quantile(host(resp), 0.9))
+    corners, locs = harris.refineCorners(resp, thr, min_dist, ctx=ctx)
+    halo = so.harris_halo(ksize, window, min_dist)
+    rs, cs, ls = [], [], []
+    for g in range(world):
+        band, held = so.band_with_halo(rows, world, g, halo)
+        r, c, l = so.harris_sharded(di[held[0]:held[1]], band, held, ksize, window, 1.5, 0.04, thr, min_dist,
+                                    fns.grad, fns.response, fns.refine, so.LocalComm())
+        rs.append(r), cs.append(c), ls.append(l)
+    assert same(host(torch.cat(rs)), host(resp))
+    assert torch.equal(torch.cat(cs), corners)
+    assert torch.equal(torch.cat(ls), locs)
+
+    mask = dev((rng.random((rows, cols)) < density).astype(np.uint8) * 255)
+    whole = hough.houghLinesAccumulate(mask, 1, 1, ctx=ctx)
+    radius = int(rng.integers(1, 12))
+    whole_c = hough.houghCirclesAccumulate(mask, radius, ctx=ctx)
+    total, total_c = torch.zeros_like(whole), torch.zeros_like(whole_c)
+    for g in range(world):
+        (a, b), _ = so.band_with_halo(rows, world, g, 0)
+        total += so.hough_lines_sharded(mask[a:b], (a, b), rows, 1, 1, fns.hough_lines_band, so.LocalComm())
+        total_c += so.hough_circles_sharded(mask[a:b], (a, b), rows, radius, fns.hough_circles_band, so.LocalComm())
+    assert torch.equal(total, whole) and torch.equal(total_c, whole_c)
