@@ -24,14 +24,16 @@
 namespace micv {
 
 constexpr int SD = 4, SN = 8;
-constexpr int SHIST = (SD + 2) * (SD + 2) * (SN + 2);
-// Private copies of the histogram per wave, picked by the lane's column within its 8x8 block: lanes
+// The wave's histogram holds the 4 x 4 cells the descriptor keeps, nine orientation slots each (slot 8 = the upper
+// share of bin 7, folded onto bin 0 at the end): shares that fall on the ring of cells around the 4 x 4 grid are dropped
+// by the published algorithm when it copies the histogram out, so they are not added in the first place (36 % of all
+// shares), and a copy is 1 152 bytes instead of the 2 880 of the full 6 x 6 x 10 array.
+constexpr int SHIST = SD * SD * (SN + 1);
+// Private copies of the histogram per wave, picked by the lane's position within its 4x4 block: lanes
 // that hit the same bin in the same instruction serialise in the LDS atomic unit (flat regions and
-// straight edges send a whole block to one bin), and COPIES copies divide that by COPIES.  Measured on
-// 5 035 keypoints of a 4K checkerboard: 1 copy 0.342 ms, 2 copies 0.294 ms, 4 copies 0.374 ms (LDS
-// then limits the waves per CU below what the keypoint list offers).
+// straight edges send a whole block to one bin), and COPIES copies divide that by COPIES.
 #ifndef MICV_SIFT_COPIES
-#define MICV_SIFT_COPIES 2
+#define MICV_SIFT_COPIES 4
 #endif
 constexpr int COPIES = MICV_SIFT_COPIES;
 
@@ -171,14 +173,16 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
     constexpr int G = 4 / WPK;  // keypoints per workgroup
     constexpr int LEN = SD * SD * SN;
     __shared__ unsigned long long hist_all[4][COPIES * SHIST];
-    __shared__ float dst_all[G][LEN];
+    // per wave: the queue of sweep 2; after it (and a keypoint_sync) the first G of these are the keypoints' float rows
+    __shared__ unsigned scratch_all[4][LEN];
     __shared__ float bound_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = wave / WPK, sub = wave - grp * WPK;
     const long long k = (long long)blockIdx.x * G + grp;
     if (k >= n) return;  // WPK 1: whole waves leave, no workgroup barrier below; WPK 4: never taken
     unsigned long long *hist = hist_all[wave];
-    float *dst = dst_all[grp];
+    float *dst = reinterpret_cast<float *>(scratch_all[grp]);
+    unsigned *queue = scratch_all[wave];
     float *out = desc + (size_t)k * dstride;
     const SiftGeom g = sift_geometry(kps + 4 * k, rows, cols);
     for (int t = lane; t < COPIES * SHIST; t += 64) hist[t] = 0ull;
@@ -237,69 +241,70 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
     // sweep 2: eight trilinear shares per sample, fixed-point adds into the wave's histogram
     // (the wave's zero fill of its own copies is ordered before its own atomics: same wave, in order)
     // A lone wave is bound by the latency of its gradient loads (one dependent L2 / HBM round trip per
-    // sample would cost ~1 us each), so the samples go four at a time: the geometry tests and the
+    // sample would cost ~1 us each), so the samples go four passes at a time: the geometry tests and the
     // eight unconditional loads of a batch first (rejected samples read element 0), the arithmetic
     // and the LDS atomics after them.
-    // The wave visits the bounding square in 8x8-pixel blocks (the sums are order-independent): about
-    // half of the square lies outside the rotated window, and a block that is outside altogether is
-    // skipped by the whole wave (row-major runs of 64 almost always keep a few live lanes).
+    // The wave visits the bounding square in 4x4-pixel blocks, four blocks per pass (the sums are
+    // order-independent): about half of the square lies outside the rotated window, and only blocks that can hold an
+    // accepted sample are visited at all.
     {
         constexpr int U = 4;
-        const int nb = (side + 7) >> 3;
-        const int nblk = g.valid ? nb * nb : 0;
-        const int ly = lane >> 3, lx = lane & 7;
-        // Blocks that cannot hold an accepted sample are dropped BEFORE their 64 per-sample tests (r05): rbin and cbin are
+        constexpr int CAND = 128;  // candidate blocks per round, two per lane; the survivors' (bi, bj) queue in LDS
+        const unsigned nb = (unsigned)(side + 3) >> 2;
+        const unsigned nblk = g.valid ? nb * nb : 0u;  // (nb <= 46 341 for the 65 535-pixel sides the entry point admits)
+        const int ly = (lane >> 2) & 3, lx = lane & 3, quarter = lane >> 4;
+        // Blocks that cannot hold an accepted sample are dropped BEFORE their per-sample tests (r05): rbin and cbin are
         // monotone in i and in j separately (a float product of a fixed factor is monotone, so is a float sum in each
         // operand), so over a block they lie between their values at the block's four corners; if that range misses
-        // (-1, SD) for either coordinate no sample of the block passes sift_test.  One lane = one block here: 64 blocks
-        // per pass, the survivors as a bit mask the wave then walks.  Exact, not a heuristic: nothing that contributes is
-        // skipped (about 30 % of the blocks of a size-10 window go).
-        for (int base = 0; base < nblk; base += 64) {
-            const int blk_l = base + lane;
-            bool maybe = false;
-            if (blk_l < nblk) {
-                const int bi_l = blk_l / nb, bj_l = blk_l - bi_l * nb;
-                const int i0 = -g.radius + 8 * bi_l, j0 = -g.radius + 8 * bj_l;
-                const int i1 = i0 + 7 < g.radius ? i0 + 7 : g.radius, j1 = j0 + 7 < g.radius ? j0 + 7 : g.radius;
-                float rmin = INFINITY, rmax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
+        // (-1, SD) for either coordinate no sample of the block passes sift_test.  One lane = one candidate block.
+        // Exact, not a heuristic: nothing that contributes is skipped.  With 4x4 blocks 86 % of the visited lanes hold an
+        // accepted sample of a size-10 window (8x8 blocks, one per pass: 63 %).
+        for (unsigned base = 0; base < nblk; base += CAND) {
+            int count = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int i = (k & 2) ? i1 : i0, j = (k & 1) ? j1 : j0;
-                    const float c_rot = (float)j * g.cos_t - (float)i * g.sin_t;  // sift_test's own expressions
-                    const float r_rot = (float)j * g.sin_t + (float)i * g.cos_t;
-                    const float rb = r_rot + (float)(SD / 2) - 0.5f, cb = c_rot + (float)(SD / 2) - 0.5f;
-                    rmin = fminf(rmin, rb); rmax = fmaxf(rmax, rb);
-                    cmin = fminf(cmin, cb); cmax = fmaxf(cmax, cb);
-                }
-                // (NaN geometry cannot occur: g.valid; the comparisons are the negation of sift_test's, on the extremes)
-                maybe = rmax > -1.f && rmin < (float)SD && cmax > -1.f && cmin < (float)SD;
-            }
-            unsigned long long todo = __ballot(maybe);
-            // this wave's share of the surviving blocks: every WPK-th one, U at a time
-            int seen = 0;
-            while (todo) {
-                int blks[U];
-                int nu = 0;
+            for (int q = 0; q < CAND / 64; q++) {
+                const unsigned cand = base + q * 64 + lane;
+                bool maybe = false;
+                unsigned packed = 0;
+                if (cand < nblk) {
+                    const unsigned bi_l = cand / nb, bj_l = cand - bi_l * nb;
+                    const int i0 = -g.radius + 4 * (int)bi_l, j0 = -g.radius + 4 * (int)bj_l;
+                    const int i1 = i0 + 3 < g.radius ? i0 + 3 : g.radius, j1 = j0 + 3 < g.radius ? j0 + 3 : g.radius;
+                    float rmin = INFINITY, rmax = -INFINITY, cmin = INFINITY, cmax = -INFINITY;
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    blks[u] = -1;
-                    while (todo && nu == u) {
-                        const int bit = __builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        if ((seen++ % WPK) == sub) {
-                            blks[u] = base + bit;
-                            nu++;
-                        }
+                    for (int k = 0; k < 4; k++) {
+                        const int i = (k & 2) ? i1 : i0, j = (k & 1) ? j1 : j0;
+                        const float c_rot = (float)j * g.cos_t - (float)i * g.sin_t;  // sift_test's own expressions
+                        const float r_rot = (float)j * g.sin_t + (float)i * g.cos_t;
+                        const float rb = r_rot + (float)(SD / 2) - 0.5f, cb = c_rot + (float)(SD / 2) - 0.5f;
+                        rmin = fminf(rmin, rb); rmax = fmaxf(rmax, rb);
+                        cmin = fminf(cmin, cb); cmax = fmaxf(cmax, cb);
                     }
+                    // (NaN geometry cannot occur: g.valid; the comparisons are the negation of sift_test's, on the extremes)
+                    maybe = rmax > -1.f && rmin < (float)SD && cmax > -1.f && cmin < (float)SD;
+                    packed = bi_l << 16 | bj_l;
                 }
-                if (nu == 0) break;
+                const unsigned long long m = __ballot(maybe);
+                if (maybe)
+                    queue[count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = packed;
+                count += __popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's own queue writes before its reads
+            __builtin_amdgcn_wave_barrier();
+            // this wave's share of the passes (four queued blocks each): every WPK-th one, U at a time
+            const int npass = (count + 3) >> 2;
+            for (int p0 = sub; p0 < npass; p0 += U * WPK) {
             float rbin[U], cbin[U], dx[U], dy[U], w[U];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int bi = blks[u] >= 0 ? blks[u] / nb : 0, bj = blks[u] >= 0 ? blks[u] - bi * nb : 0;
-                const int i = -g.radius + 8 * bi + ly, j = -g.radius + 8 * bj + lx;
-                ok[u] = blks[u] >= 0 && i <= g.radius && j <= g.radius &&
+                ok[u] = false;
+                const int pp = p0 + u * WPK;
+                if (pp >= npass) continue;  // the same in every lane
+                const int slot = 4 * pp + quarter;
+                const unsigned packed = queue[slot < count ? slot : 0];
+                const int i = -g.radius + 4 * (int)(packed >> 16) + ly, j = -g.radius + 4 * (int)(packed & 0xffffu) + lx;
+                ok[u] = slot < count && i <= g.radius && j <= g.radius &&
                         sift_test(rows, cols, g, i, j, rbin[u], cbin[u], w[u]);
                 const size_t off = ok[u] ? (size_t)(g.py + i) * gstride + (g.px + j) : 0;
                 dx[u] = gx[off];
@@ -330,33 +335,31 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
                 // the histogram; what they add is llrintf(NaN) as the host's cvtss2si returns it, INT64_MIN, for
                 // each of the eight shares (every share of a NaN magnitude is NaN)
                 o0 = o0 < 0 ? 0 : (o0 > SN - 1 ? SN - 1 : o0);
-                const int idx = ((r0 + 1) * (SD + 2) + c0 + 1) * (SN + 2) + o0 + (lane & (COPIES - 1)) * SHIST;
+                // r0, c0 in [-1, SD - 1]: the shares on row r0 (column c0) belong to the grid when r0 (c0) >= 0, those on
+                // row r0 + 1 (column c0 + 1) when it is <= SD - 1
+                const bool r_lo = r0 >= 0, r_hi = r0 < SD - 1, c_lo = c0 >= 0, c_hi = c0 < SD - 1;
+                const int idx = (r0 * SD + c0) * (SN + 1) + o0 + (lane & (COPIES - 1)) * SHIST;
+                constexpr int DC = SN + 1, DR = SD * (SN + 1);
                 if (mag != mag) {
                     const unsigned long long ind = 0x8000000000000000ull;
-                    atomicAdd(&hist[idx], ind);
-                    atomicAdd(&hist[idx + 1], ind);
-                    atomicAdd(&hist[idx + (SN + 2)], ind);
-                    atomicAdd(&hist[idx + (SN + 3)], ind);
-                    atomicAdd(&hist[idx + (SD + 2) * (SN + 2)], ind);
-                    atomicAdd(&hist[idx + (SD + 2) * (SN + 2) + 1], ind);
-                    atomicAdd(&hist[idx + (SD + 3) * (SN + 2)], ind);
-                    atomicAdd(&hist[idx + (SD + 3) * (SN + 2) + 1], ind);
+                    if (r_lo && c_lo) { atomicAdd(&hist[idx], ind); atomicAdd(&hist[idx + 1], ind); }
+                    if (r_lo && c_hi) { atomicAdd(&hist[idx + DC], ind); atomicAdd(&hist[idx + DC + 1], ind); }
+                    if (r_hi && c_lo) { atomicAdd(&hist[idx + DR], ind); atomicAdd(&hist[idx + DR + 1], ind); }
+                    if (r_hi && c_hi) { atomicAdd(&hist[idx + DR + DC], ind); atomicAdd(&hist[idx + DR + DC + 1], ind); }
                     continue;
                 }
                 // llrintf(ldexpf(v, sh)) for 0 <= v * 2^sh < 2^41: one double fma onto 2^52 rounds to the
                 // nearest-even integer and leaves it in the low mantissa bits
 #define MICV_FX(v) ((unsigned long long)__double_as_longlong(fma((double)(v), fx_scale, 4503599627370496.0)) & 0x000FFFFFFFFFFFFFull)
-                atomicAdd(&hist[idx], MICV_FX(v000));
-                atomicAdd(&hist[idx + 1], MICV_FX(v001));
-                atomicAdd(&hist[idx + (SN + 2)], MICV_FX(v010));
-                atomicAdd(&hist[idx + (SN + 3)], MICV_FX(v011));
-                atomicAdd(&hist[idx + (SD + 2) * (SN + 2)], MICV_FX(v100));
-                atomicAdd(&hist[idx + (SD + 2) * (SN + 2) + 1], MICV_FX(v101));
-                atomicAdd(&hist[idx + (SD + 3) * (SN + 2)], MICV_FX(v110));
-                atomicAdd(&hist[idx + (SD + 3) * (SN + 2) + 1], MICV_FX(v111));
+                if (r_lo && c_lo) { atomicAdd(&hist[idx], MICV_FX(v000)); atomicAdd(&hist[idx + 1], MICV_FX(v001)); }
+                if (r_lo && c_hi) { atomicAdd(&hist[idx + DC], MICV_FX(v010)); atomicAdd(&hist[idx + DC + 1], MICV_FX(v011)); }
+                if (r_hi && c_lo) { atomicAdd(&hist[idx + DR], MICV_FX(v100)); atomicAdd(&hist[idx + DR + 1], MICV_FX(v101)); }
+                if (r_hi && c_hi) { atomicAdd(&hist[idx + DR + DC], MICV_FX(v110)); atomicAdd(&hist[idx + DR + DC + 1], MICV_FX(v111)); }
 #undef MICV_FX
             }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // queue reads before the next round's writes
+            __builtin_amdgcn_wave_barrier();
         }
     }
     keypoint_sync<WPK>();
@@ -366,12 +369,12 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
     for (int t = 64 * sub + lane; t < LEN; t += 64 * WPK) {
         const int cell = t / SN, o = t - cell * SN;
         const int ci = cell / SD, cj = cell - ci * SD;
-        const int idx = ((ci + 1) * (SD + 2) + (cj + 1)) * (SN + 2);
+        const int idx = (ci * SD + cj) * (SN + 1);
         long long h = 0;
 #pragma unroll
         for (int cp = 0; cp < COPIES * WPK; cp++) {
             h += (long long)hist0[cp * SHIST + idx + o];
-            if (o < 2) h += (long long)hist0[cp * SHIST + idx + SN + o];
+            if (o == 0) h += (long long)hist0[cp * SHIST + idx + SN];  // the orientation axis is circular
         }
         dst[t] = ldexpf((float)h, e - 40);
     }
@@ -409,6 +412,7 @@ extern "C" int micv_sift_descriptors_dev(micv_ctx *ctx, const float *gx, const f
     MICV_REQUIRE(dstride % 4 == 0 && dstride >= 128 * 4 && dstride / 4 < ((size_t)1 << 30),
                  "micv_sift_descriptors: descriptor rows are 128 floats");
     MICV_REQUIRE(n < ((int64_t)1 << 31) * 4, "micv_sift_descriptors: too many keypoints");
+    MICV_REQUIRE(rows <= 65535 && cols <= 65535, "micv_sift_descriptors: images up to 65 535 pixels on a side");
     MICV_HIP(hipSetDevice(ctx->device));
     if (n == 0) return MICV_OK;
     // fewer keypoints than two waves per SIMD: spend four waves on each
