@@ -90,16 +90,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float p1 = 0.9997878412794807f * 57.29577951308232f, p3 = -0.3258083974640975f * 57.29577951308232f,
                 p5 = 0.1555786518463281f * 57.29577951308232f, p7 = -0.04432655554792128f * 57.29577951308232f;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // one quotient for both octants (the operands are selected, not the results: a divergent branch would run the IEEE
+    // division and the polynomial twice per wave) -- the same operations on the same values as the two-branch form
+    const bool flat = ax >= ay;
+    const float c = (flat ? ay : ax) / ((flat ? ax : ay) + (float)DBL_EPSILON);
+    const float c2 = c * c;
+    const float p = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = flat ? p : 90.f - p;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
@@ -308,13 +305,14 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
                         sift_test(rows, cols, g, i, j, rbin[u], cbin[u], w[u]);
                 const size_t off = ok[u] ? (size_t)(g.py + i) * gstride + (g.px + j) : 0;
                 dx[u] = gx[off];
-                dy[u] = -gy[off];  // SIFT's dy is "up minus down"
+                dy[u] = gy[off];  // (negated below: a negation here would wait for the load inside the batch)
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (!ok[u]) continue;
-                const float mag = sqrtf(dx[u] * dx[u] + dy[u] * dy[u]) * exp_neg(w[u]);
-                float obin = (fast_atan2_deg(dy[u], dx[u]) - g.ori) * ((float)SN / 360.f);
+                const float dyu = -dy[u];  // SIFT's dy is "up minus down"
+                const float mag = sqrtf(dx[u] * dx[u] + dyu * dyu) * exp_neg(w[u]);
+                float obin = (fast_atan2_deg(dyu, dx[u]) - g.ori) * ((float)SN / 360.f);
                 float rb = rbin[u], cb = cbin[u];
                 const float r0f = floorf(rb), c0f = floorf(cb), o0f = floorf(obin);
                 rb -= r0f;
