@@ -158,7 +158,7 @@ __device__ __forceinline__ void keypoint_sync() {
 }
 
 // WPK waves per keypoint: 1 when there are enough keypoints to fill the chip (4 keypoints per
-// workgroup), 4 when there are few (one keypoint per workgroup, the window's blocks dealt round-robin
+// workgroup), 2 in between, 4 when there are few (one keypoint per workgroup, the window's passes dealt round-robin
 // to the waves, each wave adding into its own histogram copies) -- a lone wave takes ~0.13 ms for a
 // 107x107 window, which is all the latency a small keypoint list would ever see.
 template <int WPK>
@@ -175,8 +175,12 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
     __shared__ float bound_all[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = wave / WPK, sub = wave - grp * WPK;
-    const long long k = (long long)blockIdx.x * G + grp;
-    if (k >= n) return;  // WPK 1: whole waves leave, no workgroup barrier below; WPK 4: never taken
+    long long k = (long long)blockIdx.x * G + grp;
+    if constexpr (WPK == 1) {
+        if (k >= n) return;  // whole waves leave, there is no workgroup barrier below
+    } else {
+        k = k < n ? k : n - 1;  // WPK 2, odd n: the last workgroup's second pair of waves repeats the last keypoint (same bytes)
+    }
     unsigned long long *hist = hist_all[wave];
     float *dst = reinterpret_cast<float *>(scratch_all[grp]);
     unsigned *queue = scratch_all[wave];
@@ -222,16 +226,19 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
         bound_all[wave] = bound;
         __syncthreads();
 #pragma unroll
-        for (int w2 = 0; w2 < WPK; w2++) bound = bound_all[w2] > bound ? bound_all[w2] : bound;
+        for (int w2 = 0; w2 < WPK; w2++) bound = bound_all[grp * WPK + w2] > bound ? bound_all[grp * WPK + w2] : bound;
     }
     bound = bound * 2.f;
     __builtin_amdgcn_wave_barrier();
-    if (!(bound > 0.f) || !isfinite(bound)) {  // flat (or empty, or invalid) window: all-zero descriptor
+    // flat (or empty, or invalid) window: all-zero descriptor -- the same decision in every wave of the keypoint; the
+    // keypoint's waves still meet the other keypoint's at the workgroup barriers below when WPK > 1
+    const bool flat = !(bound > 0.f) || !isfinite(bound);
+    if (flat) {
         for (int t = 64 * sub + lane; t < LEN; t += 64 * WPK) out[t] = 0.f;
-        return;  // the same decision in every wave of the keypoint
+        if constexpr (WPK == 1) return;
     }
-    int e;
-    (void)frexpf(bound, &e);  // bound < 2^e
+    int e = 0;
+    if (!flat) (void)frexpf(bound, &e);  // bound < 2^e
     const int sh = 40 - e;
     const double fx_scale = ldexp(1.0, sh);
 
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
         constexpr int U = 4;
         constexpr int CAND = 128;  // candidate blocks per round, two per lane; the survivors' (bi, bj) queue in LDS
         const unsigned nb = (unsigned)(side + 3) >> 2;
-        const unsigned nblk = g.valid ? nb * nb : 0u;  // (nb <= 46 341 for the 65 535-pixel sides the entry point admits)
+        const unsigned nblk = g.valid && !flat ? nb * nb : 0u;  // (nb <= 46 341 for the 65 535-pixel sides the entry point admits)
         const int ly = (lane >> 2) & 3, lx = lane & 3, quarter = lane >> 4;
         // Blocks that cannot hold an accepted sample are dropped BEFORE their per-sample tests (r05): rbin and cbin are
         // monotone in i and in j separately (a float product of a fixed factor is monotone, so is a float sum in each
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(256) void sift_descriptor_kernel(const float *__res
         dst[t] = ldexpf((float)h, e - 40);
     }
     keypoint_sync<WPK>();
+    if (flat) return;  // (after the last barrier)
     // the two 128-term norms, left to right in float (every lane computes them: uniform, no broadcast)
     float nrm2 = 0.f;
     for (int t = 0; t < LEN; t++) nrm2 += dst[t] * dst[t];
@@ -414,8 +422,15 @@ extern "C" int micv_sift_descriptors_dev(micv_ctx *ctx, const float *gx, const f
     MICV_HIP(hipSetDevice(ctx->device));
     if (n == 0) return MICV_OK;
     // fewer keypoints than two waves per SIMD: spend four waves on each
-    if (n < 2048)
+    // Waves per keypoint by the list's length (r05, 4K / 1080p checkerboards, size-10 keypoints, ms at 4 / 2 / 1 waves):
+    // 1 222 keypoints 0.075 / 0.085 / 0.119; 2 006: 0.112 / 0.106 / 0.123; 3 476: 0.171 / 0.164 / 0.179; 5 035: 0.231 /
+    // 0.218 / 0.220; 9 176: 0.390 / 0.360 / 0.351 -- a short list needs the waves, a long one pays for the repeated set-up.
+    const int wpk = n < 1800 ? 4 : (n < 6144 ? 2 : 1);
+    if (wpk == 4)
         sift_descriptor_kernel<4><<<(unsigned)n, 256, 0, static_cast<hipStream_t>(stream)>>>(
+            gx, gy, (int)(gstride / 4), rows, cols, kp_xysa, (long long)n, desc, (int)(dstride / 4));
+    else if (wpk == 2)
+        sift_descriptor_kernel<2><<<(unsigned)((n + 1) / 2), 256, 0, static_cast<hipStream_t>(stream)>>>(
             gx, gy, (int)(gstride / 4), rows, cols, kp_xysa, (long long)n, desc, (int)(dstride / 4));
     else
         sift_descriptor_kernel<1><<<(unsigned)((n + 3) / 4), 256, 0, static_cast<hipStream_t>(stream)>>>(

@@ -116,23 +116,24 @@ def test_descriptors_gpu_match_oracle(rows, cols, size, thr):
 
 @pytest.mark.gpu
 def test_descriptors_many_keypoints_one_wave_each():
-    """Lists of 2048 keypoints and more run one wave per keypoint (four per workgroup) instead of four
-    waves per keypoint: same answers, and the same answer for a keypoint whichever kernel it lands in."""
+    """Lists of 6144 keypoints and more run one wave per keypoint (four per workgroup), 1800 and more two waves, shorter
+    ones four: same answers, and the same answer for a keypoint whichever kernel it lands in."""
     import torch
     from introtocomputervision_amd import harris
     rows, cols = 160, 210
     gx, gy = orc.sobel(scene(rows, cols, seed=5), 3, 1.0)
     rng = np.random.default_rng(0x51F7)
-    n = 2051  # not a multiple of 4: the last workgroup has an idle wave
+    n = 6147  # not a multiple of 4: the last workgroup has an idle wave
     kps = np.stack([rng.uniform(-5, cols + 5, n), rng.uniform(-5, rows + 5, n), rng.choice([1.5, 8 / 3, 4, 6.5], n),
                     rng.uniform(-180, 540, n)], 1).astype(np.float32)
     exp = orc.sift_descriptors(gx, gy, kps)
-    assert exp.any(axis=1).sum() > 2000
+    assert exp.any(axis=1).sum() > 6000
     dgx, dgy = torch.from_numpy(gx).cuda(), torch.from_numpy(gy).cuda()
     got = harris.computeDescriptors(dgx, dgy, torch.from_numpy(kps).cuda()).cpu().numpy()
     assert np.array_equal(got, exp)
-    few = harris.computeDescriptors(dgx, dgy, torch.from_numpy(kps[:300]).cuda()).cpu().numpy()
-    assert np.array_equal(few, exp[:300])
+    for m in (2051, 300):  # two waves per keypoint (odd: the last workgroup repeats the last keypoint), four waves
+        few = harris.computeDescriptors(dgx, dgy, torch.from_numpy(kps[:m]).cuda()).cpu().numpy()
+        assert np.array_equal(few, exp[:m])
     # non-finite and flat gradients, pitched planes: a NaN gradient adds llrintf(NaN) = INT64_MIN per share, as the
     # host's conversion returns it (r03: the kernel added the NaN's mantissa bits instead -- 62 descriptors differed)
     gx2, gy2 = gx.copy(), gy.copy()
@@ -145,8 +146,9 @@ def test_descriptors_many_keypoints_one_wave_each():
     px[:, :cols] = torch.from_numpy(gx2); py[:, :cols] = torch.from_numpy(gy2)
     g3 = harris.computeDescriptors(px[:, :cols], py[:, :cols], torch.from_numpy(kps).cuda()).cpu().numpy()
     assert g3.tobytes() == exp2.tobytes()
-    g4 = harris.computeDescriptors(px[:, :cols], py[:, :cols], torch.from_numpy(kps[:200]).cuda()).cpu().numpy()  # four waves per keypoint
-    assert g4.tobytes() == exp2[:200].tobytes()
+    for m in (2051, 200):  # two / four waves per keypoint: a flat keypoint's waves still meet the workgroup's barriers
+        g4 = harris.computeDescriptors(px[:, :cols], py[:, :cols], torch.from_numpy(kps[:m]).cuda()).cpu().numpy()
+        assert g4.tobytes() == exp2[:m].tobytes()
 
 
 @pytest.mark.gpu
