@@ -202,8 +202,9 @@ def test_fuzz_hough(shape, pad, seed, density, rho_bin, theta_bin, radius, num_p
 
 
 @settings(max_examples=60 * SCALE, **COMMON)
-@given(st.tuples(st.integers(3, 90), st.integers(3, 120)), pad, seed, st.integers(1, 40), st.sampled_from([0, 0, 1, 2, 3]),
-       st.floats(-8.0, 8.0))
+@given(st.tuples(st.integers(3, 90), st.integers(3, 120)), pad, seed,
+       st.one_of(st.integers(1, 40), st.integers(1, 40), st.integers(1, 40), st.sampled_from([1799, 1801, 2300, 6143, 6145])),
+       st.sampled_from([0, 0, 1, 2, 3]), st.floats(-8.0, 8.0))
 def test_fuzz_sift_descriptors(shape, pad, seed, nkp, poison, log_scale):
     """Descriptor windows over random gradient fields of any magnitude (2^-8 .. 2^8 of 8-bit gradients), keypoints in
     and out of the image with sizes from a pixel to more than the image, and poisoned fields: a NaN, an infinity, a
@@ -222,8 +223,10 @@ def test_fuzz_sift_descriptors(shape, pad, seed, nkp, poison, log_scale):
     elif poison == 3:
         gx[: rows // 2, : cols // 2] = 0
         gy[: rows // 2, : cols // 2] = 0
+    # (long lists -- two waves / one wave per keypoint instead of four -- keep to small windows: the oracle is scalar)
+    sizes = [0.5, 1.5, 8 / 3, 4, 10, 40] if nkp <= 40 else [0.5, 1.5, 8 / 3, 4]
     kps = np.stack([rng.uniform(-10, cols + 10, nkp), rng.uniform(-10, rows + 10, nkp),
-                    rng.choice([0.5, 1.5, 8 / 3, 4, 10, 40], nkp), rng.uniform(-400, 800, nkp)], 1).astype(np.float32)
+                    rng.choice(sizes, nkp), rng.uniform(-400, 800, nkp)], 1).astype(np.float32)
     exp = orc.sift_descriptors(gx, gy, kps)
     got = harris.computeDescriptors(dev(gx, pad), dev(gy, pad), torch.from_numpy(kps).cuda())
     assert same(host(got), exp), (rows, cols, pad, nkp, poison)
