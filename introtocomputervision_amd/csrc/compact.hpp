@@ -256,11 +256,24 @@ __global__ __launch_bounds__(256) void compact_masks_onepass_kernel(const unsign
     for (int j = 0; j < J; j++) {
         unsigned long long mm = m[j];
         int64_t pos = excl + sh.wcount[j * 4 + wave] + before[j];
-        while (mm) {  // a handful of set bits at most in practice (strict maxima are sparse)
+        // Words with a few set bits (strict maxima are sparse) are emitted by their own lane; a word with many (a
+        // horizontal run of an edge mask: up to 64 serial trips for one lane while the wave waits) is emitted by the
+        // whole wave, one bit per lane (r05: the 1080p edge list 22 -> see profiles/r05/hough_chain.txt).
+        const bool dense = __popcll(mm) > 4;
+        unsigned long long todo = __ballot(dense);
+        if (dense) mm = 0;
+        while (mm) {
             const int bit = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
             if (pos < cap) emit(pos, base + j * 256 + threadIdx.x, bit);
             pos++;
+        }
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;  // wave-uniform
+            todo &= todo - 1;
+            const unsigned long long w = __shfl(m[j], l);
+            const int64_t p = __shfl(pos, l) + __popcll(w & ((1ull << lane) - 1ull));
+            if (((w >> lane) & 1ull) && p < cap) emit(p, base + j * 256 + (threadIdx.x - lane) + l, lane);
         }
     }
     compact_chunk_exit(sh, nchunks, status, counters);

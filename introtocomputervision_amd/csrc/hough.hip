@@ -253,47 +253,103 @@ __global__ __launch_bounds__(256) void peak_select_kernel(const int32_t *__restr
     }
 }
 
+// Unsigned max over the wave by DPP (quad permutes, the two row mirrors, row_bcast15 / row_bcast31; lane 63 ends up
+// with the total): six dependent VALU steps instead of six LDS-crossbar round trips of __shfl_xor -- the selection rounds
+// are one wave's serial chain, so the latency of the reduction is the kernel's time.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define MICV_DPP_MAX(ctrl, rmask)                                                                          \
+    {                                                                                                      \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rmask, 0xF, false); \
+        v = o > v ? o : v;                                                                                 \
+    }
+    MICV_DPP_MAX(0xB1, 0xF)   // quad_perm [1,0,3,2]
+    MICV_DPP_MAX(0x4E, 0xF)   // quad_perm [2,3,0,1]
+    MICV_DPP_MAX(0x141, 0xF)  // row_half_mirror
+    MICV_DPP_MAX(0x140, 0xF)  // row_mirror: every lane of a row of 16 holds the row's max
+    MICV_DPP_MAX(0x142, 0xA)  // row_bcast15 into rows 1 and 3
+    MICV_DPP_MAX(0x143, 0xC)  // row_bcast31 into rows 2 and 3
+#undef MICV_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The largest of the wave's 64-bit keys (every lane returns it): the high words first, then the low words of the
+// lanes that hold that high word -- the lexicographic order of (hi, lo) is the order of the keys.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long m) {
+    const unsigned hi = (unsigned)(m >> 32), lo = (unsigned)m;
+    const unsigned H = wave_max_u32(hi);
+    const unsigned L = wave_max_u32(hi == H ? lo : 0u);
+    return ((unsigned long long)H << 32) | L;
+}
+
 // All selection rounds in ONE launch by a single 1024-thread workgroup (num_peaks <= 64): a round
 // per launch costs more in launch latency than the scan itself when the candidate list is the
-// usual few hundred entries.  Keys of up to 4096 candidates are kept in LDS between rounds.
+// usual few hundred entries.
+// Up to 4096 candidates (r05): the keys are distinct, so the K largest of the list are among the K largest of each
+// wave's 256-key slice -- every wave selects its own top K from registers (K rounds of a wave reduction, no workgroup
+// barrier), the 16 x K survivors go to LDS, and wave 0 runs the K rounds again over them: two barriers in all instead
+// of two per round (top-10 of a few hundred candidates: 16 -> 6 us).  Longer lists rescan the candidates every round.
 __global__ __launch_bounds__(1024) void peak_select_all_kernel(
     const int32_t *__restrict__ acc, const int32_t *__restrict__ cand,
     const int64_t *__restrict__ ncand_p, int64_t cap, unsigned num_peaks, int cols,
     uint32_t *__restrict__ peaks_rc, int64_t *__restrict__ count) {
-    constexpr int KEEP = 4096;
-    __shared__ unsigned long long keys[KEEP];
+    constexpr int KEEP = 4096, KMAX = 64;
+    __shared__ unsigned long long top[16 * KMAX];
     __shared__ unsigned long long wmax[16];
     const int64_t n = *ncand_p < cap ? *ncand_p : cap;
-    const bool cached = n <= KEEP;
-    if (cached) {
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            const uint32_t idx = (uint32_t)cand[i];
-            keys[i] = peak_key(acc[idx], idx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (n <= KEEP) {
+        unsigned long long key[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = wave * 256 + j * 64 + lane;
+            uint32_t idx = 0;
+            if (i < n) idx = (uint32_t)cand[i];
+            key[j] = i < n ? peak_key(acc[idx], idx) : 0ull;  // (a real key is never 0: its low word is 2^32 - 1 - index)
+        }
+        unsigned long long bound = ~0ull;
+        for (unsigned k = 0; k < num_peaks; k++) {  // the wave's own top K, descending; 0 once it runs out
+            unsigned long long m = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) m = key[j] < bound && key[j] > m ? key[j] : m;
+            m = wave_max_u64(m);
+            if (lane == 0) top[wave * KMAX + k] = m;
+            bound = m ? m : 1ull;  // (nothing is below 1)
         }
         __syncthreads();
+        if (wave != 0) return;
+        // wave 0: K rounds over the 16 x K survivors, K / 4 per lane (wave w's k-th key sits at top[w * KMAX + k])
+        bound = ~0ull;
+        int64_t found = 0;
+        for (unsigned k = 0; k < num_peaks; k++) {
+            unsigned long long m = 0;
+            for (unsigned t = lane; t < 16 * num_peaks; t += 64) {
+                const unsigned long long c = top[(t / num_peaks) * KMAX + t % num_peaks];
+                m = c < bound && c > m ? c : m;
+            }
+            m = wave_max_u64(m);
+            if (m == 0) break;
+            if (lane == 0) {
+                const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(m & 0xFFFFFFFFull);
+                peaks_rc[2 * found] = idx / (uint32_t)cols;      // rho = row
+                peaks_rc[2 * found + 1] = idx % (uint32_t)cols;  // theta = col
+            }
+            bound = m;
+            found++;
+        }
+        if (lane == 0) *count = found;
+        return;
     }
     unsigned long long bound = ~0ull;
     int64_t found = 0;
     for (unsigned k = 0; k < num_peaks; k++) {
         unsigned long long m = 0;
-        if (cached) {
-            for (int i = threadIdx.x; i < n; i += 1024) {
-                const unsigned long long key = keys[i];
-                if (key < bound && key > m) m = key;
-            }
-        } else {
-            for (int64_t i = threadIdx.x; i < n; i += 1024) {
-                const uint32_t idx = (uint32_t)cand[i];
-                const unsigned long long key = peak_key(acc[idx], idx);
-                if (key < bound && key > m) m = key;
-            }
+        for (int64_t i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t idx = (uint32_t)cand[i];
+            const unsigned long long key = peak_key(acc[idx], idx);
+            if (key < bound && key > m) m = key;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(m, d);
-            m = o > m ? o : m;
-        }
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        m = wave_max_u64(m);
+        if (lane == 0) wmax[wave] = m;
         __syncthreads();
         m = wmax[0];
 #pragma unroll

@@ -433,6 +433,23 @@ def test_hough_peaks_many_candidates(M, num_peaks):
     assert np.array_equal(host(got).astype(np.uint32), exp)
 
 
+@pytest.mark.parametrize("shape,thr", [((20, 30), 30), ((40, 60), 30), ((120, 200), 38), ((200, 300), 40)])  # 140 / 519 / 3708 / > 4096 candidates
+@pytest.mark.parametrize("num_peaks", [1, 10, 64])
+def test_hough_peaks_two_stage_selection(M, shape, thr, num_peaks):
+    """Candidate lists of a few dozen, a few hundred and a few thousand entries (<= 4096: every wave's own top K, then
+    the K rounds over the survivors) with many equal votes: the survivors of different waves interleave in the answer,
+    ties go to the smaller index, and a list shorter than num_peaks ends early."""
+    harris, stereo, hough, synth = M
+    rng = np.random.default_rng(shape[0] * 7 + num_peaks)
+    acc = rng.integers(0, 48, shape).astype(np.int32)
+    exp = orc.hough_peaks(acc, num_peaks, thr)
+    got = hough.findLocalMaxima(dev(acc), num_peaks, thr)
+    assert np.array_equal(host(got).astype(np.uint32), exp)
+    # the same through the device-side count (no read-back)
+    peaks, cnt = hough.findLocalMaxima(dev(acc), num_peaks, thr, lazy=True)
+    assert int(cnt.item()) == len(exp) and np.array_equal(host(peaks)[:len(exp)].astype(np.uint32), exp)
+
+
 def test_hough_peaks_ties_are_stable(M):
     harris, stereo, hough, synth = M
     acc = np.zeros((40, 50), np.int32)
