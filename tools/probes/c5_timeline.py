@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 if len(sys.argv) > 2 and sys.argv[1] == "--timeline":
     f = sorted(glob.glob(os.path.join(sys.argv[2], "**", "*kernel_trace.csv"), recursive=True))[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-    firsts = [i for i, r in enumerate(rows) if "harris_image_response" in r["Kernel_Name"]]
+    marker = sys.argv[3] if len(sys.argv) > 3 else "harris_image_response"   # the chain's first kernel
+    firsts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
     a, b = firsts[-2], firsts[-1]          # the last complete iteration
     t0, prev_end = int(rows[a]["Start_Timestamp"]), None
     for r in rows[a:b]:
