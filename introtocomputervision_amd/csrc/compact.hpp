@@ -14,6 +14,8 @@
 //   scan  : one workgroup scans the chunk counts                              -> chunk_off[], total
 //   emit  : every chunk recomputes pred, ranks its hits and writes them at chunk_off + rank
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "common.hpp"
 
 namespace micv {
@@ -175,6 +177,17 @@ __device__ __forceinline__ void compact_chunk_exit(CompactShared &sh, int nchunk
     }
 }
 
+// Pred::center(i) / Pred::test(i, value) when the predicate offers them (see PeakPred), Pred::operator()(i) otherwise.
+template <typename P, typename = void>
+struct CompactHasCenter : std::false_type {};
+template <typename P>
+struct CompactHasCenter<P, std::void_t<decltype(std::declval<const P &>().center((int64_t)0))>> : std::true_type {};
+template <typename P>
+__device__ __forceinline__ auto compact_center(const P &p, int64_t i) {
+    if constexpr (CompactHasCenter<P>::value) return p.center(i);
+    else return 0;
+}
+
 template <typename Pred, typename Emit>
 __global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit emit, int64_t n, int nchunks,
                                                                unsigned long long *__restrict__ status,
@@ -190,10 +203,21 @@ __global__ __launch_bounds__(256) void compact_onepass_kernel(Pred pred, Emit em
     const int64_t base = (int64_t)chunk * kChunk1;
     unsigned hits = 0;
     int before[J];
+    // predicates that split into "load the element" and "decide" have all J loads in flight before the first decision
+    [[maybe_unused]] decltype(compact_center(pred, (int64_t)0)) ctr[J];
+    if constexpr (CompactHasCenter<Pred>::value) {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int64_t i = base + j * 256 + threadIdx.x;
+            ctr[j] = pred.center(i < n ? i : n - 1);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < J; j++) {
         const int64_t i = base + j * 256 + threadIdx.x;
-        const bool hit = i < n && pred(i);
+        bool hit;
+        if constexpr (CompactHasCenter<Pred>::value) hit = i < n && pred.test(i, ctr[j]);
+        else hit = i < n && pred(i);
         const unsigned long long m = __ballot(hit);
         before[j] = __popcll(m & ((1ull << lane) - 1ull));
         hits |= (unsigned)hit << j;

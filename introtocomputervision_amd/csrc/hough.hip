@@ -203,10 +203,14 @@ __global__ __launch_bounds__(1024) void hough_circles_tiled_kernel(
 struct PeakPred {
     const int32_t *acc;
     int rows, cols, threshold;
-    __device__ bool operator()(int64_t i) const {
-        const int ty = (int)(i / cols), tx = (int)(i - (int64_t)ty * cols);
-        const int v = acc[i];
+    // Two steps for the one-launch compaction: a workgroup's 16 centre loads per thread go out together, the rare
+    // cells at or above the threshold then look at their neighbours (as one call the 16 loads ran one after the other,
+    // each behind the previous cell's branch: 15.3 -> see profiles/r05/hough_chain.txt).
+    __device__ int center(int64_t i) const { return acc[i]; }
+    __device__ bool test(int64_t i, int v) const {
         if (v < threshold) return false;
+        const uint32_t ii = (uint32_t)i;  // (the entry point admits fewer than 2^31 cells: a 32-bit quotient)
+        const int ty = (int)(ii / (uint32_t)cols), tx = (int)(ii - (uint32_t)ty * (uint32_t)cols);
         const int y1 = rows - 1 < ty + 1 ? rows - 1 : ty + 1;  // exclusive bounds, as written
         const int x1 = cols - 1 < tx + 1 ? cols - 1 : tx + 1;
         for (int y = ty - 1 > 0 ? ty - 1 : 0; y < y1; y++)
@@ -214,6 +218,7 @@ struct PeakPred {
                 if (acc[(size_t)y * cols + x] > v) return false;
         return true;
     }
+    __device__ bool operator()(int64_t i) const { return test(i, acc[i]); }
 };
 
 // Selection round k: the largest key strictly below the key chosen in round k-1.
