@@ -304,12 +304,20 @@ __global__ __launch_bounds__(1024) void peak_select_all_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (n <= KEEP) {
         unsigned long long key[4];
+        uint32_t idx[4];
+        int votes[4];
+        // the four candidate loads together, then the four accumulator loads (clamped indices: no branch between them)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int i = wave * 256 + j * 64 + lane;
-            uint32_t idx = 0;
-            if (i < n) idx = (uint32_t)cand[i];
-            key[j] = i < n ? peak_key(acc[idx], idx) : 0ull;  // (a real key is never 0: its low word is 2^32 - 1 - index)
+            const int64_t i = wave * 256 + j * 64 + lane;
+            idx[j] = n > 0 ? (uint32_t)cand[i < n ? i : n - 1] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) votes[j] = acc[idx[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t i = wave * 256 + j * 64 + lane;
+            key[j] = i < n ? peak_key(votes[j], idx[j]) : 0ull;  // (a real key is never 0: its low word is 2^32 - 1 - index)
         }
         unsigned long long bound = ~0ull;
         for (unsigned k = 0; k < num_peaks; k++) {  // the wave's own top K, descending; 0 once it runs out

@@ -164,9 +164,10 @@ __global__ __launch_bounds__(256) void bf_merge_kernel(const int32_t *__restrict
 struct RatioPred {
     const float *dist2;
     double ratio;
-    __device__ bool operator()(int64_t q) const {
-        return (double)dist2[2 * q] < ratio * (double)dist2[2 * q + 1];  // Solution.cpp:181
-    }
+    // (center / test: the one-launch compaction loads a thread's 16 pairs before it decides the first, compact.hpp)
+    __device__ float2 center(int64_t q) const { return make_float2(dist2[2 * q], dist2[2 * q + 1]); }  // (caller's pointer: 4-byte aligned)
+    __device__ bool test(int64_t, float2 d) const { return (double)d.x < ratio * (double)d.y; }  // Solution.cpp:181
+    __device__ bool operator()(int64_t q) const { return test(q, center(q)); }
 };
 
 __global__ void bf_emit_kernel(const int32_t *__restrict__ sel, const int64_t *__restrict__ count,

@@ -86,11 +86,13 @@ __global__ __launch_bounds__(256) void stereo_energy_kernel(StereoArgs a, float 
     const bool full = a.wcols == W;
     const int sp = a.s_lo - 2 * R + blockIdx.x * OUTW + lane;  // position of this lane's column
     const int xr = clampi(sp, 0, a.cols - 1);
-    float ringB[W];
+    float ringB[W], rvs[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++)  // every row's load first: between the stores below they waited one by one
+        rvs[s] = a.right[(size_t)clampi(ys - R + s, 0, a.rows - 1) * a.stride + xr];
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
-        const int yy = clampi(ys - R + s, 0, a.rows - 1);
-        const float rv = a.right[(size_t)yy * a.stride + xr];
+        const float rv = rvs[s];
         ringB[s % W] = rv * rv;
         if (s >= 2 * R) {
             float csb = 0.f;
