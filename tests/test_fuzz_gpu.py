@@ -543,3 +543,86 @@ def test_fuzz_virtual_shards_of_stereo_harris_hough(shape, seed, world, rad, min
         total += so.hough_lines_sharded(mask[a:b], (a, b), rows, 1, 1, fns.hough_lines_band, so.LocalComm())
         total_c += so.hough_circles_sharded(mask[a:b], (a, b), rows, radius, fns.hough_circles_band, so.LocalComm())
     assert torch.equal(total, whole) and torch.equal(total_c, whole_c)
+
+
+def pitched(a, pad):
+    """A numpy view with a row pitch of cols + pad elements (what a cv::Mat ROI hands to the `_host` entry points)."""
+    a = np.ascontiguousarray(a)
+    if pad == 0:
+        return a
+    wide = np.full((a.shape[0], a.shape[1] + pad), 7, a.dtype)
+    wide[:, :a.shape[1]] = a
+    return wide[:, :a.shape[1]]
+
+
+@settings(max_examples=80 * SCALE, **COMMON)
+@given(st.tuples(st.integers(8, 70), st.integers(8, 110)), pad, seed, st.integers(0, 9))
+def test_fuzz_host_entry_points_match_the_device_ones(shape, pad, seed, op):
+    """Every `_host` entry point (host pointers in and out, staging and copies inside) against its `_dev` twin on the same
+    inputs, with pitched rows as a cv::Mat region of interest has them: the same bits."""
+    from introtocomputervision_amd import harris, hough, lk, mhi, pyr, stereo
+    rows, cols = shape
+    rng = np.random.default_rng(seed)
+    a = image(seed, rows, cols, 1)
+    b = np.roll(a, (1, -2), (0, 1)) + np.float32(0.5)
+    A, B_ = pitched(a, pad), pitched(b, pad)
+    if op == 0:
+        win, levels = int(rng.choice([5, 7, 15, 21])), int(rng.integers(1, 4))
+        for g, e in zip(lk.calcOpticalFlowPyr(A, B_, win, levels), lk.calcOpticalFlowPyr(dev(a), dev(b), win, levels)):
+            assert same(g, host(e))
+    elif op == 1:
+        win = int(rng.choice([3, 7, 15, 23]))
+        for g, e in zip(lk.calcOpticalFlow(A, B_, win), lk.calcOpticalFlow(dev(a), dev(b), win)):
+            assert same(g, host(e))
+    elif op == 2:
+        du = (rng.standard_normal((rows, cols)) * 3).astype(np.float32)
+        dv = (rng.standard_normal((rows, cols)) * 3).astype(np.float32)
+        assert same(lk.warp(A, pitched(du, pad), pitched(dv, pad)), host(lk.warp(dev(a), dev(du), dev(dv))))
+    elif op == 3:
+        assert same(pyr.pyrDown(A), host(pyr.pyrDown(dev(a))))
+        assert same(pyr.pyrUp(A), host(pyr.pyrUp(dev(a))))
+        for g, e in zip(pyr.makeGaussianPyramid(A, 3), pyr.makeGaussianPyramid(dev(a), 3)):
+            assert same(g, host(e))
+    elif op == 4:
+        k, w = int(rng.choice([3, 5])), int(rng.choice([3, 5, 7]))
+        gx, gy = harris.getGradients(A, k)
+        dgx, dgy = harris.getGradients(dev(a), k)
+        assert same(gx, host(dgx)) and same(gy, host(dgy))
+        R = harris.getCornerResponse(pitched(gx, pad), pitched(gy, pad), w, 1.5, 0.04)
+        dR = harris.getCornerResponse(dgx, dgy, w, 1.5, 0.04)
+        assert same(R, host(dR))
+        thr = float(np.quantile(R, 0.9))
+        (c, l), (dc, dl) = harris.refineCorners(pitched(R, pad), thr, 3), harris.refineCorners(dR, thr, 3)
+        assert same(c, host(dc)) and np.array_equal(l, host(dl))
+        kp, dkp = harris.getKeypoints(gx, gy, l, 4), harris.getKeypoints(dgx, dgy, dl, 4)
+        assert same(np.asarray(kp), host(dkp) if torch.is_tensor(dkp) else np.asarray(dkp))
+        if len(l):
+            assert same(harris.computeDescriptors(gx, gy, np.asarray(kp)), host(harris.computeDescriptors(dgx, dgy, dkp)))
+    elif op == 5:
+        w = int(rng.choice([3, 5, 7, 9]))
+        h, d = harris.cornersFromImage(A, 3, w, 1.5, 0.04, 1e6, 2), harris.cornersFromImage(dev(a), 3, w, 1.5, 0.04, 1e6, 2)
+        assert np.array_equal(h["locs"], host(d["locs"])) and same(h["gx"], host(d["gx"])) and same(h["gy"], host(d["gy"]))
+    elif op == 6:
+        rad, mn = int(rng.integers(0, 6)), -int(rng.integers(0, 20))
+        for fn in (stereo.disparitySSD, stereo.disparityNCorr):
+            assert np.array_equal(fn(A, B_, rad, mn, mn + 12), host(fn(dev(a), dev(b), rad, mn, mn + 12)))
+    elif op == 7:
+        m = (rng.random((rows, cols)) < 0.05).astype(np.uint8) * 255
+        M = pitched(m, pad)
+        acc, dacc = hough.houghLinesAccumulate(M, 1, 1), hough.houghLinesAccumulate(dev(m), 1, 1)
+        assert np.array_equal(acc, host(dacc))
+        r = int(rng.integers(1, 9))
+        assert np.array_equal(hough.houghCirclesAccumulate(M, r), host(hough.houghCirclesAccumulate(dev(m), r)))
+        assert np.array_equal(hough.findLocalMaxima(acc, 8, 3), host(hough.findLocalMaxima(dacc, 8, 3)).astype(np.uint32))
+    elif op == 8:
+        img = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        gs, lo = int(rng.choice([1, 3, 5])), float(rng.integers(0, 60))
+        assert np.array_equal(hough.generateEdge(pitched(img, pad), gs, 1.2, lo, lo + 50), host(hough.generateEdge(dev(img), gs, 1.2, lo, lo + 50)))
+    else:
+        f1 = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        f2 = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        d = mhi.frameDifference(f1, f2, 20, (3, 3), 1.0)  # (the mhi wrappers take contiguous frames)
+        dd = mhi.frameDifference(dev(f1), dev(f2), 20, (3, 3), 1.0)
+        assert np.array_equal(d, host(dd))
+        hist = rng.integers(0, 40, (rows, cols), dtype=np.uint8)
+        assert np.array_equal(mhi.calcMotionHistory(hist.copy(), d, 30), host(mhi.calcMotionHistory(dev(hist), dd, 30)))
