@@ -69,6 +69,9 @@ void orc_sep_filter_cvcpu(const float *src, int rows, int cols, size_t sstride,
                           float *dst, size_t dstride, int fused);
 int orc_lk_flow_ex(const float *prev, const float *next, int rows, int cols, size_t stride,
                    int win, int variant, float *u, float *v, size_t ostride, double *det_out);
+/* the same on a crop at frame position (oy, ox): see oracle_lk.c */
+int orc_lk_flow_pyr_at(const float *prev, const float *next, int rows, int cols, size_t stride,
+                       int win, int levels, int oy, int ox, float *u, float *v, size_t ostride);
 int orc_lk_flow_pyr_ex(const float *prev, const float *next, int rows, int cols, size_t stride,
                        int win, int levels, int variant, float *u, float *v, size_t ostride, double *det0_out);
 

@@ -239,6 +239,12 @@ int orc_cv_round(float v) {
 
 /* cv::remap, CV_32FC1 maps, INTER_LINEAR, BORDER_CONSTANT(0)
  * (OpenCV 3.4.1 imgproc/src/imgwarp.cpp: RemapInvoker + remapBilinear<Cast<float,float>>). */
+/* The frame position of pixel (0, 0) of the arrays orc_lk_warp works on (orc_lk_flow_pyr_at: the oracle on a CROP of a
+ * large frame).  cv::remap's map is the float sum "pixel index + flow", so a warped value depends on where in the frame
+ * the pixel sits (the sum rounds at the magnitude of the index): with an origin the map carries the frame's index and the
+ * tap addresses are brought back into the crop after the fixed-point conversion.  (0, 0) everywhere else. */
+static int g_org_y = 0, g_org_x = 0, g_base_org_y = 0, g_base_org_x = 0;
+
 void orc_remap_linear(const float *src, int rows, int cols, size_t sstride,
                       const float *mapx, const float *mapy, size_t mstride,
                       float *dst, int drows, int dcols, size_t dstride) {
@@ -247,7 +253,7 @@ void orc_remap_linear(const float *src, int rows, int cols, size_t sstride,
             int sx = orc_cv_round(AT(mapx, mstride, y, x) * 32.f); /* cvRound(v*INTER_TAB_SIZE) */
             int sy = orc_cv_round(AT(mapy, mstride, y, x) * 32.f);
             int fx = sx & 31, fy = sy & 31;
-            int ix = sat_short(sx >> 5), iy = sat_short(sy >> 5);
+            int ix = sat_short(sx >> 5) - g_org_x, iy = sat_short(sy >> 5) - g_org_y;
             /* BilinearTab_f: 1-D taps {1 - k/32, k/32}, 2-D weight = vy*vx */
             float ax1 = fx * (1.f / 32.f), ax0 = 1.f - ax1;
             float ay1 = fy * (1.f / 32.f), ay0 = 1.f - ay1;
@@ -273,8 +279,8 @@ void orc_lk_warp(const float *src, const float *du, const float *dv, int rows, i
     float *mx = (float *)malloc(2 * n * sizeof(float)), *my = mx + n;
     for (int y = 0; y < rows; y++)
         for (int x = 0; x < cols; x++) {
-            mx[(size_t)y * cols + x] = (float)x + AT(du, stride, y, x); /* :113 */
-            my[(size_t)y * cols + x] = (float)y + AT(dv, stride, y, x); /* :114 */
+            mx[(size_t)y * cols + x] = (float)(x + g_org_x) + AT(du, stride, y, x); /* :113 */
+            my[(size_t)y * cols + x] = (float)(y + g_org_y) + AT(dv, stride, y, x); /* :114 */
         }
     orc_remap_linear(src, rows, cols, stride, mx, my, cols, dst, rows, cols, stride); /* :119 */
     free(mx);
@@ -345,6 +351,18 @@ void orc_pyr_up(const float *src, int rows, int cols, size_t sstride,
     free(up);
 }
 
+/* orc_lk_flow_pyr on a crop whose pixel (0, 0) is pixel (oy, ox) of the frame (both multiples of 2^(levels - 1), so the
+ * crop's pyramid is a crop of the frame's): away from the crop's own borders the result is the frame's, bit for bit --
+ * the size-independent check of tests/test_large_gpu.py.  Not re-entrant (file-scope origin). */
+int orc_lk_flow_pyr_at(const float *prev, const float *next, int rows, int cols, size_t stride,
+                       int win, int levels, int oy, int ox, float *u, float *v, size_t ostride) {
+    if (levels < 1 || levels > 16 || oy < 0 || ox < 0 || (oy & ((1 << (levels - 1)) - 1)) || (ox & ((1 << (levels - 1)) - 1))) return -1;
+    g_base_org_y = oy; g_base_org_x = ox;
+    int rc = orc_lk_flow_pyr_ex(prev, next, rows, cols, stride, win, levels, 0, u, v, ostride, NULL);
+    g_base_org_y = 0; g_base_org_x = 0;
+    return rc;
+}
+
 /* lk::calcOpticalFlowPyr, OpticalFlow.cpp:122-167; `levels` replaces pyrDepth = 4 (:127). */
 int orc_lk_flow_pyr(const float *prev, const float *next, int rows, int cols, size_t stride,
                     int win, int levels, float *u, float *v, size_t ostride) {
@@ -405,7 +423,9 @@ int orc_lk_flow_pyr_ex(const float *prev, const float *next, int rows, int cols,
         float *warped = (float *)malloc((size_t)R * C * sizeof(float));
         float *dx = (float *)malloc((size_t)R * C * sizeof(float));
         float *dy = (float *)malloc((size_t)R * C * sizeof(float));
+        g_org_y = g_base_org_y >> k; g_org_x = g_base_org_x >> k;  /* (0 unless orc_lk_flow_pyr_at set them) */
         orc_lk_warp(np[k], du, dv, R, C, C, warped);               /* :155 */
+        g_org_y = 0; g_org_x = 0;
         rc = orc_lk_flow_ex(pp[k], warped, R, C, C, win, variant, dx, dy, C, k == 0 ? det0_out : NULL);  /* :159 */
         for (size_t i = 0; i < (size_t)R * C; i++) { du[i] = du[i] + dx[i]; dv[i] = dv[i] + dy[i]; } /* :161-162 */
         free(warped); free(dx); free(dy);

@@ -163,6 +163,20 @@ def gaussian_pyramid(src, levels):
     return out
 
 
+_lkpat = _sig("orc_lk_flow_pyr_at", i32, [vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, vp, sz])
+
+
+def lk_flow_pyr_at(prev, nxt, win, levels, oy, ox):
+    """lk_flow_pyr on a crop whose pixel (0, 0) is pixel (oy, ox) of a larger frame (multiples of 2^(levels - 1))."""
+    prev = _f(prev); nxt = _f(nxt)
+    r, c = prev.shape
+    u = np.empty_like(prev); v = np.empty_like(prev)
+    rc = _lkpat(_p(prev), _p(nxt), r, c, c, win, levels, int(oy), int(ox), _p(u), _p(v), c)
+    if rc:
+        raise ValueError(f"orc_lk_flow_pyr_at rc={rc}")
+    return u, v
+
+
 def lk_flow_pyr(prev, nxt, win, levels):
     prev = _f(prev); nxt = _f(nxt)
     r, c = prev.shape

@@ -1,0 +1,98 @@
+"""Maximum sizes ("cover the edge cases ... maximum sizes"): a 16384 x 16384 frame pair -- 268 Mpx, 1 GB a
+plane, 130 x the 1080p frames of the bench -- through the device entry points, checked against the CPU oracle on CROPS.
+Every operator here is local (an output depends on a bounded neighbourhood of the inputs), so the oracle run on a crop
+with a margin larger than that neighbourhood must reproduce the interior of the crop bit for bit; crops start at multiples
+of 16 so that the pyramid's decimation lattice (level l takes pixel 2^l y + 2^l - 1) is the same in the crop and in the
+frame, and the pyramid's oracle is told the crop's position (cv::remap's map is the float sum "pixel index + flow": a warped
+value depends on where in the frame the pixel sits -- orc_lk_flow_pyr_at, pinned by tests/test_oracle_crosscheck.py).  The frames are made on the device (a smooth texture, its translate) and only the crops travel to the host."""
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N = 16384
+CROP, MARGIN = 1280, 512          # oracle input / the rim that is not compared
+CROPS = [(0, 0), (N - CROP, N - CROP), (6144, 9984), (N - CROP, 0)]   # two corners of the frame, the middle, an edge
+
+
+@pytest.fixture(scope="module")
+def frames():
+    g = torch.Generator(device="cuda").manual_seed(0x5EED16)
+    low = torch.rand((1, 1, N // 8 + 2, N // 8 + 2), device="cuda", generator=g) * 255
+    prev = torch.nn.functional.interpolate(low, scale_factor=8, mode="bicubic", align_corners=False)[0, 0, 8:8 + N, 8:8 + N].contiguous()
+    del low
+    nxt = (torch.roll(prev, (2, -3), (0, 1)) + 0.25).contiguous()
+    torch.cuda.synchronize()
+    yield prev, nxt
+    del prev, nxt
+    torch.cuda.empty_cache()
+
+
+def crop(t, y, x, h=CROP, w=CROP):
+    return t[y:y + h, x:x + w].cpu().numpy()
+
+
+def inner(a, y, x):
+    """The part of a crop-sized array that a frame edge or the margin protects: a crop side that lies ON the frame's
+    border is exact up to that border (the oracle reflects there exactly as the frame does)."""
+    t = 0 if y == 0 else MARGIN
+    b = CROP if y + CROP == N else CROP - MARGIN
+    l = 0 if x == 0 else MARGIN
+    r = CROP if x + CROP == N else CROP - MARGIN
+    return a[t:b, l:r]
+
+
+def test_pyramidal_lk_on_a_268_megapixel_pair(frames):
+    from introtocomputervision_amd import lk
+    prev, nxt = frames
+    u, v = lk.calcOpticalFlowPyr(prev, nxt, 15, 5)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(u[::64, ::64]).all()) and float(u[4096:4160, 4096:4160].abs().median()) > 1.0  # (it did track the shift)
+    for y, x in CROPS:
+        eu, ev = orc.lk_flow_pyr_at(crop(prev, y, x), crop(nxt, y, x), 15, 5, y, x)
+        gu, gv = crop(u, y, x), crop(v, y, x)
+        assert np.array_equal(inner(gu, y, x), inner(eu, y, x)), (y, x)
+        assert np.array_equal(inner(gv, y, x), inner(ev, y, x)), (y, x)
+    del u, v
+
+
+def test_local_operators_on_a_268_megapixel_frame(frames):
+    from introtocomputervision_amd import harris, lk, pyr, stereo
+    prev, nxt = frames
+    h, w = 256, 384  # small crops: these neighbourhoods are a few pixels wide
+    spots = [(0, 0), (N - h, N - w), (8000, 12000)]
+
+    def eq(got, exp, y, x, m):
+        t, b = (0 if y == 0 else m), (h if y + h == N else h - m)
+        l, r = (0 if x == 0 else m), (w if x + w == N else w - m)
+        assert np.array_equal(got[t:b, l:r], exp[t:b, l:r]), (y, x)
+
+    u1, v1 = lk.calcOpticalFlow(prev, nxt, 15)
+    for y, x in spots:
+        eu, ev = orc.lk_flow(crop(prev, y, x, h, w), crop(nxt, y, x, h, w), 15)
+        eq(crop(u1, y, x, h, w), eu, y, x, 12)
+        eq(crop(v1, y, x, h, w), ev, y, x, 12)
+    del u1, v1
+    gx, gy = harris.getGradients(prev, 3)
+    R = harris.getCornerResponse(gx, gy, 5, 1.5, 0.04)
+    for y, x in spots:
+        egx, egy = orc.sobel(crop(prev, y, x, h, w), 3, 1.0)
+        eq(crop(gx, y, x, h, w), egx, y, x, 2)
+        eq(crop(gy, y, x, h, w), egy, y, x, 2)
+        eq(crop(R, y, x, h, w), orc.harris_response(egx, egy, 5, 1.5, 0.04), y, x, 6)
+    chain = harris.cornersFromImage(prev, 3, 5, 1.5, 0.04, 5e8, 5, capacity=1 << 22, want_response=True, lazy=True)
+    assert torch.equal(chain["response"], R) and torch.equal(chain["gx"], gx)
+    del gx, gy, R, chain
+    down = pyr.pyrDown(prev)
+    for y, x in spots:
+        y2, x2 = y & ~1, x & ~1
+        assert np.array_equal(crop(down, y2 // 2, x2 // 2, h // 2, w // 2), orc.pyr_down(crop(prev, y2, x2, h, w))), (y, x)
+    del down
+    d = stereo.disparitySSD(prev, nxt, 5, -16, 0)
+    for y, x in [(0, 4096), (N - h, 9000), (8000, 12000)]:   # rows are independent; columns reach 16 + 5 to the left
+        e = orc.disparity_ssd(crop(prev, y, x, h, w), crop(nxt, y, x, h, w), 5, -16, 0)
+        t, b = (0 if y == 0 else 6), (h if y + h == N else h - 6)
+        assert np.array_equal(crop(d, y, x, h, w)[t:b, 24:w - 6], e[t:b, 24:w - 6]), (y, x)
