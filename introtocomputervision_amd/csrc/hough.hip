@@ -138,7 +138,7 @@ __global__ __launch_bounds__(1024) void hough_circles_tiled_kernel(
     int32_t *__restrict__ acc) {
     constexpr int TA = 64, TB = 32, CH = 2048, NT = 1024;  // 16 waves per tile: the heaviest tile sets the tail
     __shared__ int hist[TA * TB];
-    __shared__ int list[CH];
+    __shared__ int list[4 * CH];  // (point, quadrant of the angle) entries: up to four per point
     __shared__ int nlist;
     __shared__ long long range[2];
     const int tid = threadIdx.x;
@@ -174,15 +174,31 @@ __global__ __launch_bounds__(1024) void hough_circles_tiled_kernel(
         for (long long i = base + tid; i < end; i += NT) {
             const int p = pts[i];
             const int yl = p / cols, x = p - yl * cols;
-            if (x >= a0 - reach && x < a0 + TA + reach) list[atomicAdd(&nlist, 1)] = ((yl + row0) << 16) | x;
+            if (x >= a0 - reach && x < a0 + TA + reach) {
+                // Only the quadrants of the circle that can reach the tile are listed (r05): at angle t the centre lies at
+                // (x - r cos t, y - r sin t), so over t in [90 q, 90 q + 90) it stays on one side of the point in each axis --
+                // left of it (cos >= 0: q = 0, 3; the truncated column is in [x - reach, x]) or right of it (q = 1, 2:
+                // [x - 1, x + reach], the - 1 for table entries that are a rounding error off zero), likewise above
+                // (q = 0, 1) or below.  A quadrant is listed unless the tile lies wholly on the other side; the exact
+                // test of every vote below is unchanged, so the filter only has to be conservative.  It drops about half
+                // of the (point, angle) pairs a tile used to evaluate.
+                const int y = yl + row0;
+                const bool lft = x >= a0, rgt = x <= a0 + TA, up = y >= b0, dwn = y <= b0 + TB;
+                const int e = (y << 15) | x;  // (rows, cols <= 32767: 15 bits each, the quadrant on top)
+                if (lft && up) list[atomicAdd(&nlist, 1)] = e;
+                if (rgt && up) list[atomicAdd(&nlist, 1)] = e | (1 << 30);
+                if (rgt && dwn) list[atomicAdd(&nlist, 1)] = e | (2 << 30);
+                if (lft && dwn) list[atomicAdd(&nlist, 1)] = e | (3 << 30);
+            }
         }
         __syncthreads();
         // (point, angle) pairs dealt flat over the workgroup: every lane busy, one vote per trip
-        const int nv = nlist * 360;
+        const int nv = nlist * 90;
         for (int w = tid; w < nv; w += NT) {
-            const int k = w / 360, t = w - k * 360;
-            const int e = list[k];
-            const float fx = (float)(e & 0xFFFF), fy = (float)(e >> 16);
+            const int k = w / 90;
+            const unsigned e = (unsigned)list[k];
+            const int t = (w - k * 90) + 90 * (int)(e >> 30);
+            const float fx = (float)(e & 0x7FFF), fy = (float)((e >> 15) & 0x7FFF);
             // v_cvt_u32_f32 saturates (negative and NaN -> 0, >= 2^32 -> 0xFFFFFFFF): it IS f2u_sat
             unsigned a, b;
             const float va = fx - radius * tc[t], vb = fy - radius * ts[t];
