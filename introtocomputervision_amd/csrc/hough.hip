@@ -136,7 +136,8 @@ __global__ __launch_bounds__(1024) void hough_circles_tiled_kernel(
     const int32_t *__restrict__ pts, const int64_t *__restrict__ npts_p, int rows, int cols, int row0,
     const float *__restrict__ ct, const float *__restrict__ st, float radius, int reach,
     int32_t *__restrict__ acc) {
-    constexpr int TA = 64, TB = 32, CH = 2048, NT = 1024;  // 16 waves per tile: the heaviest tile sets the tail
+    // 16 waves per tile: the launch lasts as long as its heaviest tile's vote loop (r05: 512 threads 54.6 us, 256: 86.9, against 41.5)
+    constexpr int TA = 64, TB = 32, CH = 2048, NT = 1024;
     __shared__ int hist[TA * TB];
     __shared__ int list[4 * CH];  // (point, quadrant of the angle) entries: up to four per point
     __shared__ int nlist;
@@ -144,17 +145,25 @@ __global__ __launch_bounds__(1024) void hough_circles_tiled_kernel(
     const int tid = threadIdx.x;
     const int a0 = blockIdx.x * TA, b0 = blockIdx.y * TB;
     for (int i = tid; i < TA * TB; i += NT) hist[i] = 0;
-    if (tid < 2) {
-        // first point with local row >= yl (tid 0: lowest row that reaches the tile; tid 1: one past
-        // the highest)
-        const long long yl = tid == 0 ? (long long)b0 - reach - row0 : (long long)b0 + TB + reach - row0;
+    if (tid < 128) {
+        // first point with local row >= yl (wave 0: lowest row that reaches the tile; wave 1: one past the highest).
+        // A 64-ary search by the whole wave: three dependent loads for 19 k points where the one-lane bisection took
+        // fourteen -- at ~0.8 us each that chain was most of a tile's time (r05: 44 -> see profiles/r05/hough_chain.txt).
+        const int wv = tid >> 6, ln = tid & 63;
+        const long long yl = wv == 0 ? (long long)b0 - reach - row0 : (long long)b0 + TB + reach - row0;
         const long long key = yl <= 0 ? 0 : yl * cols;
-        long long lo = 0, hi = *npts_p;
-        while (lo < hi) {
-            const long long mid = (lo + hi) >> 1;
-            if ((long long)pts[mid] < key) lo = mid + 1; else hi = mid;
+        long long lo = 0, hi = *npts_p;  // the answer is in [lo, hi]
+        while (hi - lo > 64) {
+            const long long stride = (hi - lo + 63) >> 6;
+            const long long at = lo + (ln + 1) * stride - 1;  // the last element of this lane's segment
+            const bool below = at < hi && (long long)pts[at] < key;
+            const int c = __popcll(__ballot(below));  // whole segments below the key (the predicate is monotone)
+            lo += c * stride;
+            hi = lo + stride < hi ? lo + stride : hi;
         }
-        range[tid] = lo;
+        const bool below = lo + ln < hi && (long long)pts[lo + ln] < key;
+        lo += __popcll(__ballot(below));
+        if (ln == 0) range[wv] = lo;
     }
     __shared__ float tc[360], ts[360];
     for (int i = tid; i < 360; i += NT) {
