@@ -314,7 +314,8 @@ def secondary_block(ctx, stream, torch, np):
         gx, gy, locs = h["gx"], h["gy"], h["locs"][:min(int(count_host[0]), 1 << 20)]
         kp = harris.getKeypoints(gx, gy, locs, 10, ctx=ctx)
         desc = harris.computeDescriptors(gx, gy, kp, ctx=ctx)
-        yy, xx = locs[:, 0].long(), locs[:, 1].long()
+        ll = locs.long()  # one conversion kernel for both index columns
+        yy, xx = ll[:, 0], ll[:, 1]
         return locs, kp, desc, u_[yy, xx], v_[yy, xx]
     p4, n4 = c5_frames(2160, 3840)
     P4, N4 = dev(p4), dev(n4)

@@ -57,7 +57,8 @@ def c5():
     desc = harris.computeDescriptors(h["gx"], h["gy"], kp, ctx=ctx)
     if not overlap:
         u_, v_ = lk.calcOpticalFlowPyr(P, N, WIN, LEVELS, ctx=ctx)
-    yy, xx = locs[:, 0].long(), locs[:, 1].long()
+    ll = locs.long()
+    yy, xx = ll[:, 0], ll[:, 1]
     return locs, kp, desc, u_[yy, xx], v_[yy, xx]
 
 
