@@ -464,13 +464,6 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
     __shared__ __attribute__((aligned(16))) int RN[(TH + 2 * DMAX) * TW];
     const int RW = TW + 2 * d, RH = TH + 2 * d, TS = RW | 1;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    // candidate path (below): the tile's kept cells as one mask per row, the cells at or above the threshold
-    constexpr int NCAND = 256;
-    __shared__ unsigned long long keepmask[TH];
-    __shared__ unsigned short cand[NCAND];
-    __shared__ int ncand;
-    if (threadIdx.x < TH) keepmask[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) ncand = 0;
     // Staging: 128 lanes per region row (RW <= 96), two rows per pass of the workgroup, four
     // passes' loads in flight at once -- no division by the runtime pitch anywhere.
     {
@@ -478,16 +471,13 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         const int xx = x0 - d + lx;
         const bool col_in = (unsigned)xx < (unsigned)cols;
         const int xc = clampi(xx, 0, cols - 1);
-        // (r05: the whole region's loads in flight at once when the radius is a template argument -- 21 per thread at
-        // d = 5; four at a time made a tile six dependent round trips long, and that was the kernel's time)
-        constexpr int NL = DT > 0 ? (TH + 2 * DT + 1) / 2 : 4;
-        for (int rb = 0; rb < RH; rb += 2 * NL) {
-            float v[NL];
+        for (int rb = 0; rb < RH; rb += 8) {
+            float v[4];
 #pragma unroll
-            for (int k = 0; k < NL; k++)
+            for (int k = 0; k < 4; k++)
                 v[k] = resp[(size_t)clampi(y0 - d + rb + 2 * k + lr, 0, rows - 1) * rstride + xc];
 #pragma unroll
-            for (int k = 0; k < NL; k++) {
+            for (int k = 0; k < 4; k++) {
                 const int ly = rb + 2 * k + lr, yy = y0 - d + ly;
                 if (ly < RH && lx < RW)
                     T[ly * TS + lx] = (col_in && (unsigned)yy < (unsigned)rows) ? v[k] : __builtin_nanf("");
@@ -496,55 +486,6 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
     }
     __syncthreads();
     if constexpr (DT > 0) {
-        // Few cells of a tile reach the threshold on real frames (1.5 % of a 4K checkerboard's), and only those can be kept:
-        // when there are at most NCAND of them (r05), each gets a lane that scans its own (2d + 1)^2 window in the staged
-        // region -- kept = no larger value and no second cell of the same value, which is what "equals the window's
-        // maximum, and the maximum occurs once" says (NaN cells, the region outside the frame included, compare false
-        // either way) -- instead of the separable (max, multiplicity) passes over all of the tile's 2048 cells.
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int x = x0 + lane;
-#pragma unroll
-        for (int k = 0; k < TH / 4; k++) {
-            const int r = wv + 4 * k;  // (wave-uniform: a wave is one 64-cell row segment)
-            const float pv = T[(r + DT) * TS + lane + DT];
-            const bool isc = x < cols && y0 + r < rows && (double)pv >= threshold;
-            const unsigned long long m = __ballot(isc);
-            if (m == 0) continue;
-            int at = 0;
-            if (lane == 0) at = atomicAdd(&ncand, __popcll(m));
-            at = __builtin_amdgcn_readfirstlane(at) + __popcll(m & ((1ull << lane) - 1ull));
-            if (isc && at < NCAND) cand[at] = (unsigned short)(r * 64 + lane);
-        }
-        __syncthreads();
-        const int nc = ncand;
-        if (nc <= NCAND) {
-            if ((int)threadIdx.x < nc) {
-                const int id = cand[threadIdx.x], r = id >> 6, c = id & 63;
-                const float pv = T[(r + DT) * TS + c + DT];
-                const float *tp = T + r * TS + c;  // the window's first cell
-                bool larger = false;
-                int same = 0;
-                for (int dy = 0; dy <= 2 * DT; dy++) {
-#pragma unroll
-                    for (int dx = 0; dx <= 2 * DT; dx++) {
-                        const float w = tp[dy * TS + dx];
-                        larger |= w > pv;
-                        same += w == pv ? 1 : 0;
-                    }
-                }
-                if (!larger && same == 1) atomicOr(&keepmask[r], 1ull << c);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < TH / 4; k++) {
-                const int r = wv + 4 * k, y = y0 + r;
-                if (y >= rows) break;  // (wave-uniform)
-                const unsigned long long m = keepmask[r];
-                if (corners && x < cols) corners[(size_t)y * cstride + x] = ((m >> lane) & 1ull) ? T[(r + DT) * TS + lane + DT] : 0.f;
-                if (lane == 0) rowmask[(size_t)y * tiles_x + blockIdx.x] = m;
-            }
-            return;
-        }
         // Four adjacent windows at a time (nms_window4): 4 + 2d staged values serve four cells, and their common
         // part is scanned once -- 14 LDS reads and ~70 instructions per four cells at d = 5 instead of 44 and 132.
         // Row pass: job = (region row, group of four columns); lanes = 16 groups x 4 rows, conflict-free at the odd pitch.
@@ -562,7 +503,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         }
         __syncthreads();
         // column pass: job = (column, group of four rows)
-        const int c = lane;
+        const int c = threadIdx.x & 63, x = x0 + c;
         for (int rg = threadIdx.x >> 6; rg < TH / 4; rg += 4) {  // (wave-uniform: a wave is one 64-cell row segment)
             const int ry0 = 4 * rg;
             if (y0 + ry0 >= rows) break;
