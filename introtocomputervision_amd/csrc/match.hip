@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void bf_knn2_kernel(const float *__restrict__ 
                                                        int qstride, const float *__restrict__ train,
                                                        int nt, int tstride, int dim, int slice_rows,
                                                        int32_t *__restrict__ part_i,
-                                                       float *__restrict__ part_d) {
+                                                       float *__restrict__ part_d, int vec_ok) {
     __shared__ __attribute__((aligned(16))) float Qt[kDC][kQT];
     __shared__ __attribute__((aligned(16))) float Tt[kDC][kTT];
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -63,20 +63,39 @@ __global__ __launch_bounds__(256) void bf_knn2_kernel(const float *__restrict__ 
         // run and written to LDS after them: the global round trip flies under 32 x 32 packed instructions instead of in
         // front of them (r05; the same move as the stereo NCC kernel).
         float pq[8], pt[16];
+        // (a lane reads 8 / 16 consecutive floats of ITS OWN row, so every load instruction touches 64 different cache
+        // lines: as 16-byte loads -- rows and pitches aligned, dim a multiple of 4 -- that is 6 instructions per chunk
+        // instead of 24, and the address unit stops being the co-limiter of the chains; r05)
         auto prefetch = [&](int k0) {
             {
                 const int r = tid & 63, kq = (tid >> 6) * 8;
                 const bool rin = q0 + r < nq;
                 const float *src = query + (size_t)(rin ? q0 + r : 0) * qstride + k0 + kq;
+                if (vec_ok) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) pq[i] = (rin && k0 + kq + i < dim) ? src[i] : 0.f;
+                    for (int i = 0; i < 2; i++) {
+                        const mf4 v = (rin && k0 + kq + 4 * i < dim) ? *reinterpret_cast<const mf4 *>(src + 4 * i) : (mf4)(0.f);
+                        pq[4 * i] = v.x; pq[4 * i + 1] = v.y; pq[4 * i + 2] = v.z; pq[4 * i + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pq[i] = (rin && k0 + kq + i < dim) ? src[i] : 0.f;
+                }
             }
             {
                 const int r = tid & 127, kh = (tid >> 7) * 16;
                 const bool rin = t0 + r < ts1;
                 const float *src = train + (size_t)(rin ? t0 + r : 0) * tstride + k0 + kh;
+                if (vec_ok) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) pt[i] = (rin && k0 + kh + i < dim) ? src[i] : 0.f;
+                    for (int i = 0; i < 4; i++) {
+                        const mf4 v = (rin && k0 + kh + 4 * i < dim) ? *reinterpret_cast<const mf4 *>(src + 4 * i) : (mf4)(0.f);
+                        pt[4 * i] = v.x; pt[4 * i + 1] = v.y; pt[4 * i + 2] = v.z; pt[4 * i + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) pt[i] = (rin && k0 + kh + i < dim) ? src[i] : 0.f;
+                }
             }
         };
         prefetch(0);
@@ -198,9 +217,12 @@ int micv_bf_knn2_dev(micv_ctx *ctx, const float *query, int nq, size_t qstride, 
     MICV_REQUIRE(stride_ok(qstride, dim, 4) && stride_ok(tstride, dim, 4), "micv_bf_knn2: bad stride");
     MICV_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // slices of the train set: enough workgroups for ~2 per CU, whole 128-row passes per slice
+    // slices of the train set: enough workgroups for 2 - 4 per CU, whole 128-row passes per slice
     const int qblocks = (int)cdiv(nq, kQT), passes = (int)cdiv(nt, kTT);
-    int slices = (512 + qblocks - 1) / qblocks;
+    // (r05: four workgroups per CU once every workgroup still has eight passes to run -- 8192 x 8192: 0.438 -> 0.389 ms;
+    // shorter jobs keep two per CU: 5035 x 5035 0.202 against 0.210, 500 x 20000 0.127 against 0.140)
+    const int want_wgs = (long long)qblocks * passes >= 8192 ? 1024 : 512;
+    int slices = (want_wgs + qblocks - 1) / qblocks;
     if (slices > passes) slices = passes;
     if (slices < 1) slices = 1;
     const int slice_rows = (int)cdiv(passes, slices) * kTT;
@@ -210,9 +232,11 @@ int micv_bf_knn2_dev(micv_ctx *ctx, const float *query, int nq, size_t qstride, 
     Carver c(scratch);
     int32_t *part_i = c.take<int32_t>((size_t)slices * nq * 2);
     float *part_d = c.take<float>((size_t)slices * nq * 2);
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(train) | qstride | tstride) & 15) == 0 &&
+                       (dim & 3) == 0;
     bf_knn2_kernel<<<dim3(qblocks, slices), 256, 0, s>>>(query, nq, (int)(qstride / 4), train, nt,
                                                          (int)(tstride / 4), dim, slice_rows, part_i,
-                                                         part_d);
+                                                         part_d, vec_ok);
     MICV_LAUNCH_CHECK();
     bf_merge_kernel<<<cdiv(nq, 256), 256, 0, s>>>(part_i, part_d, nq, slices, idx2, dist2);
     MICV_LAUNCH_CHECK();

@@ -430,8 +430,9 @@ def test_fuzz_lk_option_combinations(shape, seed, kind, win, levels, batch, opts
 
 
 @settings(max_examples=60 * SCALE, **COMMON)
-@given(st.integers(1, 700), st.integers(2, 1500), st.integers(1, 160), seed, st.integers(0, 2), st.floats(0.3, 1.0))  # (k = 2 needs two train rows: the C ABI says so)
-def test_fuzz_bf_knn2_and_ratio(nq, nt, dim, seed, kind, ratio):
+@given(st.integers(1, 700), st.integers(2, 1500), st.one_of(st.integers(1, 160), st.sampled_from([4, 32, 64, 128, 132])), seed, st.integers(0, 2),
+       st.floats(0.3, 1.0), pad, st.booleans())  # (k = 2 needs two train rows: the C ABI says so)
+def test_fuzz_bf_knn2_and_ratio(nq, nt, dim, seed, kind, ratio, pad, shifted):
     """BFMatcher knn2 + ratio test (match.hip; its chunk staging is prefetched since r05) on random set sizes and
     dimensions around the 64 x 128 x 32 tile, with duplicated train rows (ties: the lower index wins) and clustered
     descriptors (near-ties): indices and distances bit-exact against the oracle."""
@@ -453,7 +454,13 @@ def test_fuzz_bf_knn2_and_ratio(nq, nt, dim, seed, kind, ratio):
     q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
     eidx = np.empty((nq, 2), np.int32); edist = np.empty((nq, 2), np.float32)
     knn(q.ctypes.data, nq, dim, t.ctypes.data, nt, dim, dim, eidx.ctypes.data, edist.ctypes.data)
-    idx, dist = match.knnMatch2(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+    # row pitches and base addresses that are / are not multiples of 16 bytes: the staging loads by float4 only when it can
+    dq, dt = dev(q, pad), dev(t, pad)
+    if shifted:
+        wide = torch.zeros((nt, dim + 5), device="cuda")
+        wide[:, 1:1 + dim] = torch.from_numpy(t).cuda()
+        dt = wide[:, 1:1 + dim]
+    idx, dist = match.knnMatch2(dq, dt)
     assert np.array_equal(host(idx), eidx), (nq, nt, dim, kind)
     assert same(host(dist), edist), (nq, nt, dim, kind)
     em = np.empty((nq, 2), np.int32); ed = np.empty(nq, np.float32)
