@@ -423,9 +423,11 @@ int orc_lk_flow_pyr_ex(const float *prev, const float *next, int rows, int cols,
         float *warped = (float *)malloc((size_t)R * C * sizeof(float));
         float *dx = (float *)malloc((size_t)R * C * sizeof(float));
         float *dy = (float *)malloc((size_t)R * C * sizeof(float));
-        g_org_y = g_base_org_y >> k; g_org_x = g_base_org_x >> k;  /* (0 unless orc_lk_flow_pyr_at set them) */
+        const int at = g_base_org_y | g_base_org_x;  /* (0 unless orc_lk_flow_pyr_at set them: then nothing is written here,
+                                                       * so concurrent plain calls -- bench.py's all-cores baseline -- share no state) */
+        if (at) { g_org_y = g_base_org_y >> k; g_org_x = g_base_org_x >> k; }
         orc_lk_warp(np[k], du, dv, R, C, C, warped);               /* :155 */
-        g_org_y = 0; g_org_x = 0;
+        if (at) { g_org_y = 0; g_org_x = 0; }
         rc = orc_lk_flow_ex(pp[k], warped, R, C, C, win, variant, dx, dy, C, k == 0 ? det0_out : NULL);  /* :159 */
         for (size_t i = 0; i < (size_t)R * C; i++) { du[i] = du[i] + dx[i]; dv[i] = dv[i] + dy[i]; } /* :161-162 */
         free(warped); free(dx); free(dy);
