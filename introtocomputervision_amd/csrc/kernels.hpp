@@ -39,6 +39,9 @@ int launch_flow_expand_resize(hipStream_t s, const float *src_u, const float *sr
                               size_t src_pair, float *dst_u, float *dst_v, int drows, int dcols,
                               size_t dst_pair, int batch);
 int launch_warp(hipStream_t s, const float *src, int sstride, const float *du, const float *dv,
-                int fstride, int rows, int cols, float *dst, int dstride);
+                int fstride, int rows, int cols, float *dst, int dstride, int batch = 1, size_t src_img = 0,
+                size_t flow_img = 0, size_t dst_img = 0);
+int launch_pyr_up_batch(hipStream_t s, const float *src_u, const float *src_v, int rows, int cols, size_t src_img,
+                        float *dst_u, float *dst_v, size_t dst_img, float scale, int batch);
 
 }  // namespace micv

@@ -10,12 +10,20 @@ namespace micv {
 
 // ---- generic single-level pieces (one thread per pixel) -------------------------------
 
+// blockIdx.z of the generic kernels = the pair of a batch: element offsets of pair z's images, base flow and outputs
+// (r05: one launch per step for the whole batch instead of one per pair -- window 43 on 8 x 1080p pairs was bound by the
+// host issuing ~330 launches per call).  The product / sum planes of pair z are the five fields from 5 z on.
+struct LkPairs {
+    size_t prev = 0, next = 0, base = 0, out = 0;
+};
+
 // computeGradients x2 + OpticalFlow.cpp:62-70: the five product fields, planar in S.
 __global__ __launch_bounds__(256) void lk_products_kernel(const float *__restrict__ prev,
                                                            int pstride,
                                                            const float *__restrict__ next,
                                                            int nstride, int rows, int cols,
-                                                           float *__restrict__ S, size_t field) {
+                                                           float *__restrict__ S, size_t field, LkPairs pp) {
+    prev += blockIdx.z * pp.prev; next += blockIdx.z * pp.next; S += blockIdx.z * 5 * field;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
@@ -52,7 +60,9 @@ __global__ __launch_bounds__(256) void lk_solve_kernel(const float *__restrict__
                                                         const float *__restrict__ base_u,
                                                         const float *__restrict__ base_v,
                                                         int bstride, float *__restrict__ u,
-                                                        float *__restrict__ v, int ostride) {
+                                                        float *__restrict__ v, int ostride, LkPairs pp) {
+    S += blockIdx.z * 5 * field; u += blockIdx.z * pp.out; v += blockIdx.z * pp.out;
+    if (base_u) { base_u += blockIdx.z * pp.base; base_v += blockIdx.z * pp.base; }
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
@@ -81,7 +91,8 @@ __global__ __launch_bounds__(256) void lk_solve_kernel(const float *__restrict__
 // ds_read_b128 per plane and chunk; the five products of the four new cells are formed from them in registers.
 __global__ __launch_bounds__(256) void lk_products_rows_kernel(const float *__restrict__ prev, int pstride,
                                                                 const float *__restrict__ next, int nstride, int rows,
-                                                                int cols, float *__restrict__ T, size_t field, Taps t) {
+                                                                int cols, float *__restrict__ T, size_t field, Taps t, LkPairs pp) {
+    prev += blockIdx.z * pp.prev; next += blockIdx.z * pp.next; T += blockIdx.z * 5 * field;
     constexpr int TW = 256, TR = 8;
     extern __shared__ float lkg_lds[];
     const int a = t.n / 2, rw = TW + t.n - 1, pw = ((rw + 3) & ~3) + 4;
@@ -192,7 +203,9 @@ __global__ __launch_bounds__(256) void lk_products_rows_kernel(const float *__re
 __global__ __launch_bounds__(256) void lk_cols_solve_kernel(const float *__restrict__ T, size_t field, int rows, int cols,
                                                              Taps t, const float *__restrict__ base_u,
                                                              const float *__restrict__ base_v, int bstride,
-                                                             float *__restrict__ u, float *__restrict__ v, int ostride) {
+                                                             float *__restrict__ u, float *__restrict__ v, int ostride, LkPairs pp) {
+    T += blockIdx.z * 5 * field; u += blockIdx.z * pp.out; v += blockIdx.z * pp.out;
+    if (base_u) { base_u += blockIdx.z * pp.base; base_v += blockIdx.z * pp.base; }
     constexpr int TW = 64, TH = 32, RP = TH / 4, NB = (32 + 62 + 3) / 4;  // n <= 63
     extern __shared__ float lkg_lds[];
     const int a = t.n / 2, ph = TH + t.n - 1;  // staged rows
@@ -280,7 +293,8 @@ typedef float lk_v2f __attribute__((ext_vector_type(2)));
 template <int N>
 __global__ __launch_bounds__(256) void lk_products_rows_pk_kernel(const float *__restrict__ prev, int pstride,
                                                                    const float *__restrict__ next, int nstride, int rows,
-                                                                   int cols, float *__restrict__ T, size_t field, Taps t) {
+                                                                   int cols, float *__restrict__ T, size_t field, Taps t, LkPairs pp) {
+    prev += blockIdx.z * pp.prev; next += blockIdx.z * pp.next; T += blockIdx.z * 5 * field;
     constexpr int TW = 256, TR = 8, A = N / 2, RW = TW + N - 1, PW = ((RW + 3) & ~3) + 4;
     constexpr int NV4 = (N + 3 + 3) / 4;  // float4 of a thread's window: values 0 .. N + 2
     static_assert(4 * 63 + 4 * NV4 <= PW, "window reads stay inside a staged row");
@@ -393,7 +407,9 @@ template <int N>
 __global__ __launch_bounds__(256) void lk_cols_solve_pk_kernel(const float *__restrict__ T, size_t field, int rows, int cols,
                                                                 Taps t, const float *__restrict__ base_u,
                                                                 const float *__restrict__ base_v, int bstride,
-                                                                float *__restrict__ u, float *__restrict__ v, int ostride) {
+                                                                float *__restrict__ u, float *__restrict__ v, int ostride, LkPairs pp) {
+    T += blockIdx.z * 5 * field; u += blockIdx.z * pp.out; v += blockIdx.z * pp.out;
+    if (base_u) { base_u += blockIdx.z * pp.base; base_v += blockIdx.z * pp.base; }
     constexpr int TW = 128, TH = 32, RP = 8, A = N / 2, PH = TH + N - 1, V4 = TW / 4, NB = (PH * V4 + 255) / 256;
     static_assert((PH * V4) % 64 == 0, "whole waves of staging slots");
     typedef __attribute__((address_space(3))) void lds_void;
@@ -516,7 +532,9 @@ __global__ __launch_bounds__(256) void lk_warp_kernel(const float *__restrict__ 
                                                        const float *__restrict__ du,
                                                        const float *__restrict__ dv, int fstride,
                                                        int rows, int cols,
-                                                       float *__restrict__ dst, int dstride) {
+                                                       float *__restrict__ dst, int dstride, size_t src_img, size_t flow_img,
+                                                       size_t dst_img) {
+    src += blockIdx.z * src_img; du += blockIdx.z * flow_img; dv += blockIdx.z * flow_img; dst += blockIdx.z * dst_img;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows) return;
@@ -539,7 +557,9 @@ __global__ __launch_bounds__(256) void lk_warp_tiled_kernel(const float *__restr
                                                              const float *__restrict__ du,
                                                              const float *__restrict__ dv, int fstride,
                                                              int rows, int cols,
-                                                             float *__restrict__ dst, int dstride) {
+                                                             float *__restrict__ dst, int dstride, size_t src_img, size_t flow_img,
+                                                             size_t dst_img) {
+    src += blockIdx.z * src_img; du += blockIdx.z * flow_img; dv += blockIdx.z * flow_img; dst += blockIdx.z * dst_img;
     __shared__ __attribute__((aligned(16))) float N[WT_NH * WT_NW];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * WT_W, y0 = blockIdx.y * WT_H;
@@ -593,18 +613,19 @@ __global__ __launch_bounds__(256) void flow_bound_kernel(const float *__restrict
 }
 
 int launch_warp(hipStream_t s, const float *src, int sstride, const float *du, const float *dv,
-                int fstride, int rows, int cols, float *dst, int dstride) {
+                int fstride, int rows, int cols, float *dst, int dstride, int batch, size_t src_img, size_t flow_img,
+                size_t dst_img) {
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(du) | reinterpret_cast<uintptr_t>(dv) |
                        reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
-                     ((sstride | fstride | dstride | cols) & 3) == 0;
+                     ((sstride | fstride | dstride | cols) & 3) == 0 && ((src_img | flow_img | dst_img) & 3) == 0;
     if (vec) {
-        lk_warp_tiled_kernel<<<dim3(cdiv(cols, WT_W), cdiv(rows, WT_H)), 256, 0, s>>>(src, sstride, du, dv, fstride, rows, cols,
-                                                                                   dst, dstride);
+        lk_warp_tiled_kernel<<<dim3(cdiv(cols, WT_W), cdiv(rows, WT_H), batch), 256, 0, s>>>(src, sstride, du, dv, fstride, rows, cols,
+                                                                                          dst, dstride, src_img, flow_img, dst_img);
         MICV_LAUNCH_CHECK();
         return MICV_OK;
     }
-    lk_warp_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4)), 256, 0, s>>>(src, sstride, du, dv, fstride,
-                                                                        rows, cols, dst, dstride);
+    lk_warp_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 4), batch), 256, 0, s>>>(src, sstride, du, dv, fstride,
+                                                                               rows, cols, dst, dstride, src_img, flow_img, dst_img);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
@@ -626,19 +647,23 @@ static int lk_generic_form(const micv_ctx *ctx) {
 static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const float *next,
                             int nstride, int rows, int cols, int win, const float *base_u,
                             const float *base_v, int bstride, float *u, float *v, int ostride,
-                            float *scratch, int form = 0) {
+                            float *scratch, int form = 0, int batch = 1, LkPairs pp = LkPairs()) {
+    // scratch: 10 planar fields PER PAIR -- the five product fields of every pair first, then the five row sums of every
+    // pair (so the four-launch form's filter launches see 5 x batch fields one field apart)
     const size_t n = (size_t)rows * cols;
-    float *S = scratch, *T = scratch + 5 * n;
+    float *S = scratch, *T = scratch + 5 * n * batch;
+    const unsigned zb = (unsigned)batch;
     Taps g;
     gaussian_taps(win, (double)((float)win / 3.f), &g);  // OpticalFlow.cpp:73
     // form: 0 = by size, 2 = always the four launches, 1 = always two (MICV_OPT_LK_FORCE_GENERIC 2 / 1 on a window
-    // the fused kernels do not cover).  Small levels are latency-bound and the two long kernels lose there.
+    // the fused kernels do not cover).  Small levels are latency-bound and the two long kernels lose there (per pair:
+    // scaling the sizes by the batch was measured neutral, 0.780 against 0.787 ms at 8 x 1080p, window 43).
     const bool two = form == 1 || (form == 0 && (size_t)rows * cols >= kTwoLaunchMinPixels);
     if (g.n == 43 && (form == 1 || (form == 0 && (size_t)rows * cols >= kTwoLaunchMinPixelsUnrolled))) {  // config/ps5.yaml:11
         constexpr int N = 43;
         const size_t lds_a = (size_t)3 * 8 * ((((256 + N - 1) + 3) & ~3) + 4) * sizeof(float);
-        lk_products_rows_pk_kernel<N><<<dim3(cdiv(cols, 256), cdiv(rows, 8)), 256, lds_a, s>>>(prev, pstride, next, nstride,
-                                                                                               rows, cols, T, n, g);
+        lk_products_rows_pk_kernel<N><<<dim3(cdiv(cols, 256), cdiv(rows, 8), zb), 256, lds_a, s>>>(prev, pstride, next, nstride,
+                                                                                                   rows, cols, T, n, g, pp);
         MICV_LAUNCH_CHECK();
         static thread_local int attr_dev = -1;
         int dev = 0;
@@ -648,27 +673,27 @@ static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_dev = dev;
         }
-        lk_cols_solve_pk_kernel<N><<<dim3(cdiv(cols, 128), cdiv(rows, 32)), 256, (size_t)2 * 128 * (32 + N - 1) * sizeof(float), s>>>(
-            T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride);
+        lk_cols_solve_pk_kernel<N><<<dim3(cdiv(cols, 128), cdiv(rows, 32), zb), 256, (size_t)2 * 128 * (32 + N - 1) * sizeof(float), s>>>(
+            T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride, pp);
         MICV_LAUNCH_CHECK();
         return MICV_OK;
     }
     if (two && g.n >= 5) {  // two launches: images -> row sums -> flow
         const size_t lds_a = (size_t)3 * 8 * ((((256 + g.n - 1) + 3) & ~3) + 4) * sizeof(float);
-        lk_products_rows_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 8)), 256, lds_a, s>>>(prev, pstride, next, nstride, rows,
-                                                                                         cols, T, n, g);
+        lk_products_rows_kernel<<<dim3(cdiv(cols, 256), cdiv(rows, 8), zb), 256, lds_a, s>>>(prev, pstride, next, nstride, rows,
+                                                                                             cols, T, n, g, pp);
         MICV_LAUNCH_CHECK();
-        lk_cols_solve_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32)), 256, (size_t)64 * (32 + g.n - 1) * sizeof(float), s>>>(
-            T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride);
+        lk_cols_solve_kernel<<<dim3(cdiv(cols, 64), cdiv(rows, 32), zb), 256, (size_t)64 * (32 + g.n - 1) * sizeof(float), s>>>(
+            T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride, pp);
         MICV_LAUNCH_CHECK();
         return MICV_OK;
     }
-    const dim3 grid(cdiv(cols, 64), cdiv(rows, 4));
-    lk_products_kernel<<<grid, 256, 0, s>>>(prev, pstride, next, nstride, rows, cols, S, n);
+    const dim3 grid(cdiv(cols, 64), cdiv(rows, 4), zb);
+    lk_products_kernel<<<grid, 256, 0, s>>>(prev, pstride, next, nstride, rows, cols, S, n, pp);
     MICV_LAUNCH_CHECK();
-    MICV_TRY(launch_filter_rows(s, S, cols, n, T, cols, n, rows, cols, 5, g));
-    MICV_TRY(launch_filter_cols(s, T, cols, n, S, cols, n, rows, cols, 5, g));
-    lk_solve_kernel<<<grid, 256, 0, s>>>(S, n, rows, cols, base_u, base_v, bstride, u, v, ostride);
+    MICV_TRY(launch_filter_rows(s, S, cols, n, T, cols, n, rows, cols, 5 * batch, g));
+    MICV_TRY(launch_filter_cols(s, T, cols, n, S, cols, n, rows, cols, 5 * batch, g));
+    lk_solve_kernel<<<grid, 256, 0, s>>>(S, n, rows, cols, base_u, base_v, bstride, u, v, ostride, pp);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
@@ -814,9 +839,11 @@ static int lk_chain_fused(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, 
     return MICV_OK;
 }
 
-// Generic path (any odd window): the same chain with the one-thread-per-pixel kernels, pair by pair.
+// Generic path (any odd window): the same chain with the generic kernels, every step ONE launch for all pairs of the
+// chain (r05; blockIdx.z = pair): a level is at most seven launches whatever the batch -- base flow (a memset, the batched
+// 2 x pyrUp, or the fused path's expand + resize launch for odd sizes), lk::warp, and the two to four launches of the level.
 static int lk_chain_generic(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c, int win, float *warped,
-                            float *gen, float *tmp_a, float *tmp_b) {
+                            float *gen) {
     hipStream_t s = c.s;
     int cur = 0, fr = 0, fc = 0;
     for (int level = 0; level < plan.levels; level++) {
@@ -825,34 +852,28 @@ static int lk_chain_generic(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c
         const bool last = (k == 0);
         const size_t lvl_elems = (size_t)R * C;
         if (c.profile) MICV_TRY(ctx->prof_begin(k, s));
-        for (int b = 0; b < c.nb; b++) {
-            const float *pk = last ? c.prev + b * c.pair_elems : c.ppyr[k] + b * lvl_elems;
-            const float *nk = last ? c.next + b * c.pair_elems : c.npyr[k] + b * lvl_elems;
-            const int ist = last ? c.stride : C;
-            float *bu = c.fu[cur ^ 1] + b * lvl_elems, *bv = c.fv[cur ^ 1] + b * lvl_elems;
-            if (level == 0) {
-                MICV_HIP(hipMemsetAsync(bu, 0, lvl_elems * 4, s));  // OpticalFlow.cpp:132-133
-                MICV_HIP(hipMemsetAsync(bv, 0, lvl_elems * 4, s));
-            } else {
-                const float *cu = c.fu[cur] + b * (size_t)fr * fc;
-                const float *cv = c.fv[cur] + b * (size_t)fr * fc;
-                if (2 * fr == R && 2 * fc == C) {
-                    MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, bu, C, 2.f, tmp_b));
-                    MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, bv, C, 2.f, tmp_b));
-                } else {
-                    MICV_TRY(launch_pyr_up(s, cu, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
-                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bu, R, C, C));
-                    MICV_TRY(launch_pyr_up(s, cv, fr, fc, fc, tmp_a, 2 * fc, 2.f, tmp_b));
-                    MICV_TRY(launch_resize_linear(s, tmp_a, 2 * fr, 2 * fc, 2 * fc, bv, R, C, C));
-                }
-            }
-            MICV_TRY(launch_warp(s, nk, ist, bu, bv, C, R, C, warped, C));  // :155
-            // in place is fine here: lk_solve_kernel reads and writes the same pixel in one thread
-            float *ou = last ? c.u + b * c.opair_elems : bu;
-            float *ov = last ? c.v + b * c.opair_elems : bv;
-            MICV_TRY(lk_level_generic(s, pk, ist, warped, C, R, C, win, bu, bv, C, ou, ov,
-                                      last ? c.ostride : C, gen, lk_generic_form(ctx)));  // :159-162
+        const float *pk = last ? c.prev : c.ppyr[k];
+        const float *nk = last ? c.next : c.npyr[k];
+        const int ist = last ? c.stride : C;
+        const size_t img_pair = last ? c.pair_elems : lvl_elems;
+        float *bu = c.fu[cur ^ 1], *bv = c.fv[cur ^ 1];  // this level's base flow, pairs lvl_elems apart
+        if (level == 0) {
+            MICV_HIP(hipMemsetAsync(bu, 0, lvl_elems * 4 * c.nb, s));  // OpticalFlow.cpp:132-133
+            MICV_HIP(hipMemsetAsync(bv, 0, lvl_elems * 4 * c.nb, s));
+        } else if (2 * fr == R && 2 * fc == C) {
+            MICV_TRY(launch_pyr_up_batch(s, c.fu[cur], c.fv[cur], fr, fc, (size_t)fr * fc, bu, bv, lvl_elems, 2.f, c.nb));  // :140-145
+        } else {  // :148-151, odd sizes: 2 x pyrUp then cv::resize, one launch (the fused path's)
+            MICV_TRY(launch_flow_expand_resize(s, c.fu[cur], c.fv[cur], fr, fc, (size_t)fr * fc, bu, bv, R, C, lvl_elems, c.nb));
         }
+        MICV_TRY(launch_warp(s, nk, ist, bu, bv, C, R, C, warped, C, c.nb, img_pair, lvl_elems, lvl_elems));  // :155
+        // in place is fine here: the solve reads and writes the same pixel in one thread
+        LkPairs pp;
+        pp.prev = img_pair;
+        pp.next = lvl_elems;  // the warped frames
+        pp.base = lvl_elems;
+        pp.out = last ? c.opair_elems : lvl_elems;
+        MICV_TRY(lk_level_generic(s, pk, ist, warped, C, R, C, win, bu, bv, C, last ? c.u : bu, last ? c.v : bv,
+                                  last ? c.ostride : C, gen, lk_generic_form(ctx), c.nb, pp));  // :159-162
         if (c.profile) MICV_TRY(ctx->prof_end(k, s));
         cur ^= 1;
         fr = R;
@@ -874,10 +895,10 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // at level-0 size per pair, and the generic path's temporaries.
     const size_t flow_elems = (n0 + 63) & ~size_t(63);
     size_t total = Carver::need(plan.pyr_elems * batch, 4) * 2 + Carver::need(flow_elems * batch, 4) * 4;
-    // Generic path: the pairs of a batch run on up to four forked streams (r04), each with its own temporaries: the
-    // coarse levels are launches of a few workgroups whose time is latency, and the pairs' launches overlap.
-    const int gen_groups = fused ? 0 : (batch < 4 ? batch : 4);
-    if (!fused) total += (Carver::need(n0, 4) * 3 + Carver::need(lk_generic_scratch(rows, cols), 4)) * gen_groups;
+    // Generic path: every step is one launch for the whole batch (r05; r04 ran the pairs on four forked streams, one
+    // launch per pair and step -- ~330 launches per call at 8 pairs and 5 levels, and the host was the limit): the warped
+    // frames and the ten product / sum planes of every pair.
+    if (!fused) total += Carver::need(n0 * batch, 4) + Carver::need(lk_generic_scratch(rows, cols) * batch, 4);
     // MICV_OPT_LK_SPLIT: the padded gradient planes of the largest level some launch of the chain will split (the
     // levels run one after the other on the chain's stream and share the block)
     size_t grad_elems = 0;
@@ -987,22 +1008,9 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
 
     if (!fused) {
         ctx->prof_pairs = batch;
-        if (gen_groups > 1) MICV_TRY(ctx->fork(s, gen_groups - 1));
-        int rc = MICV_OK;
-        for (int g = 0; g < gen_groups && rc == MICV_OK; g++) {
-            float *warped = carve.take<float>(n0), *tmp_a = carve.take<float>(n0), *tmp_b = carve.take<float>(n0);
-            float *gen = carve.take<float>(lk_generic_scratch(rows, cols));
-            const int b0 = (int)((long long)batch * g / gen_groups);
-            const int nb = (int)((long long)batch * (g + 1) / gen_groups) - b0;
-            if (g == 0) ctx->prof_pairs = nb;  // the profiled launches are group 0's
-            rc = lk_chain_generic(ctx, plan, make_chain(g == 0 ? s : ctx->aux_stream[g - 1], b0, nb, g == 0), win, warped, gen,
-                                  tmp_a, tmp_b);
-        }
-        if (gen_groups > 1) {  // always re-join, also after an error
-            const int rcj = ctx->join(s, gen_groups - 1);
-            if (rc == MICV_OK) rc = rcj;
-        }
-        return rc;
+        float *warped = carve.take<float>(n0 * batch);
+        float *gen = carve.take<float>(lk_generic_scratch(rows, cols) * batch);
+        return lk_chain_generic(ctx, plan, make_chain(s, 0, batch, true), win, warped, gen);
     }
 
     // Fused path: the batch is split into groups of pairs whose chains run on forked HIP streams and

@@ -167,9 +167,18 @@ __global__ __launch_bounds__(256) void pyr_up_cols_kernel(const float *__restric
 // HBM: 1080p -> 2160p moves 8.3 + 33.2 MB instead of 8.3 + 2 x 16.6 + 16.6 + 33.2.  Same chains as the
 // two-launch form (taps left -> right, then top -> bottom, fmaf from +0, then * scale): same bits.
 constexpr int PU_W = 128, PU_H = 32, PU_CW = PU_W / 2 + 2, PU_CH = PU_H / 2 + 2, PU_CP = PU_CW + 2;
+// blockIdx.z = 2 * image + field when a second field (src2 / dst2) is given, the image otherwise (launch_pyr_up_batch).
 __global__ __launch_bounds__(256) void pyr_up_tiled_kernel(const float *__restrict__ src, int sstride,
                                                             float *__restrict__ dst, int dstride, int rows,
-                                                            int cols, float scale, int vec_ok) {
+                                                            int cols, float scale, int vec_ok,
+                                                            const float *__restrict__ src2 = nullptr, float *__restrict__ dst2 = nullptr,
+                                                            size_t src_img = 0, size_t dst_img = 0) {
+    {
+        const unsigned z = blockIdx.z, img = src2 ? z >> 1 : z;
+        if (src2 && (z & 1)) { src = src2; dst = dst2; }
+        src += img * src_img;
+        dst += img * dst_img;
+    }
     __shared__ float Cs[PU_CH][PU_CP];                              // coarse rows r0-1 .., columns c0-1 ..
     __shared__ __attribute__((aligned(16))) float Rp[PU_CH][PU_W];  // row pass: coarse row x fine column
     const int tid = threadIdx.x;
@@ -523,6 +532,17 @@ int launch_pyr_up(hipStream_t s, const float *src, int rows, int cols, int sstri
     MICV_LAUNCH_CHECK();
     pyr_up_cols_kernel<<<dim3(cdiv(2 * cols, 64), cdiv(2 * rows, 4)), 256, 0, s>>>(
         tmp, dst, dstride, rows, cols, scale);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
+// 2 * pyrUp of both flow fields of `batch` dense images in one launch (OpticalFlow.cpp:140-145 for a whole batch).
+int launch_pyr_up_batch(hipStream_t s, const float *src_u, const float *src_v, int rows, int cols, size_t src_img,
+                        float *dst_u, float *dst_v, size_t dst_img, float scale, int batch) {
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(dst_u) | reinterpret_cast<uintptr_t>(dst_v)) & 15) == 0 && ((2 * cols) & 3) == 0 &&
+                       (dst_img & 3) == 0;
+    pyr_up_tiled_kernel<<<dim3(cdiv(2 * cols, PU_W), cdiv(2 * rows, PU_H), 2 * batch), 256, 0, s>>>(
+        src_u, cols, dst_u, 2 * cols, rows, cols, scale, vec_ok, src_v, dst_v, src_img, dst_img);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }

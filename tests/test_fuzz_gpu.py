@@ -633,3 +633,22 @@ def test_fuzz_host_entry_points_match_the_device_ones(shape, pad, seed, op):
         assert np.array_equal(d, host(dd))
         hist = rng.integers(0, 40, (rows, cols), dtype=np.uint8)
         assert np.array_equal(mhi.calcMotionHistory(hist.copy(), d, 30), host(mhi.calcMotionHistory(dev(hist), dd, 30)))
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(st.tuples(st.integers(8, 130), st.integers(8, 300)), seed, kind, st.sampled_from([5, 9, 13, 23, 27, 43, 63]), st.integers(1, 4),
+       st.integers(1, 5), st.sampled_from([0, 0, 2, 3]))
+def test_fuzz_lk_generic_windows_batched(shape, seed, kind, win, levels, batch, form):
+    """The generic chain (windows without a fused kernel), one launch per step for the whole batch: every pair of a random
+    batch against the oracle, in the size-dependent default and in the forced four- and two-launch forms."""
+    from introtocomputervision_amd import lk, _capi
+    rows, cols = shape
+    levels = max(1, min(levels, int(np.log2(min(rows, cols)))))
+    prev = np.stack([image(seed + i, rows, cols, kind) for i in range(batch)])
+    nxt = np.stack([np.roll(p, (1, -2), (0, 1)) for p in prev])
+    ctx = _capi.Context(0)
+    ctx.set_option(_capi.OPT_LK_FORCE_GENERIC, form)
+    u, v = lk.calcOpticalFlowPyrBatch(torch.from_numpy(prev).cuda(), torch.from_numpy(nxt).cuda(), win, levels, ctx=ctx)
+    for b in range(batch):
+        eu, ev = orc.lk_flow_pyr(prev[b], nxt[b], win, levels)
+        assert same(host(u[b]), eu) and same(host(v[b]), ev), (rows, cols, win, levels, batch, b, form)

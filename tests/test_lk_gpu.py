@@ -887,3 +887,23 @@ def test_strip_launch_is_bit_exact(mods, rows, cols, levels, batch, blocks):
     if rows * cols * levels <= 1080 * 1920 * 5:
         eu, ev = orc.lk_flow_pyr(prev[batch - 1], nxt[batch - 1], 15, levels)
         assert np.array_equal(host(u[batch - 1]), eu, equal_nan=True) and np.array_equal(host(v[batch - 1]), ev, equal_nan=True)
+
+
+@pytest.mark.parametrize("rows,cols,levels,batch,win", [(270, 480, 3, 3, 43), (135, 241, 3, 2, 9), (540, 960, 4, 2, 43), (97, 400, 2, 5, 23),
+                                                        (64, 64, 3, 1, 5), (300, 332, 4, 4, 13), (200, 1030, 2, 2, 63), (1080, 1920, 5, 2, 43)])
+def test_generic_windows_batched(mods, rows, cols, levels, batch, win):
+    """Windows without a fused kernel (config/ps5.yaml runs 43) through the batch entry point: since r05 every step of the
+    generic chain is ONE launch for all pairs (blockIdx.z = pair; r04: one launch per pair on four forked streams, and the host
+    was the limit) -- each pair against the oracle, odd level sizes (the expand + resize launch) and the unrolled window-43
+    kernels at 1080p included, plus the caller's own output buffers with a row pitch."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    pairs = [synth.lk_pair(0x5EED0100 + 7 * i, rows, cols, 2 + i % 2, -1 - i % 3) for i in range(batch)]
+    prev = np.stack([p for p, _ in pairs])
+    nxt = np.stack([n for _, n in pairs])
+    bu, bv = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), win, levels)
+    for b in (range(batch) if rows * cols <= 540 * 960 else (0, batch - 1)):
+        eu, ev = orc.lk_flow_pyr(prev[b], nxt[b], win, levels)
+        assert np.array_equal(host(bu[b]), eu) and np.array_equal(host(bv[b]), ev), b
+    su, sv = lk.calcOpticalFlowPyr(dev(prev[batch - 1]), dev(nxt[batch - 1]), win, levels)
+    assert torch.equal(su, bu[batch - 1]) and torch.equal(sv, bv[batch - 1])
