@@ -895,7 +895,7 @@ def test_generic_windows_batched(mods, rows, cols, levels, batch, win):
     """Windows without a fused kernel (config/ps5.yaml runs 43) through the batch entry point: since r05 every step of the
     generic chain is ONE launch for all pairs (blockIdx.z = pair; r04: one launch per pair on four forked streams, and the host
     was the limit) -- each pair against the oracle, odd level sizes (the expand + resize launch) and the unrolled window-43
-    kernels at 1080p included, plus the caller's own output buffers with a row pitch."""
+    kernels at 1080p included (pitched buffers: test_batch_entry_point_with_pitched_buffers)."""
     lk, pyr = mods
     from introtocomputervision_amd import synth
     pairs = [synth.lk_pair(0x5EED0100 + 7 * i, rows, cols, 2 + i % 2, -1 - i % 3) for i in range(batch)]
@@ -907,3 +907,36 @@ def test_generic_windows_batched(mods, rows, cols, levels, batch, win):
         assert np.array_equal(host(bu[b]), eu) and np.array_equal(host(bv[b]), ev), b
     su, sv = lk.calcOpticalFlowPyr(dev(prev[batch - 1]), dev(nxt[batch - 1]), win, levels)
     assert torch.equal(su, bu[batch - 1]) and torch.equal(sv, bv[batch - 1])
+
+
+@pytest.mark.parametrize("win", [9, 43, 15])
+def test_batch_entry_point_with_pitched_buffers(mods, win):
+    """micv_lk_flow_pyr_batch_dev on buffers with a row pitch and a pair stride that are not the dense ones (and not
+    multiples of 16 bytes: the generic chain's batched launches fall back to their scalar forms where a kernel wants
+    aligned rows), inputs and outputs alike: the same bits as the dense call."""
+    lk, pyr = mods
+    from introtocomputervision_amd import synth
+    from introtocomputervision_amd._capi import lib, check, Context
+    rows, cols, levels, batch = 150, 262, 3, 3
+    pairs = [synth.lk_pair(0x5EED0200 + i, rows, cols, 2, -1) for i in range(batch)]
+    prev = torch.from_numpy(np.stack([p for p, _ in pairs])).cuda()
+    nxt = torch.from_numpy(np.stack([n for _, n in pairs])).cuda()
+    ctx = Context(0)
+    du, dv = lk.calcOpticalFlowPyrBatch(prev, nxt, win, levels, ctx=ctx)
+    for pitch, extra in ((cols + 3, 5), (cols + 4, 8)):
+        pair = rows * pitch + extra
+        def wide(src=None):
+            t = torch.full((batch * pair,), float("nan"), device="cuda")
+            if src is not None:
+                for b in range(batch):
+                    t[b * pair: b * pair + rows * pitch].view(rows, pitch)[:, :cols] = src[b]
+            return t
+        wp, wn, wu, wv = wide(prev), wide(nxt), wide(), wide()
+        check(lib.micv_lk_flow_pyr_batch_dev(ctx.handle, wp.data_ptr(), wn.data_ptr(), batch, pair * 4, rows, cols, pitch * 4,
+                                             win, levels, wu.data_ptr(), wv.data_ptr(), pair * 4, pitch * 4,
+                                             torch.cuda.current_stream().cuda_stream))
+        for b in range(batch):
+            gu = wu[b * pair: b * pair + rows * pitch].view(rows, pitch)
+            gv = wv[b * pair: b * pair + rows * pitch].view(rows, pitch)
+            assert torch.equal(gu[:, :cols], du[b]) and torch.equal(gv[:, :cols], dv[b]), (win, pitch, b)
+            assert bool(torch.isnan(gu[:, cols:]).all()) and bool(torch.isnan(gv[:, cols:]).all())  # nothing written past a row
