@@ -403,20 +403,26 @@ __global__ __launch_bounds__(256) void lk_products_rows_pk_kernel(const float *_
 // assembly -- and every window row is read once into a register window that slides with the taps.  Tiles that
 // lie inside the image (16-byte aligned rows) stage by LDS-DMA, field f + 1 into the second buffer while field f
 // is summed: no staging registers, no ds_write.  Edge tiles load element by element, columns clamped.
-template <int N>
+template <int N, int TW = 128>
 __global__ __launch_bounds__(256) void lk_cols_solve_pk_kernel(const float *__restrict__ T, size_t field, int rows, int cols,
                                                                 Taps t, const float *__restrict__ base_u,
                                                                 const float *__restrict__ base_v, int bstride,
                                                                 float *__restrict__ u, float *__restrict__ v, int ostride, LkPairs pp) {
     T += blockIdx.z * 5 * field; u += blockIdx.z * pp.out; v += blockIdx.z * pp.out;
     if (base_u) { base_u += blockIdx.z * pp.base; base_v += blockIdx.z * pp.base; }
-    constexpr int TW = 128, TH = 32, RP = 8, A = N / 2, PH = TH + N - 1, V4 = TW / 4, NB = (PH * V4 + 255) / 256;
-    static_assert((PH * V4) % 64 == 0, "whole waves of staging slots");
+    // TW = 128: a wave is 64 column pairs x 8 rows, the tile 128 x 32.  TW = 64 (r05): a wave is 32 column pairs x two groups
+    // of 8 rows, the tile 64 x 64 -- the column pass stages TH + N - 1 rows of every field for TH outputs, 2.3 x the planes'
+    // bytes at 32 rows and window 43 and 1.66 x at 64, in the same LDS (two workgroups per CU either way).
+    constexpr int LW = TW / 2, RG = 64 / LW;  // lanes per row of pairs, row groups per wave
+    constexpr int TH = 32 * RG, RP = 8, A = N / 2, PH0 = TH + N - 1, V4 = TW / 4;
+    constexpr int PH = PH0 + ((64 - (PH0 * V4) % 64) % 64) / V4;  // staged rows: whole waves of staging slots (the extra rows are never read)
+    constexpr int NB = (PH * V4 + 255) / 256;
+    static_assert((PH * V4) % 64 == 0 && ((64 - (PH0 * V4) % 64) % 64) % V4 == 0, "whole waves of staging slots");
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void glb_cvoid;
     extern __shared__ float lkg_lds[];
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int lane = threadIdx.x & 63, rb = (threadIdx.x >> 6) * RP;
+    const int lane = threadIdx.x & 63, cl = lane % LW, rb = ((threadIdx.x >> 6) * RG + lane / LW) * RP;
     const bool dma = (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(T) & 15) == 0 && x0 + TW <= cols;  // uniform
     // staging slot i = float4 (i % V4) of staged row i / V4; its first element's offset inside a field (a field is
     // below 2^31 elements: the callers' size checks)
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(256) void lk_cols_solve_pk_kernel(const float *__re
         float *cur = lkg_lds + (f & 1) * (PH * TW), *nxt = lkg_lds + ((f + 1) & 1) * (PH * TW);
         __syncthreads();  // field f is staged (and field f - 1, in the other buffer, has been summed by every wave)
         if (f < 4) stage(T + (f + 1) * field, nxt);
-        const float *lp = cur + rb * TW + 2 * lane;
+        const float *lp = cur + rb * TW + 2 * cl;
 #pragma unroll
         for (int j = 0; j < RP; j++) acc[f][j] = (lk_v2f){0.f, 0.f};
         lk_v2f W[N + RP - 1];
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256) void lk_cols_solve_pk_kernel(const float *__re
         asm volatile("" : "+v"(acc[f][0]), "+v"(acc[f][1]), "+v"(acc[f][2]), "+v"(acc[f][3]), "+v"(acc[f][4]), "+v"(acc[f][5]),
                           "+v"(acc[f][6]), "+v"(acc[f][7])
                      :: "memory");
-    const int x = x0 + 2 * lane;
+    const int x = x0 + 2 * cl;
     if (x >= cols) return;
     const bool pair_ok = x + 1 < cols && (ostride & 1) == 0 && (bstride & 1) == 0 &&
                          ((reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(base_u) |
@@ -668,12 +674,13 @@ static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const
         static thread_local int attr_dev = -1;
         int dev = 0;
         MICV_HIP(hipGetDevice(&dev));
-        if (attr_dev != dev) {  // two staging buffers: 74 KB of dynamic LDS
-            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_cols_solve_pk_kernel<N>),
+        if (attr_dev != dev) {  // two staging buffers: 54 KB of dynamic LDS
+            MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lk_cols_solve_pk_kernel<N, 64>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_dev = dev;
         }
-        lk_cols_solve_pk_kernel<N><<<dim3(cdiv(cols, 128), cdiv(rows, 32), zb), 256, (size_t)2 * 128 * (32 + N - 1) * sizeof(float), s>>>(
+        // 64 x 64 tiles (r05; 128 x 32 before): 8 x 1080p 0.777 -> 0.761 ms per call, 4 pairs 0.451 -> 0.444, one pair the same
+        lk_cols_solve_pk_kernel<N, 64><<<dim3(cdiv(cols, 64), cdiv(rows, 64), zb), 256, (size_t)2 * 64 * (64 + N - 1 + 2) * sizeof(float), s>>>(
             T, n, rows, cols, g, base_u, base_v, bstride, u, v, ostride, pp);
         MICV_LAUNCH_CHECK();
         return MICV_OK;
