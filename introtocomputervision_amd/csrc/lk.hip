@@ -662,10 +662,12 @@ static int lk_level_generic(hipStream_t s, const float *prev, int pstride, const
     Taps g;
     gaussian_taps(win, (double)((float)win / 3.f), &g);  // OpticalFlow.cpp:73
     // form: 0 = by size, 2 = always the four launches, 1 = always two (MICV_OPT_LK_FORCE_GENERIC 2 / 1 on a window
-    // the fused kernels do not cover).  Small levels are latency-bound and the two long kernels lose there (per pair:
-    // scaling the sizes by the batch was measured neutral, 0.780 against 0.787 ms at 8 x 1080p, window 43).
-    const bool two = form == 1 || (form == 0 && (size_t)rows * cols >= kTwoLaunchMinPixels);
-    if (g.n == 43 && (form == 1 || (form == 0 && (size_t)rows * cols >= kTwoLaunchMinPixelsUnrolled))) {  // config/ps5.yaml:11
+    // the fused kernels do not cover).  Small levels are latency-bound and the two long kernels lose there.
+    // (the sizes are the LAUNCH's: a batch of small levels fills the GPU like one large level -- window 43, 8 x 1080p: 0.757 ->
+    // 0.746 ms per call, 4 pairs 0.445 -> 0.437)
+    const size_t launch_px = (size_t)rows * cols * batch;
+    const bool two = form == 1 || (form == 0 && launch_px >= kTwoLaunchMinPixels);
+    if (g.n == 43 && (form == 1 || (form == 0 && launch_px >= kTwoLaunchMinPixelsUnrolled))) {  // config/ps5.yaml:11
         constexpr int N = 43;
         const size_t lds_a = (size_t)3 * 8 * ((((256 + N - 1) + 3) & ~3) + 4) * sizeof(float);
         lk_products_rows_pk_kernel<N><<<dim3(cdiv(cols, 256), cdiv(rows, 8), zb), 256, lds_a, s>>>(prev, pstride, next, nstride,
