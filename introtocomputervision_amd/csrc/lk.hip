@@ -907,7 +907,10 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // Generic path: every step is one launch for the whole batch (r05; r04 ran the pairs on four forked streams, one
     // launch per pair and step -- ~330 launches per call at 8 pairs and 5 levels, and the host was the limit): the warped
     // frames and the ten product / sum planes of every pair.
-    if (!fused) total += Carver::need(n0 * batch, 4) + Carver::need(lk_generic_scratch(rows, cols) * batch, 4);
+    // (at most kGenChunk pairs per launch: blockIdx.z carries 5 x pairs fields in the four-launch form)
+    constexpr int kGenChunk = 4096;
+    const int gen_nb = batch < kGenChunk ? batch : kGenChunk;
+    if (!fused) total += Carver::need(n0 * gen_nb, 4) + Carver::need(lk_generic_scratch(rows, cols) * gen_nb, 4);
     // MICV_OPT_LK_SPLIT: the padded gradient planes of the largest level some launch of the chain will split (the
     // levels run one after the other on the chain's stream and share the block)
     size_t grad_elems = 0;
@@ -1016,10 +1019,12 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     };
 
     if (!fused) {
-        ctx->prof_pairs = batch;
-        float *warped = carve.take<float>(n0 * batch);
-        float *gen = carve.take<float>(lk_generic_scratch(rows, cols) * batch);
-        return lk_chain_generic(ctx, plan, make_chain(s, 0, batch, true), win, warped, gen);
+        ctx->prof_pairs = gen_nb;
+        float *warped = carve.take<float>(n0 * gen_nb);
+        float *gen = carve.take<float>(lk_generic_scratch(rows, cols) * gen_nb);
+        for (int b0 = 0; b0 < batch; b0 += kGenChunk)
+            MICV_TRY(lk_chain_generic(ctx, plan, make_chain(s, b0, batch - b0 < kGenChunk ? batch - b0 : kGenChunk, b0 == 0), win, warped, gen));
+        return MICV_OK;
     }
 
     // Fused path: the batch is split into groups of pairs whose chains run on forked HIP streams and

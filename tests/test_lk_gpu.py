@@ -940,3 +940,19 @@ def test_batch_entry_point_with_pitched_buffers(mods, win):
             gv = wv[b * pair: b * pair + rows * pitch].view(rows, pitch)
             assert torch.equal(gu[:, :cols], du[b]) and torch.equal(gv[:, :cols], dv[b]), (win, pitch, b)
             assert bool(torch.isnan(gu[:, cols:]).all()) and bool(torch.isnan(gv[:, cols:]).all())  # nothing written past a row
+
+
+def test_generic_chain_chunks_a_very_large_batch(mods):
+    """More pairs than one launch of the generic chain carries in blockIdx.z (4096): the batch runs in chunks -- pairs on
+    both sides of the chunk boundary against the oracle, and every pair of the second chunk against its twin in the first."""
+    lk, pyr = mods
+    rows, cols, nb = 12, 20, 4100
+    rng = np.random.default_rng(77)
+    base = (rng.random((4096, rows, cols)) * 255).astype(np.float32)
+    prev = np.concatenate([base, base[:nb - 4096]])
+    nxt = np.roll(prev, (1, -1), (1, 2)) + np.float32(0.5)
+    u, v = lk.calcOpticalFlowPyrBatch(dev(prev), dev(nxt), 5, 2)
+    for b in (0, 1, 4095, 4096, 4099):
+        eu, ev = orc.lk_flow_pyr(prev[b], nxt[b], 5, 2)
+        assert np.array_equal(host(u[b]), eu) and np.array_equal(host(v[b]), ev), b
+    assert torch.equal(u[4096:], u[:nb - 4096]) and torch.equal(v[4096:], v[:nb - 4096])
