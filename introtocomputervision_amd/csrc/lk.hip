@@ -603,6 +603,108 @@ __global__ __launch_bounds__(256) void lk_warp_tiled_kernel(const float *__restr
     *reinterpret_cast<wv4f *>(dst + (size_t)y * dstride + x) = out;
 }
 
+// The generic chain's two steps between levels as ONE launch (r05): base flow = 2 * pyrUp(coarse flow) for the tile's own
+// pixels (pyr_up_tiled_kernel's chains: row taps left -> right over the coarse rows, column taps top -> bottom, fmaf from
+// +0, then * 2 -- OpticalFlow.cpp:140-145), written to bu / bv for the solve that follows, and lk::warp of `next` by exactly
+// those registers (lk_warp_tiled_kernel's body).  Saves the 8 B per pixel the warp launch read back, and a launch per level.
+// blockIdx.z = pair.  Needs what the tiled warp needs (16-byte rows everywhere, cols % 4 == 0) and R == 2 fr, C == 2 fc.
+__global__ __launch_bounds__(256) void lk_expand_warp_kernel(const float *__restrict__ cu, const float *__restrict__ cv, int fr, int fc,
+                                                              size_t coarse_img, const float *__restrict__ src, int sstride,
+                                                              size_t src_img, int rows, int cols, float *__restrict__ bu,
+                                                              float *__restrict__ bv, float *__restrict__ dst, size_t fine_img) {
+    constexpr int CW = WT_W / 2 + 2, CH = WT_H / 2 + 2;  // coarse block: rows r0 - 1 .., columns c0 - 1 ..
+    __shared__ __attribute__((aligned(16))) float N[WT_NH * WT_NW];
+    __shared__ float Cs[2][CH][CW + 1];
+    __shared__ __attribute__((aligned(16))) float Rp[2][CH][WT_W];
+    const unsigned pair = blockIdx.z;
+    cu += pair * coarse_img; cv += pair * coarse_img; src += pair * src_img;
+    bu += pair * fine_img; bv += pair * fine_img; dst += pair * fine_img;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * WT_W, y0 = blockIdx.y * WT_H;
+    const int nx0 = x0 - WT_M, ny0 = y0 - WT_M;
+    const int c0 = x0 >> 1, r0 = y0 >> 1;
+    const float g5[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    // every global load first: the `next` window (as lk_warp_tiled_kernel) and the coarse block of both fields
+    constexpr int V4 = WT_NW / 4, NCH = WT_NH * V4, NB = (NCH + 255) / 256;
+    wv4f w[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const int i = tid + k * 256 < NCH ? tid + k * 256 : NCH - 1;
+        const int ly = i / V4, lv = i - ly * V4;
+        const int gy = ny0 + ly, gx = nx0 + 4 * lv;
+        const bool in = (unsigned)gy < (unsigned)rows && (unsigned)gx < (unsigned)cols;  // cols % 4 == 0: whole chunk
+        w[k] = (wv4f){0.f, 0.f, 0.f, 0.f};
+        if (in) w[k] = *reinterpret_cast<const wv4f *>(src + (size_t)gy * sstride + gx);
+    }
+    constexpr int NC = 2 * CH * CW, NCB = (NC + 255) / 256;
+    float cval[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; k++) {
+        const int i = tid + k * 256 < NC ? tid + k * 256 : NC - 1;
+        const int f = i / (CH * CW), j = i - f * (CH * CW), ly = j / CW, lx = j - ly * CW;
+        const float *cp = f ? cv : cu;
+        cval[k] = cp[(size_t)clampi(r0 - 1 + ly, 0, fr - 1) * fc + clampi(c0 - 1 + lx, 0, fc - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++)
+        if (tid + k * 256 < NCH) *reinterpret_cast<wv4f *>(N + 4 * (tid + k * 256)) = w[k];
+#pragma unroll
+    for (int k = 0; k < NCB; k++) {
+        const int i = tid + k * 256;
+        if (i < NC) {
+            const int f = i / (CH * CW), j = i - f * (CH * CW), ly = j / CW, lx = j - ly * CW;
+            Cs[f][ly][lx] = cval[k];
+        }
+    }
+    __syncthreads();
+    // row pass: (field, coarse row, fine column) -- 2 x CH x 64 values
+    for (int i = tid; i < 2 * CH * WT_W; i += 256) {
+        const int f = i / (CH * WT_W), j = i - f * (CH * WT_W), cr = j / WT_W, t = j - cr * WT_W;
+        const int x = x0 + t;
+        if (x >= cols) continue;  // (past the frame: no output reads it, and its taps would fall outside the staged block)
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc = fmaf(Cs[f][cr][(reflect101(x + k - 2, cols) >> 1) - (c0 - 1)], g5[k], acc);
+        Rp[f][cr][t] = acc;
+    }
+    __syncthreads();
+    const int x = x0 + 4 * (tid & 15), y = y0 + (tid >> 4);
+    if (x >= cols || y >= rows) return;
+    wv4f fu = {0.f, 0.f, 0.f, 0.f}, fv = fu;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int ri = (reflect101(y + k - 2, rows) >> 1) - (r0 - 1);
+        const wv4f gk = {g5[k], g5[k], g5[k], g5[k]};
+        fu = __builtin_elementwise_fma(*reinterpret_cast<const wv4f *>(&Rp[0][ri][4 * (tid & 15)]), gk, fu);
+        fv = __builtin_elementwise_fma(*reinterpret_cast<const wv4f *>(&Rp[1][ri][4 * (tid & 15)]), gk, fv);
+    }
+    fu = fu * (wv4f){2.f, 2.f, 2.f, 2.f};
+    fv = fv * (wv4f){2.f, 2.f, 2.f, 2.f};
+    *reinterpret_cast<wv4f *>(bu + (size_t)y * cols + x) = fu;
+    *reinterpret_cast<wv4f *>(bv + (size_t)y * cols + x) = fv;
+    wv4f out;
+    const float yf32 = 32.f * (float)y;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        out[j] = warp_sample_staged<WT_NW, WT_NH, 32>(N, nx0, ny0, src, rows, cols, sstride,
+                                                      (wv2f){32.f * (float)(x + j), yf32}, (wv2f){fu[j], fv[j]});
+    *reinterpret_cast<wv4f *>(dst + (size_t)y * cols + x) = out;
+}
+
+// Launches it when the shapes allow; *done = false otherwise (the caller then runs the two launches).
+static int launch_expand_warp(hipStream_t s, const float *cu, const float *cv, int fr, int fc, size_t coarse_img, const float *src,
+                              int sstride, size_t src_img, int rows, int cols, float *bu, float *bv, float *dst, size_t fine_img,
+                              int batch, bool *done) {
+    *done = rows == 2 * fr && cols == 2 * fc && (cols & 3) == 0 && (sstride & 3) == 0 && ((src_img | fine_img) & 3) == 0 &&
+            ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(bu) | reinterpret_cast<uintptr_t>(bv) |
+              reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if (!*done) return MICV_OK;
+    lk_expand_warp_kernel<<<dim3(cdiv(cols, WT_W), cdiv(rows, WT_H), batch), 256, 0, s>>>(cu, cv, fr, fc, coarse_img, src, sstride, src_img,
+                                                                                       rows, cols, bu, bv, dst, fine_img);
+    MICV_LAUNCH_CHECK();
+    return MICV_OK;
+}
+
 // micv_flow_bound_check_dev: raises *flag when a flow value of the given rows exceeds `bound` in magnitude
 // (or is not finite).  One atomic per wave that sees a violation.
 __global__ __launch_bounds__(256) void flow_bound_kernel(const float *__restrict__ v, size_t pair_elems, int stride,
@@ -866,15 +968,20 @@ static int lk_chain_generic(micv_ctx *ctx, const PyrPlan &plan, const LkChain &c
         const int ist = last ? c.stride : C;
         const size_t img_pair = last ? c.pair_elems : lvl_elems;
         float *bu = c.fu[cur ^ 1], *bv = c.fv[cur ^ 1];  // this level's base flow, pairs lvl_elems apart
+        bool warped_done = false;
         if (level == 0) {
             MICV_HIP(hipMemsetAsync(bu, 0, lvl_elems * 4 * c.nb, s));  // OpticalFlow.cpp:132-133
             MICV_HIP(hipMemsetAsync(bv, 0, lvl_elems * 4 * c.nb, s));
         } else if (2 * fr == R && 2 * fc == C) {
-            MICV_TRY(launch_pyr_up_batch(s, c.fu[cur], c.fv[cur], fr, fc, (size_t)fr * fc, bu, bv, lvl_elems, 2.f, c.nb));  // :140-145
+            // :140-145 and :155 in one launch when the shapes allow (16-byte rows), else the batched pyrUp and the warp below
+            MICV_TRY(launch_expand_warp(s, c.fu[cur], c.fv[cur], fr, fc, (size_t)fr * fc, nk, ist, img_pair, R, C, bu, bv, warped, lvl_elems,
+                                        c.nb, &warped_done));
+            if (!warped_done)
+                MICV_TRY(launch_pyr_up_batch(s, c.fu[cur], c.fv[cur], fr, fc, (size_t)fr * fc, bu, bv, lvl_elems, 2.f, c.nb));
         } else {  // :148-151, odd sizes: 2 x pyrUp then cv::resize, one launch (the fused path's)
             MICV_TRY(launch_flow_expand_resize(s, c.fu[cur], c.fv[cur], fr, fc, (size_t)fr * fc, bu, bv, R, C, lvl_elems, c.nb));
         }
-        MICV_TRY(launch_warp(s, nk, ist, bu, bv, C, R, C, warped, C, c.nb, img_pair, lvl_elems, lvl_elems));  // :155
+        if (!warped_done) MICV_TRY(launch_warp(s, nk, ist, bu, bv, C, R, C, warped, C, c.nb, img_pair, lvl_elems, lvl_elems));  // :155
         // in place is fine here: the solve reads and writes the same pixel in one thread
         LkPairs pp;
         pp.prev = img_pair;
