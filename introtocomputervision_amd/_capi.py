@@ -34,7 +34,8 @@ STEREO_COLS_2R, STEREO_MIN_SSD_5E6, STEREO_SERIAL, STEREO_ROLLING = 1, 2, 4, 8
 # micv_ctx_set_option (include/mi_cv.h): none of these changes a result
 (OPT_LK_STREAM_GROUPS, OPT_LK_FORCE_GENERIC, OPT_LK_NARROW_TILES, OPT_SOBEL_GENERIC, OPT_HARRIS_GENERIC,
  OPT_NMS_SCAN, OPT_STEREO_ROWS, OPT_LK_CHAIN, OPT_LK_SHORT_TILES, OPT_LK_STREAM, OPT_LK_TALL_TILES,
- OPT_COMPACT_3PASS, OPT_LK_DIRECT_LEVELS, OPT_LK_BUILD_OVERLAP, OPT_LK_SPLIT, OPT_LK_STRIP) = range(1, 17)
+ OPT_COMPACT_3PASS, OPT_LK_DIRECT_LEVELS, OPT_LK_BUILD_OVERLAP, OPT_LK_SPLIT, OPT_LK_STRIP,
+ OPT_STEREO_EXACT) = range(1, 18)
 
 
 MICV_COMM_ID_BYTES = 128  # mi_cv.h

@@ -133,6 +133,13 @@ struct micv_ctx {
     CompactSlot compact_slots[kLkTicketSlots];
     int compact_used = 0;
     int compact_state(hipStream_t stream, int nchunks, unsigned long long **status, unsigned **counters);
+    // Eligibility word of the exact-sum stereo path (stereo_exact.hip): the pack pre-pass of call number `stereo_epoch`
+    // stores that number when an image is not 8-bit-valued; zero-filled once, never reset (epochs only grow).
+    unsigned *stereo_flag = nullptr;
+    unsigned stereo_epoch = 0;
+    int stereo_flag_word(unsigned **out);
+    int cu_count = 0;  // multiProcessorCount, read once
+    int wave_slots(int waves_per_simd);
     // Hough trig tables (hough.hip), uploaded once per context: [0] theta = -90.., [1] theta = 0..
     void *trig_tables[2] = {nullptr, nullptr};
     void *io_acquire(size_t bytes);

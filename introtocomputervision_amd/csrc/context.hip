@@ -90,6 +90,32 @@ int micv_ctx::reserve(size_t bytes, void **out) {
     return MICV_OK;
 }
 
+int micv_ctx::stereo_flag_word(unsigned **out) {
+    if (!stereo_flag) {
+        void *p = nullptr;
+        MICV_HIP(hipSetDevice(device));
+        MICV_HIP(hipMalloc(&p, 256));
+        hipError_t e = hipMemset(p, 0, 256);
+        if (e == hipSuccess) e = hipDeviceSynchronize();  // (null-stream fill: finish it before any stream reads the word)
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            MICV_HIP(e);
+        }
+        stereo_flag = static_cast<unsigned *>(p);
+    }
+    *out = stereo_flag;
+    return MICV_OK;
+}
+
+int micv_ctx::wave_slots(int waves_per_simd) {
+    if (!cu_count) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256;
+        cu_count = n;
+    }
+    return cu_count * 4 * waves_per_simd;
+}
+
 int micv_ctx::prof_begin(int level, hipStream_t s) {
     if (!profile) return MICV_OK;
     if (prof[level].size() >= kMaxProfPairs) {  // bounded: stop recording, keep what there is
@@ -211,6 +237,7 @@ void micv_ctx_destroy(micv_ctx *ctx) {
     for (auto &b : ctx->io_cache) (void)hipFree(b.p);
     for (auto &e : ctx->lk_sched) (void)hipFree(e.dev);
     if (ctx->lk_tickets) (void)hipFree(ctx->lk_tickets);
+    if (ctx->stereo_flag) (void)hipFree(ctx->stereo_flag);
     for (auto &c : ctx->compact_slots)
         if (c.buf) (void)hipFree(c.buf);
     for (void *t : ctx->trig_tables)
@@ -339,6 +366,8 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
         MICV_REQUIRE(value >= 0 && value <= 3, "micv_ctx_set_option: split launch must be 0 (never) .. 3");
     if (option == MICV_OPT_LK_STRIP)
         MICV_REQUIRE(value >= 0 && value <= 8192 + 4096 && (value & 8191) <= 4096, "micv_ctx_set_option: strip segments must be 0 (off) .. 4096 blocks of 16 rows (+ 8192: launches of 4096 tiles or more only)");
+    if (option == MICV_OPT_STEREO_EXACT)
+        MICV_REQUIRE(value >= -1 && value <= 0, "micv_ctx_set_option: exact-sum stereo must be 0 (automatic) or -1 (never)");
     ctx->opt[option] = value;
     return MICV_OK;
 }

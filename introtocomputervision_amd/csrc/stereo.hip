@@ -30,6 +30,7 @@
 
 #include "kernels.hpp"
 #include "ncc_arith.hpp"
+#include "stereo_exact.hpp"
 
 namespace micv {
 
@@ -67,6 +68,11 @@ struct StereoArgs {
     // (unclamped) column s, every column clamped on its own -- written by stereo_energy_kernel
     const float *energy;
     int e_width, s_lo;
+    // The exact-sum kernels of stereo_exact.hip were launched in front for this call: they did the work unless the
+    // flag word holds `epoch` (an image is not 8-bit-valued) -- only then do the kernels of this file run.
+    const unsigned *fallback_flag;
+    unsigned epoch;
+    __device__ bool skip() const { return fallback_flag && __builtin_nontemporal_load(fallback_flag) != epoch; }
 };
 
 // LDS budget of the staged right-image strip: DCH disparities per chunk -> SPAN columns per row.
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void stereo_energy_kernel(StereoArgs a, float 
     constexpr int W = 2 * R + 1, STEPS = RPW + 2 * R, OUTW = 64 - 2 * R;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ys = blockIdx.y * (4 * RPW) + wave * RPW;
-    if (ys >= a.rows) return;
+    if (ys >= a.rows || a.skip()) return;
     const bool full = a.wcols == W;
     const int sp = a.s_lo - 2 * R + blockIdx.x * OUTW + lane;  // position of this lane's column
     const int xr = clampi(sp, 0, a.cols - 1);
@@ -118,7 +124,7 @@ void stereo_kernel(StereoArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar row addressing
     const bool full = a.wcols == W;
     const int ys = blockIdx.y * (4 * RPW) + wave * RPW;
-    if (ys >= a.rows) return;  // whole wave; waves never synchronise with each other
+    if (ys >= a.rows || a.skip()) return;  // whole wave; waves never synchronise with each other
     constexpr int ESTEPS = MODE == ST_NCC ? RPW : 0;  // staged rows of the window-energy field
     float *Rs = st_lds + wave * ((STEPS + ESTEPS) * ST_SPAN);
     float *Es = Rs + STEPS * ST_SPAN;
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(64 * ST_ROLL_WAVES) void stereo_rolling_kernel(Ster
     const int outw = 64 - 2 * r;
     const int seg = blockIdx.x * ST_ROLL_WAVES + wave;  // this wave's run of output columns
     const int y0 = blockIdx.y * ST_STRIP;
-    if (seg * outw >= a.cols) return;  // whole wave; waves never synchronise with each other
+    if (seg * outw >= a.cols || a.skip()) return;  // whole wave; waves never synchronise with each other
     const int nr = a.rows - y0 < ST_STRIP ? a.rows - y0 : ST_STRIP;
     const int xc = seg * outw - r + lane;  // window column of this lane (unclamped)
     const int xl = clampi(xc, 0, a.cols - 1);
@@ -437,7 +443,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void stereo_generic_kernel(StereoArgs a, int r) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= a.cols || y >= a.rows) return;
+    if (x >= a.cols || y >= a.rows || a.skip()) return;
     const int x_first = x - r;  // first window column
     float best = MODE == ST_SSD_SERIAL ? 0.f : a.init_best;
     int besti = 99999999, bestd = MODE == ST_SSD_SERIAL ? 0 : -1;
@@ -542,17 +548,32 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
     a.init_best = ncc ? 0.f : ((flags & MICV_STEREO_MIN_SSD_5E6) ? 5000000.f : INFINITY);
     a.disp = disp; a.dstride = (int)dstride;
     a.energy = nullptr; a.e_width = 0; a.s_lo = 0;
+    a.fallback_flag = nullptr; a.epoch = 0;
+    size_t energy_bytes = 0;
     if (ncc && rad >= 1 && rad <= 10 && !(flags & MICV_STEREO_ROLLING)) {
         // positions a window's last column can take: lanes reach from -R to past cols + R (whole
         // 64-lane strips), shifted by every disparity
         const int outw = 64 - 2 * rad;
         a.s_lo = -rad + min_d;
         a.e_width = (int)cdiv(cols, outw) * outw + 64 + (max_d - min_d);
-        void *scratch;
-        MICV_TRY(ctx->reserve(Carver::need((size_t)rows * a.e_width, 4), &scratch));
-        a.energy = static_cast<const float *>(scratch);
+        energy_bytes = Carver::need((size_t)rows * a.e_width, 4);
     }
+    // 8-bit-valued images (every plain ps2 call, main.cpp:87-88): the exact-sum kernels go first and the kernels below
+    // return at once unless the pack pre-pass found a pixel that is not an integer in 0..255 (no host round trip).
+    const bool exact = ctx->opt[MICV_OPT_STEREO_EXACT] >= 0 && stereo_exact_covers(rad, flags, ncc);
+    const size_t exact_bytes = exact ? stereo_exact_scratch(rows, cols, rad, min_d, max_d) : 0;
+    void *scratch = nullptr;
+    if (energy_bytes + exact_bytes) MICV_TRY(ctx->reserve(energy_bytes + exact_bytes, &scratch));
+    if (energy_bytes) a.energy = static_cast<const float *>(scratch);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (exact) {
+        unsigned *flag;
+        MICV_TRY(ctx->stereo_flag_word(&flag));
+        a.fallback_flag = flag;
+        a.epoch = ++ctx->stereo_epoch;
+        MICV_TRY(stereo_exact_launch(s, static_cast<char *>(scratch) + energy_bytes, left, right, rows, cols, a.stride, rad,
+                                     min_d, max_d, flags, a.wcols, disp, a.dstride, flag, a.epoch, ctx->wave_slots(2)));
+    }
     if (flags & MICV_STEREO_ROLLING) {
         const dim3 grid(cdiv(cdiv(cols, 64 - 2 * rad), ST_ROLL_WAVES), cdiv(rows, ST_STRIP));
         if (ncc) stereo_rolling_kernel<true><<<grid, 64 * ST_ROLL_WAVES, 0, s>>>(a, rad);
