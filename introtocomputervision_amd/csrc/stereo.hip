@@ -111,30 +111,28 @@ __global__ __launch_bounds__(256) void stereo_energy_kernel(StereoArgs a, float 
     }
 }
 
-template <int R, int MODE, int RPW, int ST_DCH = ST_DCH_DEFAULT>
+template <int R, int MODE, int RPW, int ST_DCH>
 // Register budget: LDS allows three workgroups per CU = three waves per SIMD, so the SSD forms may take 170 VGPRs instead
 // of the 128 the default heuristic aims at (r05 A/B on one box: 0.2246-0.2267 -> 0.2176-0.2208 ms at C3); NCC with its
 // prefetched strips keeps the default budget -- it then takes 243 VGPRs = two waves per SIMD, 0.326 ms; capped at 170 it spills
 // (0.389 ms), told "two waves" it allocates 179 and schedules worse (0.417 ms).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == ST_NCC ? 1 : 3, MODE == ST_NCC ? 8 : 3)))
-void stereo_kernel(StereoArgs a) {
+__device__ __forceinline__ void stereo_tile(const StereoArgs &a, float *st_lds, const int bx, const int by) {
     constexpr int W = 2 * R + 1, STEPS = RPW + 2 * R, OUTW = 64 - 2 * R, ST_SPAN = 64 + ST_DCH;
-    extern __shared__ float st_lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar row addressing
     const bool full = a.wcols == W;
-    const int ys = blockIdx.y * (4 * RPW) + wave * RPW;
-    if (ys >= a.rows || a.skip()) return;  // whole wave; waves never synchronise with each other
+    const int ys = by * (4 * RPW) + wave * RPW;
+    if (ys >= a.rows) return;  // whole wave; waves never synchronise with each other
     constexpr int ESTEPS = MODE == ST_NCC ? RPW : 0;  // staged rows of the window-energy field
     float *Rs = st_lds + wave * ((STEPS + ESTEPS) * ST_SPAN);
     float *Es = Rs + STEPS * ST_SPAN;
-    const int x_base = blockIdx.x * OUTW - R;
+    const int x_base = bx * OUTW - R;
     const int xc = x_base + lane;  // window column of this lane (unclamped)
     const int xl = clampi(xc, 0, a.cols - 1);
     // output pixel whose window ENDS at this lane
     const int xo = (a.wcols == W) ? xc - R : xc - R + 1;
-    const bool lane_ok = lane >= a.wcols - 1 && xo >= blockIdx.x * OUTW &&
-                         xo < (blockIdx.x + 1) * OUTW && xo < a.cols;
+    const bool lane_ok = lane >= a.wcols - 1 && xo >= bx * OUTW &&
+                         xo < (bx + 1) * OUTW && xo < a.cols;
 
     float Lv[STEPS];
 #pragma unroll
@@ -361,6 +359,16 @@ void stereo_kernel(StereoArgs a) {
     }
 }
 
+template <int R, int MODE, int RPW, int ST_DCH = ST_DCH_DEFAULT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE == ST_NCC ? 1 : 3, MODE == ST_NCC ? 8 : 3)))
+void stereo_kernel(StereoArgs a) {
+    extern __shared__ float st_lds[];
+    // (one workgroup per tile: a grid of resident workgroups walking the tiles made the SSD form 25 % slower -- 0.214 ->
+    // 0.268 ms at C3 -- and the launch that only finds the flag and leaves no shorter: 4.6 us either way, r06)
+    if (a.skip()) return;
+    stereo_tile<R, MODE, RPW, ST_DCH>(a, st_lds, blockIdx.x, blockIdx.y);
+}
+
 // MICV_STEREO_ROLLING: the column sums as the CUDA kernels keep them (DisparitySSD.cu:97-138,
 // DisparityNCorr.cu:117-173).  Rows are cut into strips of ROWS_PER_THREAD = 40 (DisparitySSD.cu:17);
 // the first row of a strip sums its 2r+1 terms top -> bottom from 0, every further row takes the
@@ -561,7 +569,7 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
     // 8-bit-valued images (every plain ps2 call, main.cpp:87-88): the exact-sum kernels go first and the kernels below
     // return at once unless the pack pre-pass found a pixel that is not an integer in 0..255 (no host round trip).
     const bool exact = ctx->opt[MICV_OPT_STEREO_EXACT] >= 0 && stereo_exact_covers(rad, flags, ncc);
-    const size_t exact_bytes = exact ? stereo_exact_scratch(rows, cols, rad, min_d, max_d) : 0;
+    const size_t exact_bytes = exact ? stereo_exact_scratch(rows, cols, rad, min_d, max_d, a.wcols, ctx->wave_slots(3)) : 0;
     void *scratch = nullptr;
     if (energy_bytes + exact_bytes) MICV_TRY(ctx->reserve(energy_bytes + exact_bytes, &scratch));
     if (energy_bytes) a.energy = static_cast<const float *>(scratch);
@@ -572,7 +580,7 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
         a.fallback_flag = flag;
         a.epoch = ++ctx->stereo_epoch;
         MICV_TRY(stereo_exact_launch(s, static_cast<char *>(scratch) + energy_bytes, left, right, rows, cols, a.stride, rad,
-                                     min_d, max_d, flags, a.wcols, disp, a.dstride, flag, a.epoch, ctx->wave_slots(2)));
+                                     min_d, max_d, flags, a.wcols, disp, a.dstride, flag, a.epoch, ctx->wave_slots(3)));
     }
     if (flags & MICV_STEREO_ROLLING) {
         const dim3 grid(cdiv(cdiv(cols, 64 - 2 * rad), ST_ROLL_WAVES), cdiv(rows, ST_STRIP));

@@ -44,6 +44,7 @@ namespace micv {
 namespace {
 
 typedef const __attribute__((address_space(4))) uint32_t *sx_cptr;  // scalar (constant-address-space) loads
+typedef uint32_t sx_u32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SX_Y = 8;        // output rows per wave
 constexpr int SX_LW = 8;       // packed left words per column in the plan (32 B: one s_load_dwordx8)
@@ -58,44 +59,6 @@ __device__ __forceinline__ int sx_dpp(int old, int v) {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false);
 }
 __device__ __forceinline__ int sx_max(int a, int b) { return a > b ? a : b; }
-
-// ---- pre-pass 1: pack rows into bytes, test eligibility ----------------------------------------------------------
-// Strip s = output rows 8 s .. 8 s + 7; its NR = 8 + 2 R window rows (clamped to the image) go four to a dword:
-// word g, byte b = row 8 s - R + 4 g + b.  Left: plan[s][column][8 words]; right: pack[s][g][column].
-template <int R>
-__global__ __launch_bounds__(256) void stereo_pack_kernel(StereoExactArgs a) {
-    constexpr int NR = SX_Y + 2 * R, NG = sx_groups(R);
-    const int c = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
-    if (c >= a.cols) return;
-    uint32_t lw[SX_LW], rw[NG];
-#pragma unroll
-    for (int g = 0; g < SX_LW; g++) lw[g] = 0;
-#pragma unroll
-    for (int g = 0; g < NG; g++) rw[g] = 0;
-    bool ok = true;
-    float lv[NR], rv[NR];
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-        const int yy = clampi(s * SX_Y - R + k, 0, a.rows - 1);
-        lv[k] = a.left[(size_t)yy * a.stride + c];
-        rv[k] = a.right[(size_t)yy * a.stride + c];
-    }
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-        // (unsigned) of a float saturates, NaN -> 0: the comparison back rejects everything that is not 0..255 exactly
-        // (-0 passes and packs as 0: its squares, products and sums are the same numbers)
-        const uint32_t ul = (uint32_t)lv[k], ur = (uint32_t)rv[k];
-        ok = ok && (float)ul == lv[k] && ul <= 255u && (float)ur == rv[k] && ur <= 255u;
-        lw[k >> 2] |= (ul & 255u) << (8 * (k & 3));
-        rw[k >> 2] |= (ur & 255u) << (8 * (k & 3));
-    }
-    uint4 *lp = reinterpret_cast<uint4 *>(a.lplan + ((size_t)s * a.cols + c) * SX_LW);
-    lp[0] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
-    lp[1] = make_uint4(lw[4], lw[5], lw[6], lw[7]);
-#pragma unroll
-    for (int g = 0; g < NG; g++) a.rpack[((size_t)s * NG + g) * a.colsP + c] = rw[g];
-    if (!ok) *a.flag = a.epoch;  // every failing thread stores the same word
-}
 
 // Column sum of rows J .. J + 2 R (strip-local) of the byte-wise product of two packed columns.  The run of FULL
 // words is a chain in a fixed order, so the runs shared by neighbouring J are one computation (CSE); head and tail
@@ -119,51 +82,103 @@ __device__ __forceinline__ void sx_colsums(const uint32_t (&l)[NG], const uint32
     ((cs[J] = sx_colsum<R, (int)J, NG>(l, r)), ...);
 }
 
-// ---- pre-pass 2: window energies ----------------------------------------------------------------------------------
-// blockIdx.z = 0: A(y, x) = window sum of left^2 at output x (window columns x - R .. x - R + wcols - 1, each clamped
-// on its own); 1: B(y, p) the same of right at position p = x + d, p in [min_d, cols - 1 + max_d].
+// ---- the pre-pass: pack rows into bytes, test eligibility, window energies -------------------------------------------
+// Strip s = output rows 8 s .. 8 s + 7; its NR = 8 + 2 R window rows (clamped to the image) go four to a dword:
+// word g, byte b = row 8 s - R + 4 g + b.  Left: plan[s][column + R][8 words], columns -R .. (clamped copies: the
+// search kernel walks it with a plain pointer); right: pack[s][g][column], columns 0 .. cols - 1.
+// Energies: B(y, p) = window sum of right^2 at position p = x + d (window columns p - R .. p - R + wcols - 1, each
+// clamped on its own), p in [min_d, cols - 1 + max_d]; A(y, x) the same of left at x (only MIN_SSD_5E6 reads it).
+// One workgroup = 256 consecutive columns q of one strip (+ wcols - 1 more for the windows that start in them).
 template <int R>
-__global__ __launch_bounds__(256) void stereo_energy8_kernel(StereoExactArgs a) {
-    constexpr int NG = sx_groups(R), WMAX = 2 * R + 1;
-    __shared__ uint32_t cs2[SX_Y][256 + WMAX];
-    const bool right = blockIdx.z == 1;
-    const int npos = right ? a.nB : a.cols, pmin = right ? a.min_d : 0;
-    const int p0 = blockIdx.x * 256, s = blockIdx.y;
-    if (p0 >= npos) return;
+__global__ __launch_bounds__(256) void stereo_prep_kernel(StereoExactArgs a) {
+    constexpr int NR = SX_Y + 2 * R, NG = sx_groups(R), WMAX = 2 * R + 1;
+    __shared__ uint32_t csB[SX_Y][256 + WMAX], csA[SX_Y][256 + WMAX];
+    const int s = blockIdx.y, q0 = a.qlo + blockIdx.x * 256;
+    const bool want_a = a.min_ssd_5e6 != 0;
+    bool ok = true;
     for (int u = threadIdx.x; u < 256 + a.wcols - 1; u += 256) {
-        const int q = clampi(pmin + p0 + u - R, 0, a.cols - 1);
-        uint32_t w[NG];
-        if (right) {
+        const int q = q0 + u, qc = clampi(q, 0, a.cols - 1);
+        const bool own = u < 256;                                                   // this workgroup stores column q
+        const bool need_l = (own && q + R >= 0 && q + R < a.lcols) || want_a;
+        uint32_t lw[SX_LW], rw[NG];
 #pragma unroll
-            for (int g = 0; g < NG; g++) w[g] = a.rpack[((size_t)s * NG + g) * a.colsP + q];
-        } else {
+        for (int g = 0; g < SX_LW; g++) lw[g] = 0;
 #pragma unroll
-            for (int g = 0; g < NG; g++) w[g] = a.lplan[((size_t)s * a.cols + q) * SX_LW + g];
+        for (int g = 0; g < NG; g++) rw[g] = 0;
+        float lv[NR], rv[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int yy = clampi(s * SX_Y - R + k, 0, a.rows - 1);
+            rv[k] = a.right[(size_t)yy * a.stride + qc];
+            lv[k] = need_l ? a.left[(size_t)yy * a.stride + qc] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            // (unsigned) of a float saturates, NaN -> 0: the comparison back rejects everything that is not 0..255 exactly
+            // (-0 passes and packs as 0: its squares, products and sums are the same numbers)
+            const uint32_t ul = (uint32_t)lv[k], ur = (uint32_t)rv[k];
+            ok = ok && (float)ul == lv[k] && ul <= 255u && (float)ur == rv[k] && ur <= 255u;
+            lw[k >> 2] |= (ul & 255u) << (8 * (k & 3));
+            rw[k >> 2] |= (ur & 255u) << (8 * (k & 3));
+        }
+        if (own && q + R >= 0 && q + R < a.lcols) {
+            uint4 *lp = reinterpret_cast<uint4 *>(a.lplan + ((size_t)s * a.lcols + q + R) * SX_LW);
+            lp[0] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+            lp[1] = make_uint4(lw[4], lw[5], lw[6], lw[7]);
+        }
+        if (own && q >= 0 && q < a.cols) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) a.rpack[((size_t)s * NG + g) * a.colsP + q] = rw[g];
         }
         uint32_t cs[SX_Y];
-        sx_colsums<R, NG>(w, w, cs, std::make_index_sequence<SX_Y>{});
+        sx_colsums<R, NG>(rw, rw, cs, std::make_index_sequence<SX_Y>{});
 #pragma unroll
-        for (int j = 0; j < SX_Y; j++) cs2[j][u] = cs[j];
+        for (int j = 0; j < SX_Y; j++) csB[j][u] = cs[j];
+        if (want_a) {
+            uint32_t l5[NG];
+#pragma unroll
+            for (int g = 0; g < NG; g++) l5[g] = lw[g];
+            sx_colsums<R, NG>(l5, l5, cs, std::make_index_sequence<SX_Y>{});
+#pragma unroll
+            for (int j = 0; j < SX_Y; j++) csA[j][u] = cs[j];
+        }
     }
+    if (!ok) *a.flag = a.epoch;  // every failing thread stores the same word
     __syncthreads();
-    const int p = p0 + threadIdx.x;
-    if (p >= npos) return;
-    int32_t *out = right ? a.B : a.A;
+    const int p = q0 + (int)threadIdx.x + R;  // the window that starts at column q0 + t
+    const bool b_ok = p >= a.min_d && p - a.min_d < a.nB, a_ok = want_a && p >= 0 && p < a.cols;
+    if (!b_ok && !a_ok) return;
 #pragma unroll
     for (int j = 0; j < SX_Y; j++) {
-        uint32_t e = 0;
-        for (int i = 0; i < a.wcols; i++) e += cs2[j][threadIdx.x + i];
         const int y = s * SX_Y + j;
-        if (y < a.rows) out[(size_t)y * npos + p] = (int32_t)e;
+        if (y >= a.rows) break;
+        uint32_t eb = 0, ea = 0;
+        for (int i = 0; i < a.wcols; i++) eb += csB[j][threadIdx.x + i];
+        if (b_ok) a.B[(size_t)y * a.nB + (p - a.min_d)] = (int32_t)eb;
+        if (a_ok) {
+            for (int i = 0; i < a.wcols; i++) ea += csA[j][threadIdx.x + i];
+            a.A[(size_t)y * a.cols + p] = (int32_t)ea;
+        }
     }
 }
 
 // ---- the search ------------------------------------------------------------------------------------------------
 // Transposed max-reduction of the 8 keys of a column: lane group 8 j .. 8 j + 7 of the result holds row j's maximum.
-__device__ __forceinline__ int sx_merge8(int a, int b) {  // partner 8 lanes away inside a DPP row; a -> lanes with bit 3 clear
-    const int ma = sx_max(a, sx_dpp<0x128>(a, a));        // row_ror:8
-    const int mb = sx_max(b, sx_dpp<0x128>(b, b));
-    return sx_dpp<0xE4, 0xF, 0xC>(ma, mb);                // banks 2, 3 (lanes 8..15 of each row) take b's
+// First level, partner 8 lanes away inside a DPP row: out[q] takes k[2q] on lanes with bit 3 clear, k[2q + 1] on the
+// others (banks 2, 3 of every row).  The masked halves are one asm block: the compiler does not look inside asm for
+// the two wait states a DPP read (in front) or a v_permlane read (behind) of a freshly written VGPR needs -- the
+// s_nop at both ends are those.
+__device__ __forceinline__ void sx_merge8x4(const int (&k)[SX_Y], int (&m)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) m[q] = sx_max(k[2 * q], sx_dpp<0x128>(k[2 * q], k[2 * q]));  // row_ror:8
+    asm("s_nop 1\n\t"
+        "v_max_i32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_max_i32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_max_i32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_max_i32_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1"
+        : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3])
+        : "v"(k[1]), "v"(k[3]), "v"(k[5]), "v"(k[7]));
 }
 __device__ __forceinline__ int sx_merge16(int a, int b) {  // a -> even rows of 16 lanes
     const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
@@ -174,29 +189,39 @@ __device__ __forceinline__ int sx_merge32(int a, int b) {  // a -> lanes 0..31
     return sx_max((int)r[0], (int)r[1]);
 }
 __device__ __forceinline__ int sx_reduce8(const int (&k)[SX_Y]) {
-    const int a0 = sx_merge8(k[0], k[1]), a1 = sx_merge8(k[2], k[3]), a2 = sx_merge8(k[4], k[5]), a3 = sx_merge8(k[6], k[7]);
-    int x = sx_merge32(sx_merge16(a0, a1), sx_merge16(a2, a3));
+    int m[4];
+    sx_merge8x4(k, m);
+    int x = sx_merge32(sx_merge16(m[0], m[1]), sx_merge16(m[2], m[3]));
     x = sx_max(x, sx_dpp<0xB1>(x, x));   // quad_perm:[1,0,3,2]
     x = sx_max(x, sx_dpp<0x4E>(x, x));   // quad_perm:[2,3,0,1]
     x = sx_max(x, sx_dpp<0x141>(x, x));  // row_half_mirror: the other quad of the 8-lane group
     return x;
 }
 
-template <int XMAX>
-struct SxLayout {  // one wave's LDS, in dwords
-    static constexpr int P_MAX = 14;
-    static constexpr int XP = XMAX + P_MAX;            // output columns incl. the unroll's overrun
-    static constexpr int RSTR = XP + P_MAX + 64;       // right strip: window columns + 63 disparities
-    static constexpr int TSTR = XP + 64;               // key table: output columns + 63 disparities
-    static constexpr int NB = (XP + 7) / 8;            // batches of 8 output columns
-    __host__ __device__ static constexpr int words(int NG) { return NG * RSTR + SX_Y * TSTR + NB * 80; }  // per batch: 64 scores, 64 disparity bytes
+// One wave's LDS (dwords), position-major so that a column's words sit within a read's immediate offset:
+//   right strip  entry i = NG words (stride padded odd: conflict-free), i = window column + lane
+//   key table    entry i = 8 rows + 1 pad word,                        i = output column + lane
+//   results      one key per lane and batch of 8 output columns (two chunks of disparities), or score + byte (more)
+struct SxLds {
+    int rs, npos_r, npos_t, nbatch, res_stride;
+    __host__ __device__ int r_words() const { return npos_r * rs; }
+    __host__ __device__ int t_words() const { return npos_t * 9; }
+    __host__ __device__ int words() const { return r_words() + t_words() + nbatch * res_stride; }
 };
+__host__ __device__ inline SxLds sx_lds_layout(int NG, int X, int WC, int nchunks) {
+    SxLds l;
+    const int nouter = (X + WC - 1) / WC;
+    l.rs = NG | 1;
+    l.npos_r = nouter * WC + WC - 1 + 64;  // window columns of nouter * WC outputs, + 63 disparities, + 1
+    l.npos_t = nouter * WC + 64;
+    l.nbatch = (nouter * WC + 7) / 8;
+    l.res_stride = nchunks <= 2 ? 64 : 80;
+    return l;
+}
 
-template <int R, int WC, bool SERIAL, int XMAX>
+template <int R, int WC, bool SERIAL>
 __global__ __launch_bounds__(256) void stereo_exact_kernel(StereoExactArgs a) {
-    constexpr int NG = sx_groups(R), P = WC - 1;  // P: columns of the window that stay when it moves on = ring length
-    using Lay = SxLayout<XMAX>;
-    static_assert(P <= Lay::P_MAX && P >= 1, "window");
+    constexpr int NG = sx_groups(R), P = WC - 1, RS = NG | 1, TS = 9;
     extern __shared__ uint32_t sx_lds[];
     if (__builtin_nontemporal_load(a.flag) == a.epoch) return;  // not 8-bit-valued: the float kernel does this call
     const int lane = threadIdx.x & 63;
@@ -204,98 +229,172 @@ __global__ __launch_bounds__(256) void stereo_exact_kernel(StereoExactArgs a) {
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= a.ntiles) return;  // whole wave; waves never synchronise with each other
     const int s = tile / a.nxs, ys = s * SX_Y, x0 = (tile - s * a.nxs) * a.X;
-    uint32_t *Rs = sx_lds + wave * Lay::words(NG);
-    int32_t *Ts = reinterpret_cast<int32_t *>(Rs + NG * Lay::RSTR);
-    int32_t *res = Ts + SX_Y * Lay::TSTR;
-    const sx_cptr lrow = (sx_cptr)(a.lplan + (size_t)s * a.cols * SX_LW);
-    const int nouter = (a.X + P - 1) / P;  // the column loop runs nouter * P output columns (overrun: masked)
     const int nchunks = (a.max_d - a.min_d) / 64 + 1;
+    const SxLds lay = sx_lds_layout(NG, a.X, WC, nchunks);
+    uint32_t *Rs = sx_lds + wave * lay.words();
+    int32_t *Ts = reinterpret_cast<int32_t *>(Rs + lay.r_words());
+    int32_t *res = Ts + lay.t_words();
+    const int nouter = (a.X + WC - 1) / WC;  // the column loop runs nouter * WC output columns (overrun: masked)
 
     for (int chunk = 0; chunk < nchunks; chunk++) {
         const int d0 = a.min_d + 64 * chunk;
         const int nvalid = a.max_d - d0 + 1 < 64 ? a.max_d - d0 + 1 : 64;
         const int dl = lane < nvalid ? lane : nvalid - 1;  // lanes past max_d repeat the last disparity (same key)
         __builtin_amdgcn_wave_barrier();  // the previous chunk's reads are done (in-order LDS)
-        // the strip of packed `right` this chunk slides over: entry i = column clamp(x0 - R + d0 + i)
-        const int nrs = nouter * P + P + 63, nts = nouter * P + 63;
+        // Stage: every load of the chunk is issued before the first is waited for.
+        // right strip: entry i = packed column clamp(x0 - R + d0 + i)
+        {
+            constexpr int QR = 4;  // 4 x 64 entries >= npos_r (X <= 128)
+            uint32_t v[QR][NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++)
-            for (int i = lane; i < nrs; i += 64)
-                Rs[g * Lay::RSTR + i] = a.rpack[((size_t)s * NG + g) * a.colsP + clampi(x0 - R + d0 + i, 0, a.cols - 1)];
-        // key table: entry i of row j belongs to position p = x0 + d0 + i (output column x0 + x_rel seen by lane i - x_rel)
+            for (int q = 0; q < QR; q++) {
+                const int i = lane + 64 * q, c = clampi(x0 - R + d0 + i, 0, a.cols - 1);
 #pragma unroll
-        for (int j = 0; j < SX_Y; j++) {
-            const int y = ys + j < a.rows ? ys + j : a.rows - 1;
-            for (int i = lane; i < nts; i += 64) {
-                const int p = x0 + d0 + i;
+                for (int g = 0; g < NG; g++) v[q][g] = a.rpack[((size_t)s * NG + g) * a.colsP + c];
+            }
+            // key table: entry i of row j = position p = x0 + d0 + i (output column x0 + x_rel seen by lane i - x_rel)
+            constexpr int QT = 4;
+            int32_t t[QT][SX_Y];
+#pragma unroll
+            for (int q = 0; q < QT; q++) {
+                const int i = lane + 64 * q, p = x0 + d0 + i;
                 const int pi = p - a.min_d < a.nB ? p - a.min_d : a.nB - 1;
-                int t = -(a.B[(size_t)y * a.nB + pi] << 6) - i;
-                if (SERIAL && (p < -R || p > a.cols - 1 + R)) t = SX_INVALID - i;  // DisparitySSD.cpp:42-43
-                Ts[j * Lay::TSTR + i] = t;
+#pragma unroll
+                for (int j = 0; j < SX_Y; j++) {
+                    const int y = ys + j < a.rows ? ys + j : a.rows - 1;
+                    t[q][j] = a.B[(size_t)y * a.nB + pi];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QR; q++) {
+                const int i = lane + 64 * q;
+                if (i < lay.npos_r) {
+#pragma unroll
+                    for (int g = 0; g < NG; g++) Rs[i * RS + g] = v[q][g];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QT; q++) {
+                const int i = lane + 64 * q, p = x0 + d0 + i;
+                if (i < lay.npos_t) {
+#pragma unroll
+                    for (int j = 0; j < SX_Y; j++) {
+                        int k = -(t[q][j] << 6) - i;
+                        if (SERIAL && (p < -R || p > a.cols - 1 + R)) k = SX_INVALID - i;  // DisparitySSD.cpp:42-43
+                        Ts[i * TS + j] = k;
+                    }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        const uint32_t *rp = Rs + dl;
-        const int32_t *tp = Ts + dl;
-        uint32_t C[SX_Y], ring[P][SX_Y];
+        const uint32_t *rp = Rs + dl * RS;
+        const int32_t *tp = Ts + dl * TS;
+        sx_cptr lp = (sx_cptr)(a.lplan + ((size_t)s * a.lcols + x0) * SX_LW);  // record of window column 0 = image column x0 - R
+        // ring: the column sums of the window's columns, slot = window column mod WC; Cp = their sum without the
+        // column that enters next
+        uint32_t Cp[SX_Y], ring[WC][SX_Y];
 #pragma unroll
-        for (int j = 0; j < SX_Y; j++) C[j] = 0;
-        // c_rel: window column, 0 = x0 - R (uniform); c_loc: the same column counted from where rp points
-        auto column = [&](int c_rel, int c_loc, uint32_t (&cs)[SX_Y]) {
-            const int xc = clampi(x0 - R + c_rel, 0, a.cols - 1);
+        for (int j = 0; j < SX_Y; j++) Cp[j] = 0;
+        auto column = [&](int c_loc, uint32_t (&cs)[SX_Y]) {  // c_loc: window column counted from where lp / rp point
             uint32_t lw[NG], rw[NG];
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                lw[g] = lrow[xc * SX_LW + g];
-                rw[g] = rp[g * Lay::RSTR + c_loc];
+                lw[g] = lp[c_loc * SX_LW + g];
+                rw[g] = rp[c_loc * RS + g];
             }
             sx_colsums<R, NG>(lw, rw, cs, std::make_index_sequence<SX_Y>{});
         };
 #pragma unroll
         for (int k = 0; k < P; k++) {  // the first 2R (2R - 1) columns of the first window
-            uint32_t cs[SX_Y];
-            column(k, k, cs);
+            column(k, ring[k]);
 #pragma unroll
-            for (int j = 0; j < SX_Y; j++) {
-                C[j] += cs[j];
-                ring[k][j] = cs[j];
-            }
+            for (int j = 0; j < SX_Y; j++) Cp[j] += ring[k][j];
         }
         int cur = 0;
-        for (int base = 0; base < nouter * P; base += P) {
+        // The packed left words of a column are fetched ONE COLUMN AHEAD, by hand: a scalar load shares its counter with
+        // the LDS reads and returns out of order, so the compiler waits for everything (lgkmcnt(0)) at the first LDS use
+        // behind one -- issued at the top of its own column the load's whole latency was exposed, once per column
+        // (r06: 35 % of the wave's cycles).  Here it is issued behind the column's last LDS use (tied to a key) and
+        // flies under the reduction; the wait sits in front of the next column's first dot product.  (The compiler's
+        // own counted waits stay correct with one more operation in flight: they only wait longer.)
+        // The packed right words come one column ahead too (LDS, issued with the column's key-table reads at its top).
+        sx_u32x8 lraw;
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(lraw) : "s"(lp), "n"(P * SX_LW * 4));
+        uint32_t rnext[NG];
+        int tnext[SX_Y];
 #pragma unroll
-            for (int m = 0; m < P; m++) {
-                const int x_rel = base + m;  // output column x0 + x_rel; its window: columns x_rel .. x_rel + P
-                uint32_t cs[SX_Y];
-                column(x_rel + P, m + P, cs);
+        for (int g = 0; g < NG; g++) rnext[g] = rp[P * RS + g];
+#pragma unroll
+        for (int j = 0; j < SX_Y; j++) tnext[j] = tp[j];
+        for (int base = 0; base < nouter * WC; base += WC) {
+#pragma unroll
+            for (int m = 0; m < WC; m++) {
+                const int x_rel = base + m;  // output column x0 + x_rel; its window: window columns x_rel .. x_rel + P
+                uint32_t (&cs)[SX_Y] = ring[(m + P) % WC];  // the slot of the column that left one step ago
+                int tk[SX_Y];
+                {
+                    uint32_t lw[NG], rw[NG];
+                    sx_u32x8 lcur = lraw;
+#pragma unroll
+                    for (int g = 0; g < NG; g++) rw[g] = rnext[g];
+                    // the wait: this column's left words (scalar) and right words (LDS), both asked for a column ago
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lcur), "+v"(rw[0]), "+v"(tnext[0]));
+#pragma unroll
+                    for (int j = 0; j < SX_Y; j++) tk[j] = tnext[j];
+#pragma unroll
+                    for (int g = 0; g < NG; g++) rnext[g] = rp[(m + 1 + P) * RS + g];
+#pragma unroll
+                    for (int j = 0; j < SX_Y; j++) tnext[j] = tp[(m + 1) * TS + j];
+#pragma unroll
+                    for (int g = 0; g < NG; g++) lw[g] = lcur[g];
+                    sx_colsums<R, NG>(lw, rw, cs, std::make_index_sequence<SX_Y>{});
+                }
                 int key[SX_Y];
 #pragma unroll
                 for (int j = 0; j < SX_Y; j++) {
-                    C[j] += cs[j];
-                    key[j] = (int)(C[j] << 7) + tp[j * Lay::TSTR + m];
-                    C[j] -= ring[m][j];
-                    ring[m][j] = cs[j];
+                    const uint32_t C = Cp[j] + cs[j];
+                    key[j] = (int)(C << 7) + tk[j];
+                    Cp[j] = C - ring[m][j];
                 }
+                // next column's record (the last step of the unrolled body reads past the pointer bump below)
+                // (tied to the keys both ways: behind the last one's LDS operand, in front of the reduction that reads them)
+                asm volatile("s_load_dwordx8 %0, %2, %3" : "=s"(lraw), "+v"(key[0]) : "s"(lp), "n"((m + 1 + P) * SX_LW * 4), "v"(key[SX_Y - 1]));
                 const int colres = sx_reduce8(key);
-                cur = (lane & 7) == (x_rel & 7) ? colres : cur;
+                const unsigned long long sel = 0x0101010101010101ull << (x_rel & 7);  // lanes 8 j + (x_rel & 7)
+                asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(cur) : "v"(colres), "s"(sel));
                 if ((x_rel & 7) == 7) {
                     // lane 8 j + c: row j, output column 8 b + c of this strip
                     const int b = x_rel >> 3, xr = 8 * b + (lane & 7), j = lane >> 3;
-                    const int dsel = ((-cur) - xr) & 63;
-                    int score = (cur + xr + dsel) >> 6;  // 2 C - B, exact
-                    int d = d0 + dsel;
+                    int32_t *rb = res + b * lay.res_stride;
+                    auto decode = [&](int k, int dbase, int &score, int &d) {
+                        const int dsel = ((-k) - xr) & 63;
+                        score = (k + xr + dsel) >> 6;  // 2 C - B, exact
+                        d = dbase + dsel;
+                    };
+                    int score, d;
+                    decode(cur, d0, score, d);
                     if (chunk > 0) {
-                        const int ps = res[b * 80 + lane], pd = reinterpret_cast<const int8_t *>(res + b * 80 + 64)[lane];
+                        int ps, pd;
+                        if (nchunks <= 2) {
+                            decode(rb[lane], d0 - 64, ps, pd);
+                        } else {
+                            ps = rb[lane];
+                            pd = reinterpret_cast<const int8_t *>(rb + 64)[lane];
+                        }
                         if (!(score > ps)) {  // the lower disparity wins ties
                             score = ps;
                             d = pd;
                         }
                     }
                     if (chunk + 1 < nchunks) {
-                        res[b * 80 + lane] = score;
-                        reinterpret_cast<int8_t *>(res + b * 80 + 64)[lane] = (int8_t)d;
+                        if (nchunks <= 2) {
+                            rb[lane] = cur;
+                        } else {
+                            rb[lane] = score;
+                            reinterpret_cast<int8_t *>(rb + 64)[lane] = (int8_t)d;
+                        }
                     } else {
                         const int y = ys + j, x = x0 + xr;
                         if (xr < a.X && x < a.cols && y < a.rows) {
@@ -310,25 +409,26 @@ __global__ __launch_bounds__(256) void stereo_exact_kernel(StereoExactArgs a) {
                     }
                 }
             }
-            rp += P;
-            tp += P;
+            rp += WC * RS;
+            tp += WC * TS;
+            lp += WC * SX_LW;
         }
+        // the last column's look-ahead load is still in flight: its registers are free for reuse only once it has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lraw));
     }
 }
 
 template <int R, int WC, bool SERIAL>
 static int launch_search(hipStream_t s, const StereoExactArgs &a) {
-    constexpr int XMAX = 128;
-    const size_t lds = 4 * SxLayout<XMAX>::words(sx_groups(R)) * sizeof(uint32_t);
-    auto k = stereo_exact_kernel<R, WC, SERIAL, XMAX>;
-    static bool attr_set[16] = {false};  // per device: the launch needs more than 64 KB of dynamic LDS
+    const int nchunks = (a.max_d - a.min_d) / 64 + 1;
+    const size_t lds = 4 * (size_t)sx_lds_layout(sx_groups(R), a.X, WC, nchunks).words() * sizeof(uint32_t);
+    auto k = stereo_exact_kernel<R, WC, SERIAL>;
+    static size_t attr_set[16] = {0};  // per device: the launch may need more than 64 KB of dynamic LDS
     int dev = 0;
     MICV_HIP(hipGetDevice(&dev));
-    if (dev < 16 && !attr_set[dev]) {
+    if (dev >= 16 || attr_set[dev] < lds) {
         MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[dev] = true;
-    } else if (dev >= 16) {
-        MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev < 16) attr_set[dev] = lds;
     }
     k<<<cdiv(a.ntiles, 4), 256, lds, s>>>(a);
     MICV_LAUNCH_CHECK();
@@ -338,14 +438,12 @@ static int launch_search(hipStream_t s, const StereoExactArgs &a) {
 template <int R>
 static int launch_r(hipStream_t s, const StereoExactArgs &a, bool serial) {
     const int nstrips = cdiv(a.rows, SX_Y);
-    stereo_pack_kernel<R><<<dim3(cdiv(a.cols, 256), nstrips), 256, 0, s>>>(a);
-    stereo_energy8_kernel<R><<<dim3(cdiv(a.nB > a.cols ? a.nB : a.cols, 256), nstrips, 2), 256, 0, s>>>(a);
+    stereo_prep_kernel<R><<<dim3(cdiv(a.qhi - a.qlo, 256), nstrips), 256, 0, s>>>(a);
     MICV_LAUNCH_CHECK();
     const bool full = a.wcols == 2 * R + 1;
     if (serial) return full ? launch_search<R, 2 * R + 1, true>(s, a) : MICV_EUNSUPPORTED;
     if (full) return launch_search<R, 2 * R + 1, false>(s, a);
-    if constexpr (R >= 1) return launch_search<R, 2 * R, false>(s, a);
-    return MICV_EUNSUPPORTED;
+    return launch_search<R, 2 * R, false>(s, a);
 }
 
 }  // namespace
@@ -358,48 +456,66 @@ bool stereo_exact_covers(int rad, int flags, bool ncc) {
     return true;
 }
 
-size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d) {
-    const int nstrips = cdiv(rows, SX_Y), colsP = (cols + 63) & ~63, nB = cols + (max_d - min_d);
-    return Carver::need((size_t)nstrips * cols * SX_LW, 4) + Carver::need((size_t)nstrips * sx_groups(rad) * colsP, 4) +
-           Carver::need((size_t)rows * cols, 4) + Carver::need((size_t)rows * nB, 4);
+// Output columns per wave: a wave's work is X + wcols - 1 columns (+ staging); the launch takes ceil(waves / slots)
+// rounds of the chip's resident waves.  Picks the strip count with the least (rounds x columns).
+static void sx_tiling(int rows, int cols, int rad, int wcols, int nchunks, int wave_slots3, int *X_out, int *nxs_out) {
+    const int nstrips = cdiv(rows, SX_Y), XMAX = 128;
+    long best_cost = -1;
+    int bx = XMAX, bn = cdiv(cols, XMAX);
+    for (int nxs = cdiv(cols, XMAX); nxs <= 6 * (int)cdiv(cols, XMAX) && nxs <= cols; nxs++) {
+        const int X = ((int)cdiv(cols, nxs) + 7) & ~7;
+        if (X > XMAX) continue;
+        const long waves = (long)nstrips * cdiv(cols, X);
+        // three waves per SIMD while a wave's LDS stays within a twelfth of the CU's 160 KB, else two
+        const size_t lds = (size_t)sx_lds_layout(sx_groups(rad), X, wcols, nchunks).words() * 4;
+        const long slots = lds * 12 <= 160 * 1024 ? wave_slots3 : wave_slots3 / 3 * 2;
+        // fewer waves per SIMD hide less: price a two-wave launch's column 15 % higher
+        const long cost = ((waves + slots - 1) / slots) * (X + wcols - 1 + 10) * (slots == wave_slots3 ? 100 : 115);
+        if (best_cost < 0 || cost < best_cost) best_cost = cost, bx = X, bn = cdiv(cols, X);
+    }
+    *X_out = bx;
+    *nxs_out = bn;
+}
+
+static void sx_geometry(StereoExactArgs &a, int rad, int wave_slots3) {
+    const int nchunks = (a.max_d - a.min_d) / 64 + 1;
+    sx_tiling(a.rows, a.cols, rad, a.wcols, nchunks, wave_slots3, &a.X, &a.nxs);
+    a.ntiles = (int)cdiv(a.rows, SX_Y) * a.nxs;
+    a.colsP = (a.cols + 63) & ~63;
+    a.nB = a.cols + (a.max_d - a.min_d);
+    a.lcols = a.nxs * a.X + 4 * rad + 8 + 2 * (2 * rad + 1);  // window columns of every strip incl. the loop's overrun
+    // columns the pre-pass visits: the plan's (from -R), the pack's, and the window starts of every position p - R
+    a.qlo = a.min_d - rad < -rad ? a.min_d - rad : -rad;
+    const int qh1 = a.lcols - rad, qh2 = a.cols + a.max_d - rad;
+    a.qhi = qh1 > qh2 ? qh1 : qh2;
+    if (a.qhi < a.cols) a.qhi = a.cols;
+}
+
+size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int wave_slots3) {
+    StereoExactArgs a;
+    a.rows = rows; a.cols = cols; a.min_d = min_d; a.max_d = max_d; a.wcols = wcols;
+    sx_geometry(a, rad, wave_slots3);
+    const int nstrips = cdiv(rows, SX_Y);
+    return Carver::need((size_t)nstrips * a.lcols * SX_LW, 4) + Carver::need((size_t)nstrips * sx_groups(rad) * a.colsP, 4) +
+           Carver::need((size_t)rows * cols, 4) + Carver::need((size_t)rows * a.nB, 4);
 }
 
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
                         int stride, int rad, int min_d, int max_d, int flags, int wcols, int8_t *disp, int dstride,
-                        unsigned *flag, unsigned epoch, int wave_slots) {
+                        unsigned *flag, unsigned epoch, int wave_slots3) {
     StereoExactArgs a;
     const int nstrips = cdiv(rows, SX_Y);
     a.left = left; a.right = right; a.stride = stride; a.rows = rows; a.cols = cols;
     a.min_d = min_d; a.max_d = max_d; a.wcols = wcols;
-    a.colsP = (cols + 63) & ~63;
-    a.nB = cols + (max_d - min_d);
+    sx_geometry(a, rad, wave_slots3);
     Carver cv(scratch);
-    a.lplan = cv.take<uint32_t>((size_t)nstrips * cols * SX_LW);
+    a.lplan = cv.take<uint32_t>((size_t)nstrips * a.lcols * SX_LW);
     a.rpack = cv.take<uint32_t>((size_t)nstrips * sx_groups(rad) * a.colsP);
     a.A = cv.take<int32_t>((size_t)rows * cols);
     a.B = cv.take<int32_t>((size_t)rows * a.nB);
     a.flag = flag; a.epoch = epoch;
     a.disp = disp; a.dstride = dstride;
     a.min_ssd_5e6 = (flags & MICV_STEREO_MIN_SSD_5E6) ? 1 : 0;
-    // Output columns per wave: a wave's work is X + wcols - 1 columns; the launch takes ceil(waves / slots) rounds of
-    // the chip's resident waves.  Pick the strip count with the least (rounds x columns).
-    const int XMAX = 128;
-    int best_nxs = cdiv(cols, XMAX);
-    long best_cost = -1;
-    for (int nxs = cdiv(cols, XMAX); nxs <= 4 * (int)cdiv(cols, XMAX) && nxs <= cols; nxs++) {
-        const int X = ((int)cdiv(cols, nxs) + 7) & ~7;
-        if (X > XMAX) continue;
-        const long waves = (long)nstrips * cdiv(cols, X);
-        const long cost = ((waves + wave_slots - 1) / wave_slots) * (X + wcols - 1 + 12);  // + staging, in column units
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            best_nxs = cdiv(cols, X);
-            a.X = X;
-        }
-    }
-    if (best_cost < 0) a.X = XMAX, best_nxs = cdiv(cols, XMAX);
-    a.nxs = best_nxs;
-    a.ntiles = nstrips * a.nxs;
     const bool serial = flags & MICV_STEREO_SERIAL;
     switch (rad) {
         case 1: return launch_r<1>(s, a, serial);

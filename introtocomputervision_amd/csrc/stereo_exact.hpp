@@ -7,7 +7,9 @@ namespace micv {
 struct StereoExactArgs {
     const float *left, *right;  // the caller's f32 images (read by the pack pre-pass only)
     int stride, rows, cols, min_d, max_d, wcols;
-    uint32_t *lplan;  // [strip][column][8]: packed rows of `left`, one 32-byte record per column (scalar loads)
+    uint32_t *lplan;  // [strip][column + R][8]: packed rows of `left`, one 32-byte record per column (scalar loads)
+    int lcols;        // records per strip: columns -R .. lcols - R - 1, clamped copies outside the image
+    int qlo, qhi;     // columns the pre-pass visits
     uint32_t *rpack;  // [strip][word][colsP]: packed rows of `right`
     int colsP;
     int32_t *A;  // [rows][cols]  window energy of left at output x
@@ -23,10 +25,10 @@ struct StereoExactArgs {
 
 // Whether the exact path has a kernel for this call at all (radius, flags); the images decide on the device.
 bool stereo_exact_covers(int rad, int flags, bool ncc);
-size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d);
-// Enqueues pack + energy + search.  `scratch` holds stereo_exact_scratch() bytes.
+size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int wave_slots3);
+// Enqueues pre-pass + search (wave_slots3: waves the device holds at three per SIMD).  `scratch` holds stereo_exact_scratch() bytes.
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
                         int stride, int rad, int min_d, int max_d, int flags, int wcols, int8_t *disp, int dstride,
-                        unsigned *flag, unsigned epoch, int wave_slots);
+                        unsigned *flag, unsigned epoch, int wave_slots3);
 
 }  // namespace micv

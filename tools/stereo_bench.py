@@ -13,6 +13,9 @@ from introtocomputervision_amd._capi import Context, Timer
 ctx = Context(0)
 stream = torch.cuda.current_stream().cuda_stream
 rad = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if len(sys.argv) > 2:  # MICV_OPT_STEREO_EXACT: -1 = the float kernels only
+    from introtocomputervision_amd._capi import OPT_STEREO_EXACT
+    ctx.set_option(OPT_STEREO_EXACT, int(sys.argv[2]))
 
 
 def timeit(fn, iters=20, warm=3):

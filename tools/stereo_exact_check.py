@@ -46,7 +46,7 @@ for (rad, rows, cols, lo, hi, flags) in cases:
     n += 1
     if not np.array_equal(a, b):
         bad += 1
-        if bad <= 10:
+        if bad <= 40:
             w = np.argwhere(a != b)
             print("MISMATCH", dict(rad=rad, rows=rows, cols=cols, lo=lo, hi=hi, flags=flags, kind=kind), len(w), "px; first", w[:3].tolist(),
                   a[tuple(w[0])], b[tuple(w[0])])
