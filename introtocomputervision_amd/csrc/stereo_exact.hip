@@ -71,8 +71,13 @@ __device__ __forceinline__ uint32_t sx_colsum(const uint32_t (&l)[NG], const uin
     uint32_t acc = 0;
 #pragma unroll
     for (int g = f0; g <= f1; g++) acc = __builtin_amdgcn_udot4(l[g], r[g], acc, false);
+#ifdef MICV_SX_NOMASK  // timing experiment only (wrong sums): what the scalar masks cost
+    if (g0 < f0) acc = __builtin_amdgcn_udot4(l[(g0 + (k0 & 3)) % NG], r[g0], acc, false);
+    if (g1 > f1) acc = __builtin_amdgcn_udot4(l[(g1 + 1 + (k1 & 3)) % NG], r[g1], acc, false);
+#else
     if (g0 < f0) acc = __builtin_amdgcn_udot4(l[g0] & (0xFFFFFFFFu << (8 * (k0 & 3))), r[g0], acc, false);
     if (g1 > f1) acc = __builtin_amdgcn_udot4(l[g1] & (0xFFFFFFFFu >> (8 * (3 - (k1 & 3)))), r[g1], acc, false);
+#endif
     return acc;
 }
 
@@ -219,8 +224,12 @@ __host__ __device__ inline SxLds sx_lds_layout(int NG, int X, int WC, int nchunk
     return l;
 }
 
+#ifndef MICV_SX_WAVES
+#define MICV_SX_WAVES 3
+#endif
 template <int R, int WC, bool SERIAL>
-__global__ __launch_bounds__(256) void stereo_exact_kernel(StereoExactArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MICV_SX_WAVES, MICV_SX_WAVES)))
+void stereo_exact_kernel(StereoExactArgs a) {
     constexpr int NG = sx_groups(R), P = WC - 1, RS = NG | 1, TS = 9;
     extern __shared__ uint32_t sx_lds[];
     if (__builtin_nontemporal_load(a.flag) == a.epoch) return;  // not 8-bit-valued: the float kernel does this call
@@ -468,9 +477,14 @@ static void sx_tiling(int rows, int cols, int rad, int wcols, int nchunks, int w
         const long waves = (long)nstrips * cdiv(cols, X);
         // three waves per SIMD while a wave's LDS stays within a twelfth of the CU's 160 KB, else two
         const size_t lds = (size_t)sx_lds_layout(sx_groups(rad), X, wcols, nchunks).words() * 4;
-        const long slots = lds * 12 <= 160 * 1024 ? wave_slots3 : wave_slots3 / 3 * 2;
+        long slots = lds * 12 <= 160 * 1024 ? wave_slots3 : wave_slots3 / 3 * 2;
+        if (MICV_SX_WAVES == 4) {
+            if (lds * 16 > 160 * 1024) continue;
+            slots = wave_slots3 / 3 * 4;
+        }
+        if (MICV_SX_WAVES == 2) slots = wave_slots3 / 3 * 2;
         // fewer waves per SIMD hide less: price a two-wave launch's column 15 % higher
-        const long cost = ((waves + slots - 1) / slots) * (X + wcols - 1 + 10) * (slots == wave_slots3 ? 100 : 115);
+        const long cost = ((waves + slots - 1) / slots) * (X + wcols - 1 + 10) * (slots >= wave_slots3 ? 100 : 115);
         if (best_cost < 0 || cost < best_cost) best_cost = cost, bx = X, bn = cdiv(cols, X);
     }
     *X_out = bx;
