@@ -233,12 +233,24 @@ def secondary_block(ctx, stream, torch, np):
     # box-filter form of the window sum: per pixel and disparity 1 subtract + 1 multiply + (2r+1) column adds
     # + (2r+1) row adds + compare = 2 (2r+1) + 3 flop
     flop_pd = 2 * (2 * rad + 1) + 3
+    from introtocomputervision_amd._capi import Context as _Ctx, OPT_STEREO_EXACT
+    fctx = _Ctx(ctx.device)                  # the float kernels only (what every call took up to r05)
+    fctx.set_option(OPT_STEREO_EXACT, -1)
     for key, fn, ofn in (("C3_ssd", stereo.disparitySSD, orc.disparity_ssd), ("C3_ncc", stereo.disparityNCorr, orc.disparity_ncorr)):
         ms = timeit(lambda: fn(L, R, rad, -(nd - 1), 0, ctx=ctx))
         exp = ofn(sl, sr, rad, -47, 0)
         got = fn(SL, SR, rad, -47, 0, ctx=ctx).cpu().numpy()
         px = rows * cols
+        path = {}
+        if key == "C3_ssd":
+            # the pair is 8-bit-valued (as every plain ps2 call's, main.cpp:87-88): the pre-pass finds that on the device and
+            # the exact-sum kernels (stereo_exact.hip) run; same disparities as the float kernels, timed beside them
+            fms = timeit(lambda: fn(L, R, rad, -(nd - 1), 0, ctx=fctx))
+            same = bool(np.array_equal(fn(L, R, rad, -(nd - 1), 0, ctx=ctx).cpu().numpy(), fn(L, R, rad, -(nd - 1), 0, ctx=fctx).cpu().numpy()))
+            path = {"kernels": "exact-sum (8-bit-valued pair found on the device): pre-pass + search + the float kernel's empty launch",
+                    "float_kernels_ms": fms, "same_as_float_kernels_at_full_size": same}
         out[key] = {
+            **path,
             "workload": f"{cols}x{rows} rectified synthetic pair, {2 * rad + 1}x{2 * rad + 1} window, {nd} disparities, device-resident",
             "ms": ms, "Mpix_per_s": px / ms / 1e3, "Gpix_disp_per_s": px * nd / ms / 1e6,
             "algorithmic_bytes_per_px": 9, "frac_of_hbm_peak": px * 9 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

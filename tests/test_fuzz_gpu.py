@@ -180,6 +180,40 @@ def test_fuzz_stereo(shape, pad, seed, rad, min_d, span, flags, ncc, integer):
 
 
 @settings(max_examples=150 * SCALE, **COMMON)
+@given(st.tuples(st.integers(1, 70), st.integers(1, 260)), pad, seed, st.integers(1, 7), st.integers(-128, 100),
+       st.integers(0, 255), st.sampled_from([0, 1, 2, 3, 4, 8, 11]), st.booleans(), st.sampled_from([256, 3, 2]))
+def test_fuzz_stereo_exact_sum(shape, pad, seed, rad, min_d, span, flags, ncc, levels):
+    """8-bit-valued images through the exact-sum kernels (MICV_OPT_STEREO_EXACT = 1: NCC too) against the oracle:
+    any size, stride, radius 1..7, up to 256 disparities, every flag; few grey levels make ties the rule."""
+    from introtocomputervision_amd import stereo
+    from introtocomputervision_amd._capi import Context, OPT_STEREO_EXACT
+    rows, cols = shape
+    max_d = min(127, min_d + span)
+    if rad < 2:
+        flags &= ~1
+    rng = np.random.default_rng(seed)
+    scale = 255 // (levels - 1) if levels <= 3 else 1
+    left = (rng.integers(0, levels, (rows, cols)) * scale).astype(np.float32)
+    right = np.roll(left, int(rng.integers(-8, 8)), axis=1)
+    noisy = rng.random((rows, cols)) < 0.3
+    right[noisy] = (rng.integers(0, levels, int(noisy.sum())) * scale).astype(np.float32)
+    ctx = Context(0)
+    ctx.set_option(OPT_STEREO_EXACT, 1)
+    if ncc:
+        flags &= ~(2 | 4)
+        exp = orc.disparity_ncorr(left, right, rad, min_d, max_d, flags)
+        got = stereo.disparityNCorr(dev(left, pad), dev(right, pad), rad, min_d, max_d, flags, ctx=ctx)
+    elif flags & 4:
+        flags = 4
+        exp = orc.disparity_ssd_serial(left, right, rad, min_d, max_d)
+        got = stereo.disparitySSD(dev(left, pad), dev(right, pad), rad, min_d, max_d, flags, ctx=ctx)
+    else:
+        exp = orc.disparity_ssd(left, right, rad, min_d, max_d, flags)
+        got = stereo.disparitySSD(dev(left, pad), dev(right, pad), rad, min_d, max_d, flags, ctx=ctx)
+    assert np.array_equal(host(got), exp), (rows, cols, rad, min_d, max_d, flags, ncc, levels, int((host(got) != exp).sum()))
+
+
+@settings(max_examples=150 * SCALE, **COMMON)
 @given(st.tuples(st.integers(2, 120), st.integers(2, 160)), pad, seed, st.floats(0.0, 0.2), st.integers(1, 3),
        st.integers(1, 5), st.integers(1, 30), st.integers(1, 20))
 def test_fuzz_hough(shape, pad, seed, density, rho_bin, theta_bin, radius, num_peaks):

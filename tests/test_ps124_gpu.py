@@ -341,14 +341,103 @@ def test_ssd_1080p_known_ramp(M):
     assert (inner == want).mean() > 0.999
 
 
+def _stereo_ctxs():
+    """(exact-sum kernels for SSD and NCC, float kernels only): MICV_OPT_STEREO_EXACT = 1 / -1."""
+    from introtocomputervision_amd._capi import Context, OPT_STEREO_EXACT
+    exact, flt = Context(0), Context(0)
+    exact.set_option(OPT_STEREO_EXACT, 1)
+    flt.set_option(OPT_STEREO_EXACT, -1)
+    return exact, flt
+
+
+def _u8_pair(rng, rows, cols, kind):
+    if kind == "noise":
+        left = rng.integers(0, 256, (rows, cols)).astype(np.float32)
+        right = np.roll(left, -5, axis=1)
+        right[::3] = rng.integers(0, 256, right[::3].shape)
+    elif kind == "levels":  # three grey levels: equal costs / scores everywhere
+        left = (rng.integers(0, 3, (rows, cols)) * 100).astype(np.float32)
+        right = (rng.integers(0, 3, (rows, cols)) * 100).astype(np.float32)
+    elif kind == "flat":  # flat patches, a black corner, a saturated band
+        left = rng.integers(0, 256, (rows, cols)).astype(np.float32)
+        left[:, cols // 3: cols // 2] = 255
+        left[rows // 2:, : cols // 4] = 0
+        right = np.roll(left, -3, axis=1)
+    else:  # "far": the largest costs the 8-bit range allows
+        left = rng.integers(200, 256, (rows, cols)).astype(np.float32)
+        right = rng.integers(0, 30, (rows, cols)).astype(np.float32)
+    return left, right
+
+
+@pytest.mark.parametrize("rad,lo,hi,flags,kind", [
+    (1, -20, 0, 0, "noise"), (2, -70, 5, 1, "levels"), (3, 0, 127, 2, "far"), (4, -128, 127, 3, "noise"),
+    (5, -127, 0, 0, "flat"), (5, -30, 40, 4, "noise"), (5, -128, 127, 4, "levels"), (6, -70, 5, 8, "far"),
+    (6, -128, 127, 0, "levels"), (7, -100, 27, 11, "noise"), (7, -3, -3, 0, "flat"), (5, 0, 63, 3, "far")])
+def test_ssd_exact_sum_kernels(M, rad, lo, hi, flags, kind):
+    """8-bit-valued images take the exact-sum kernels (stereo_exact.hip: dot4 column sums, sliding windows, lanes =
+    disparities); they, the float kernels and the oracle agree byte for byte -- ragged sizes, one to four chunks of
+    64 disparities, every flag, serial:: semantics, ties (first minimum) and the largest costs."""
+    harris, stereo, hough, synth = M
+    exact, flt = _stereo_ctxs()
+    rng = np.random.default_rng(rad * 1000 + hi)
+    for rows, cols in ((9, 40), (33, 141), (70, 203)):
+        left, right = _u8_pair(rng, rows, cols, kind)
+        if flags & 4:
+            exp = orc.disparity_ssd_serial(left, right, rad, lo, hi)
+        else:
+            exp = orc.disparity_ssd(left, right, rad, lo, hi, flags)
+        assert np.array_equal(host(stereo.disparitySSD(dev(left), dev(right), rad, lo, hi, flags, ctx=exact)), exp)
+        assert np.array_equal(host(stereo.disparitySSD(dev(left), dev(right), rad, lo, hi, flags, ctx=flt)), exp)
+        assert np.array_equal(stereo.disparitySSD(left, right, rad, lo, hi, flags), exp)  # host entry, default options
+
+
+def test_ssd_exact_sum_kernels_leave_other_images_to_the_float_kernels(M):
+    """One pixel that is not an integer in 0..255 (a fraction, a negative, 256, NaN): the pre-pass finds it on the
+    device and the float kernels do the call -- same result as with the exact-sum path switched off, and the oracle's."""
+    harris, stereo, hough, synth = M
+    exact, flt = _stereo_ctxs()
+    rng = np.random.default_rng(3)
+    for bad in (0.5, -1.0, 256.0, np.nan):
+        for side in (0, 1):
+            left, right = _u8_pair(rng, 64, 200, "noise")
+            (left if side == 0 else right)[40, 100] = bad
+            exp = orc.disparity_ssd(left, right, 5, -30, 0)
+            assert np.array_equal(host(stereo.disparitySSD(dev(left), dev(right), 5, -30, 0, ctx=exact)), exp)
+            assert np.array_equal(host(stereo.disparitySSD(dev(left), dev(right), 5, -30, 0, ctx=flt)), exp)
+            # the next call on the same context with clean images takes the exact-sum kernels again
+            l2, r2 = _u8_pair(rng, 64, 200, "noise")
+            assert np.array_equal(host(stereo.disparitySSD(dev(l2), dev(r2), 5, -30, 0, ctx=exact)),
+                                  orc.disparity_ssd(l2, r2, 5, -30, 0))
+
+
+@pytest.mark.parametrize("rad,lo,hi,flags,kind", [
+    (2, -20, 0, 0, "noise"), (3, -70, 5, 1, "levels"), (5, -127, 0, 0, "flat"), (5, -128, 127, 8, "levels"),
+    (6, 0, 127, 0, "noise"), (7, -100, 27, 1, "flat"), (4, -5, 5, 0, "far")])
+def test_ncorr_exact_sum_kernels_on_request(M, rad, lo, hi, flags, kind):
+    """MICV_OPT_STEREO_EXACT = 1: disparityNCorr searches with an approximate score and settles every pixel whose best
+    scores are within rounding noise of each other by the contract's own arithmetic -- equal and nearly equal scores
+    (three grey levels, flat patches, windows of zeros) included; byte for byte the oracle's result."""
+    harris, stereo, hough, synth = M
+    exact, flt = _stereo_ctxs()
+    rng = np.random.default_rng(rad * 77 + hi)
+    for rows, cols in ((9, 40), (33, 141), (64, 203)):
+        left, right = _u8_pair(rng, rows, cols, kind)
+        exp = orc.disparity_ncorr(left, right, rad, lo, hi, flags)
+        assert np.array_equal(host(stereo.disparityNCorr(dev(left), dev(right), rad, lo, hi, flags, ctx=exact)), exp)
+        assert np.array_equal(host(stereo.disparityNCorr(dev(left), dev(right), rad, lo, hi, flags, ctx=flt)), exp)
+
+
 def test_ssd_1080p_c3_bit_exact(M):
     """BASELINE C3 at full size against the oracle: 1080x1920, 11x11 window, all 128 candidate
-    disparities (d in [-127, 0]), every pixel, byte for byte."""
+    disparities (d in [-127, 0]), every pixel, byte for byte -- through the exact-sum kernels (the default for this
+    8-bit-valued pair) and through the float kernels."""
     harris, stereo, hough, synth = M
     left, right, negd = synth.stereo_pair(0x5EED0002, 1080, 1920)
     exp = orc.disparity_ssd(left, right, 5, -127, 0)
     got = host(stereo.disparitySSD(dev(left), dev(right), 5, -127, 0))
     assert got.dtype == np.int8 and np.array_equal(got, exp)
+    exact, flt = _stereo_ctxs()
+    assert np.array_equal(host(stereo.disparitySSD(dev(left), dev(right), 5, -127, 0, ctx=flt)), exp)
     # the reference's own geometry: right-reference pass d in [0, 127]
     exp_r = orc.disparity_ssd(right, left, 5, 0, 127)
     assert np.array_equal(host(stereo.disparitySSD(dev(right), dev(left), 5, 0, 127)), exp_r)
