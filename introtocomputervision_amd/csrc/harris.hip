@@ -264,7 +264,10 @@ __global__ __launch_bounds__(16 * TH) void harris_image_response_kernel(const fl
     // (packed f32: both columns per instruction), products straight into the planes.  The row pass of both filters and
     // the column pass are sobel_fused_kernel<3>'s fmaf chains from +0 with the float row-pass value in between.
     constexpr int SEG = 3, NSEG = (RH + SEG - 1) / SEG, NJ = (PC / 2) * NSEG;
-    const bool interior = img_vec_ok && x0 >= 8 && x0 + TW + 8 <= cols && y0 - R - 1 >= 0 && y0 + TH + R + 1 <= rows;
+    // (rows: the jobs load SEG + 2 rows each, NSEG * SEG + 2 in all -- up to two more than the TH + 2 R + 2 the tile needs
+    // when RH is not a multiple of SEG; the test covers what is LOADED, not what is used: ADVICE r5, an exact-size image
+    // with rows % TH in 2..5 was read one or two rows past its end)
+    const bool interior = img_vec_ok && x0 >= 8 && x0 + TW + 8 <= cols && y0 - R - 1 >= 0 && y0 - R + NSEG * SEG + 1 <= rows;
     for (int n = threadIdx.x; n < NJ; n += NT) {
         const int seg = n / (PC / 2), lx = 2 * (n - seg * (PC / 2));
         const int q0 = seg * SEG;

@@ -1015,7 +1015,11 @@ static int lk_pyr_batch(micv_ctx *ctx, hipStream_t s, const float *prev, const f
     // launch per pair and step -- ~330 launches per call at 8 pairs and 5 levels, and the host was the limit): the warped
     // frames and the ten product / sum planes of every pair.
     // (at most kGenChunk pairs per launch: blockIdx.z carries 5 x pairs fields in the four-launch form)
-    constexpr int kGenChunk = 4096;
+    // ... and at most 1 GiB of these temporaries (11 level-0 planes per pair: 8 x 1080p take 0.73 GB and stay one chunk;
+    // 64 x 1080p reserved 5.8 GB of the context's one scratch block for good)
+    const size_t gen_pair_bytes = (n0 + lk_generic_scratch(rows, cols)) * sizeof(float);
+    const size_t gen_fit = (size_t(1) << 30) / gen_pair_bytes;
+    const int kGenChunk = gen_fit < 1 ? 1 : (gen_fit > 4096 ? 4096 : (int)gen_fit);
     const int gen_nb = batch < kGenChunk ? batch : kGenChunk;
     if (!fused) total += Carver::need(n0 * gen_nb, 4) + Carver::need(lk_generic_scratch(rows, cols) * gen_nb, 4);
     // MICV_OPT_LK_SPLIT: the padded gradient planes of the largest level some launch of the chain will split (the

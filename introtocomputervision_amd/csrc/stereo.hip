@@ -185,6 +185,7 @@ __device__ __forceinline__ void stereo_tile(const StereoArgs &a, float *st_lds, 
 #define MICV_STEREO_PF 2
 #endif
     constexpr int PF = MODE == ST_NCC ? MICV_STEREO_PF : 0;  // 0 = no prefetch, 1 = the right strip, 2 = + the energy strip
+    static_assert(MODE != ST_NCC || PF == 2, "the NCC staging below reads the prefetched energy strip (pre_e)");
     constexpr int NH = (ST_SPAN + 63) / 64;
     float pre_r[PF >= 1 ? STEPS : 1][NH], pre_e[PF >= 2 && ESTEPS > 0 ? ESTEPS : 1][NH];
     auto load_r = [&](int d0, int s, int h) {
@@ -509,10 +510,13 @@ static int launch_stereo(hipStream_t s, const StereoArgs &a, int r, int force_rp
 #define MICV_ST_LAUNCH(RR, RPW)                                                                    \
     do {                                                                                           \
         if (MODE == ST_NCC) {                                                                      \
+            /*  the staged strips of a 64-disparity chunk pass 64 KB of dynamic LDS for 2 RPW + 2 R > 32 */ \
+            /* (radius 9, 10; radius 7, 8 at 10 rows): those instantiations keep the 32-disparity chunk */          \
+            constexpr int DCH = (2 * RPW + 2 * RR) * (64 + MICV_NCC_DCH) * 16 > 65536 ? 32 : MICV_NCC_DCH;           \
             stereo_energy_kernel<RR, RPW><<<dim3(cdiv(a.e_width, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256, 0, s>>>( \
                 a, const_cast<float *>(a.energy));                                                 \
-            stereo_kernel<RR, MODE, RPW, MICV_NCC_DCH><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256, \
-                                              4 * (2 * RPW + 2 * RR) * (64 + MICV_NCC_DCH) * sizeof(float), s>>>(a); \
+            stereo_kernel<RR, MODE, RPW, DCH><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256, \
+                                              4 * (2 * RPW + 2 * RR) * (64 + DCH) * sizeof(float), s>>>(a); \
         } else {                                                                                   \
             stereo_kernel<RR, MODE, RPW><<<dim3(cdiv(a.cols, 64 - 2 * RR), cdiv(a.rows, 4 * RPW)), 256, \
                                            4 * (RPW + 2 * RR) * (64 + ST_DCH_DEFAULT) * sizeof(float), s>>>(a); \

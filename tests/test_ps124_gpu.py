@@ -678,3 +678,23 @@ def test_harris_corners_chain_other_sizes_host_form_and_views(M):
     assert np.array_equal(host(v["locs"]), host(locs))
     with pytest.raises(Exception):
         harris.cornersFromImage(dev(img), 4, 5, 1.5, 0.04, 5e8, 5)
+
+
+@pytest.mark.parametrize("win", [3, 5, 7])
+@pytest.mark.parametrize("rows", [67, 69, 98, 100, 131])
+def test_harris_image_tiles_read_nothing_below_the_image(M, win, rows):
+    """the fused Sobel -> response tiles load their rows in jobs of three, so a tile could count as interior
+    while its last job reached one or two rows past the image (rows % 16 in 3..5, rows % 32 in 2..4).  The image here
+    is the LAST rows of its allocation (torch's caching allocator rounds the block, so the read cannot be made to fault:
+    the test pins the result -- identical to the three separate calls -- and the predicate is what is LOADED, harris.hip)."""
+    harris, stereo, hough, synth = M
+    cols = 200
+    img = synth.checkerboard(rows + 40, cols, square=20, seed=rows * 10 + win)[:rows]
+    buf = torch.full((rows + 64, cols), float("nan"), device="cuda")  # whatever lies below must not matter either
+    view = buf[:rows]
+    view.copy_(dev(img))
+    gx, gy = harris.getGradients(dev(img), 3)
+    R = harris.getCornerResponse(gx, gy, win, 1.5, 0.04)
+    for d in (view, buf[64:64 + rows].copy_(dev(img))):  # below: NaN rows / the end of the allocation
+        out = harris.cornersFromImage(d, 3, win, 1.5, 0.04, 5e8, 5, want_response=True)
+        assert host(out["response"]).tobytes() == host(R).tobytes()
