@@ -704,7 +704,7 @@ def main(argv=None):
     # The drop-in path a cv::Mat caller links (micv_lk_flow_pyr_host: upload, kernels, download, sync in
     # every call, like OpticalFlow.cpp:12-39 / Pyramids.cu:34-73): one pair per call, pageable inputs,
     # preallocated outputs.  PCIe-inclusive, reported beside `value`, never as `value`.
-    host_pair_ms = None
+    host_pair_ms = host_seq_ms = host_seq8_ms = host_seq_same = None
     if args.mode == "pairs" and rank == 0:
         from introtocomputervision_amd._capi import check as _check, lib as _lib
         hu = np.zeros((ROWS, COLS), np.float32)
@@ -722,6 +722,39 @@ def main(argv=None):
             host_call()
             ts.append(time.perf_counter() - t0)
         host_pair_ms = sorted(ts)[len(ts) // 2] * 1e3
+        # the same boundary fed the way the ps5 driver feeds it -- consecutive frames of a sequence (Solution.cpp:255-285):
+        # micv_lk_flow_seq_host, every frame uploaded once, upload / chain / download of consecutive pairs overlapped
+        nseq = 16
+
+        def page_aligned(n_img):  # images on pages of their own, as separately allocated cv::Mats are (one registration each)
+            raw = np.zeros(n_img * ROWS * COLS + 1024, np.float32)
+            off = (-raw.ctypes.data % 4096) // 4
+            return raw[off:off + n_img * ROWS * COLS].reshape(n_img, ROWS, COLS)
+        sf = page_aligned(nseq)
+        for i in range(nseq):
+            sf[i] = prev_h[i % len(prev_h)] if i % 2 == 0 else next_h[i % len(next_h)]
+        seq = [sf[i] for i in range(nseq)]
+        su, sv = page_aligned(nseq - 1), page_aligned(nseq - 1)   # preallocated and touched, like hu / hv above
+        lk.calcOpticalFlowPyrSequence(seq, WIN, LEVELS, ctx=hctx, out=(su, sv))
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            lk.calcOpticalFlowPyrSequence(seq, WIN, LEVELS, ctx=hctx, out=(su, sv))
+            ts.append((time.perf_counter() - t0) / (nseq - 1))
+        host_seq_ms = sorted(ts)[len(ts) // 2] * 1e3
+        pu, pv = lk.calcOpticalFlowPyrFrames(seq[4], seq[5], WIN, LEVELS, ctx=hctx)
+        host_seq_same = bool(np.array_equal(su[4], pu) and np.array_equal(sv[4], pv))
+        # ... and on 8-bit frames, what the driver's cv::imread hands over (the synthetic frames ARE 8-bit-valued): the
+        # upload shrinks to 2 MB per frame, the device converts (micv_to_gray_f32_dev)
+        seq8 = [f.astype(np.uint8) for f in seq]
+        lk.calcOpticalFlowPyrSequence(seq8, WIN, LEVELS, ctx=hctx, out=(su, sv))
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            lk.calcOpticalFlowPyrSequence(seq8, WIN, LEVELS, ctx=hctx, out=(su, sv))
+            ts.append((time.perf_counter() - t0) / (nseq - 1))
+        host_seq8_ms = sorted(ts)[len(ts) // 2] * 1e3
+        host_seq_same = host_seq_same and bool(np.array_equal(su[4], pu) and np.array_equal(sv[4], pv))
         hctx.close()
 
     # sanity of what was measured: known translation comes back (not part of the timing)
@@ -892,6 +925,13 @@ def main(argv=None):
                 "host_pair_ms": host_pair_ms,
                 "host_pair_note": "micv_lk_flow_pyr_host, one 1080p pair per call: 33.2 MB over PCIe (pageable "
                                   "= pinned = 53 GB/s here: 0.62 ms) + the device call; PCIe-inclusive, not `value`",
+                "host_sequence_ms_per_pair": host_seq_ms,
+                "host_sequence_u8_ms_per_pair": host_seq8_ms,
+                "host_sequence_note": "micv_lk_flow_seq_host, 16 x 1080p frames = 15 pairs per call: one upload per frame "
+                                      "(f32: 8.3 MB, 8-bit: 2.1 MB + device conversion) and one download per pair (16.6 MB) beside "
+                                      "the chains; copies from / to pageable memory do not overlap each other on this platform "
+                                      "(0.157 + 0.31 ms per f32 pair is the floor; profiles/r06/host_sequence.md); "
+                                      "pair 4 byte-identical to the per-pair call, f32 and 8-bit: " + str(host_seq_same),
             },
             "sustained": sustained,
             "algorithmic_GBps_pipeline": value * 1e6 * algorithmic_bytes_pair(ROWS, COLS, LEVELS)

@@ -313,6 +313,17 @@ int micv_to_gray_f32_host(micv_ctx *ctx, const void *src, int rows, int cols, si
 int micv_lk_flow_pyr_frames_host(micv_ctx *ctx, const void *prev, const void *next, int rows, int cols,
                                  size_t stride, int channels, int depth, int win, int levels, float *u,
                                  float *v, size_t ostride);
+/* lk::calcOpticalFlowPyr over a sequence of frames: pairs (0, 1), (1, 2), ..., (nframes - 2, nframes - 1) -- the way
+ * the ps5 driver walks the frames of a directory (ps5_cpp/lib/Config.cpp:17-46, src/Solution.cpp:255-285; frame t is
+ * `next` of one lk::calcOpticalFlowPyr call and `prev` of the following one).  frames[t]: nframes host images of one
+ * format (as micv_lk_flow_pyr_frames_host); u[p], v[p]: nframes - 1 host outputs, rows x cols f32, ostride bytes.
+ * Every frame crosses PCIe once; upload of frame t + 2, the chain of pair t + 1 and the download of pair t run at
+ * the same time (uploads on the calling thread, the chains on their own stream, downloads on two helper threads: a
+ * copy from / to the caller's pageable memory occupies the thread that issues it).  Byte-identical to nframes - 1 calls
+ * of micv_lk_flow_pyr_frames_host.  Blocking; one call at a time per context, like every other entry point. */
+int micv_lk_flow_seq_host(micv_ctx *ctx, const void *const *frames, int nframes, int rows, int cols, size_t stride,
+                          int channels, int depth, int win, int levels, float *const *u, float *const *v,
+                          size_t ostride);
 /* cv::resize(..., INTER_LINEAR) on f32 as used at OpticalFlow.cpp:149-150. */
 int micv_resize_linear_dev(micv_ctx *ctx, const float *src, int srows, int scols, size_t sstride,
                            float *dst, int drows, int dcols, size_t dstride, micv_stream stream);

@@ -98,6 +98,7 @@ SIGNATURES = {
     "micv_to_gray_f32_dev": (i32, [vp, vp, i32, i32, sz, i32, i32, vp, sz, vp]),
     "micv_to_gray_f32_host": (i32, [vp, vp, i32, i32, sz, i32, i32, vp, sz]),
     "micv_lk_flow_pyr_frames_host": (i32, [vp, vp, vp, i32, i32, sz, i32, i32, i32, i32, vp, vp, sz]),
+    "micv_lk_flow_seq_host": (i32, [vp, C.POINTER(vp), i32, i32, i32, sz, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(vp), sz]),
     "micv_resize_linear_dev": (i32, [vp, vp, i32, i32, sz, vp, i32, i32, sz, vp]),
     # ps4
     "micv_sobel_dev": (i32, [vp, vp, i32, i32, sz, i32, f32, vp, vp, sz, vp]),

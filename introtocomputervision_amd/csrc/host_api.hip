@@ -3,6 +3,9 @@
 // download inside every call, e.g. Harris.cu:118-158, Pyramids.cu:45-72); it is PCIe-bound
 // by construction.  Device buffers are allocated per call like the reference's GpuMats.
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -164,6 +167,146 @@ int micv_lk_flow_pyr_frames_host(micv_ctx *ctx, const void *prev, const void *ne
     MICV_TRY(down2d(u, ostride, du.p, rb, rows, s));
     MICV_TRY(down2d(v, ostride, dv.p, rb, rows, s));
     MICV_HIP(hipStreamSynchronize(s));
+    return MICV_OK;
+}
+
+/* lk::calcOpticalFlowPyr over a SEQUENCE of frames -- pairs (0, 1), (1, 2), ... as the ps5 driver walks a directory
+ * (ps5_cpp/lib/Config.cpp:17-46, src/Solution.cpp:255-285: frame t is `next` of one call and `prev` of the following one).
+ * A per-pair `_host` call moves four images over PCIe one after the other around its kernels (0.745 ms per 1080p pair,
+ * r05).  Here every frame is uploaded ONCE, and the legs run side by side:
+ *   upload     frame t + 2 -> raw block -> grey f32 (device conversion), ring of three frames; the calling thread
+ *   compute    pair t + 1: the pyramid chain (micv_lk_flow_pyr_dev) on its own stream, ring of three flow outputs
+ *   download   pair t: u, v -> the caller's buffers, a thread and a stream of their own
+ * The caller's images are pageable memory, and a copy from / to pageable memory occupies the thread that issues it
+ * (streams alone do not overlap such copies: tools/probes/pcie_probe.py) -- hence the download thread.  What r06 tried
+ * instead and measured slower per 1080p f32 pair (profiles/r06/host_sequence.md): registering the caller's images in place
+ * (hipHostRegister: a fresh registration costs 0.07 ms per image and serialises with the transfers in flight, 0.71 ms),
+ * pinned staging rings with host copies on three threads (a host copy into / out of pinned memory runs at 30 GB/s here,
+ * 0.27 ms per image: 0.65 ms).  Same bits as the per-pair calls. */
+int micv_lk_flow_seq_host(micv_ctx *ctx, const void *const *frames, int nframes, int rows, int cols, size_t stride,
+                          int channels, int depth, int win, int levels, float *const *u, float *const *v,
+                          size_t ostride) {
+    MICV_REQUIRE(ctx != nullptr, "micv_lk_flow_seq_host: ctx is null");
+    MICV_REQUIRE(frames && u && v && nframes >= 2 && rows > 0 && cols > 0, "micv_lk_flow_seq_host: bad argument");
+    MICV_REQUIRE((channels == 1 || channels == 3 || channels == 4) && (depth == MICV_DEPTH_8U || depth == MICV_DEPTH_32F),
+                 "micv_lk_flow_seq_host: frames must be 1/3/4-channel 8U or 32F");
+    const size_t es = depth == MICV_DEPTH_8U ? 1 : 4, srb = (size_t)cols * channels * es;
+    MICV_REQUIRE(stride >= srb && stride_ok(ostride, cols, 4), "micv_lk_flow_seq_host: bad stride");
+    for (int t = 0; t < nframes; t++) MICV_REQUIRE(frames[t] != nullptr, "micv_lk_flow_seq_host: frame %d is null", t);
+    for (int t = 0; t + 1 < nframes; t++) MICV_REQUIRE(u[t] && v[t], "micv_lk_flow_seq_host: output %d is null", t);
+    MICV_HIP(hipSetDevice(ctx->device));
+    ::micv::io_ctx = ctx;
+    const bool convert = !(channels == 1 && depth == MICV_DEPTH_32F);
+    const size_t rb = (size_t)cols * 4, n = rb * rows;
+    constexpr int RING = 3;
+    DevBuf raw(convert ? srb * rows : 256), g0(n), g1(n), g2(n), u0(n), u1(n), u2(n), v0(n), v1(n), v2(n);
+    MICV_ALLOC_OK(raw); MICV_ALLOC_OK(g0); MICV_ALLOC_OK(g1); MICV_ALLOC_OK(g2);
+    MICV_ALLOC_OK(u0); MICV_ALLOC_OK(u1); MICV_ALLOC_OK(u2); MICV_ALLOC_OK(v0); MICV_ALLOC_OK(v1); MICV_ALLOC_OK(v2);
+    float *grey[RING] = {g0.as<float>(), g1.as<float>(), g2.as<float>()};
+    float *du[RING] = {u0.as<float>(), u1.as<float>(), u2.as<float>()}, *dv[RING] = {v0.as<float>(), v1.as<float>(), v2.as<float>()};
+    const int npairs = nframes - 1;
+
+    struct Scope {  // released on every way out, after everything enqueued has finished
+        hipStream_t up = nullptr, run = nullptr, down[2] = {nullptr, nullptr};
+        std::vector<hipEvent_t> ev;
+        ~Scope() {
+            for (hipStream_t st : {up, run, down[0], down[1]})
+                if (st) (void)hipStreamSynchronize(st);
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+            for (hipStream_t st : {up, run, down[0], down[1]})
+                if (st) (void)hipStreamDestroy(st);
+        }
+    } st;
+    MICV_HIP(hipStreamCreateWithFlags(&st.up, hipStreamNonBlocking));
+    MICV_HIP(hipStreamCreateWithFlags(&st.run, hipStreamNonBlocking));
+    MICV_HIP(hipStreamCreateWithFlags(&st.down[0], hipStreamNonBlocking));
+    MICV_HIP(hipStreamCreateWithFlags(&st.down[1], hipStreamNonBlocking));
+    st.ev.reserve((size_t)nframes + (size_t)npairs);
+    auto new_event = [&](hipEvent_t *e) -> int {
+        MICV_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        st.ev.push_back(*e);
+        return MICV_OK;
+    };
+    std::vector<hipEvent_t> ev_up(nframes), ev_pair(npairs);
+    for (auto &e : ev_up) MICV_TRY(new_event(&e));
+    for (auto &e : ev_pair) MICV_TRY(new_event(&e));
+
+    // The download threads: pair p's field is copied out once its chain has finished.  `enqueued` / `done[]` order them
+    // against the calling thread: a flow block is written again only after its previous content has reached the caller.
+    std::mutex mu;
+    std::condition_variable cv;
+    int enqueued = 0, done[2] = {0, 0};
+    bool stop = false, failed = false;
+    char down_err[256] = "";
+    auto download = [&](int which) {
+        (void)hipSetDevice(ctx->device);
+        for (int p = 0; p < npairs; p++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return enqueued > p || stop; });
+                if (enqueued <= p) return;  // the calling thread gave up
+            }
+            int rc = hipStreamWaitEvent(st.down[which], ev_pair[p], 0) == hipSuccess ? MICV_OK : MICV_EHIP;
+            if (rc == MICV_OK) rc = down2d(u[p], ostride, du[p % RING], rb, rows, st.down[which]);
+            if (rc == MICV_OK) rc = down2d(v[p], ostride, dv[p % RING], rb, rows, st.down[which]);
+            if (rc == MICV_OK && hipStreamSynchronize(st.down[which]) != hipSuccess) rc = MICV_EHIP;
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc != MICV_OK && !failed) {
+                failed = true;
+                snprintf(down_err, sizeof(down_err), "micv_lk_flow_seq_host: download of pair %d failed: %s", p, micv_last_error());
+            }
+            done[0] = done[1] = p + 1;
+            cv.notify_all();
+        }
+    };
+    // (ONE thread for both fields: two -- a stream and a thread per field -- measured slower, 0.48-0.52 against 0.45 ms
+    // per pair: copies to pageable memory do not overlap each other either)
+    std::thread tu(download, 0);
+    struct Joiner {  // (declared after Scope: runs first -- the thread is gone before its stream is)
+        std::thread &a; std::mutex &mu; std::condition_variable &cv; bool &stop;
+        ~Joiner() {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            if (a.joinable()) a.join();
+        }
+    } joiner{tu, mu, cv, stop};
+
+    for (int t = 0; t < nframes; t++) {
+        // frame t takes the grey block frame t - 3 had: pairs t - 4 and t - 3 read that one
+        if (t >= RING) MICV_HIP(hipStreamWaitEvent(st.up, ev_pair[t - RING], 0));
+        if (convert) {
+            MICV_TRY(up2d(raw.p, frames[t], stride, srb, rows, st.up));
+            MICV_TRY(micv_to_gray_f32_dev(ctx, raw.p, rows, cols, srb, channels, depth, grey[t % RING], rb, st.up));
+        } else {
+            MICV_TRY(up2d(grey[t % RING], frames[t], stride, rb, rows, st.up));
+        }
+        MICV_HIP(hipEventRecord(ev_up[t], st.up));
+        if (t == 0) continue;
+        const int p = t - 1;
+        if (p >= RING) {  // the flow blocks pair p - 3 used must have reached the caller
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return (done[0] >= p - RING + 1 && done[1] >= p - RING + 1) || failed; });
+            if (failed) break;
+        }
+        MICV_HIP(hipStreamWaitEvent(st.run, ev_up[t], 0));  // (frame t - 1: earlier on the same streams)
+        MICV_TRY(micv_lk_flow_pyr_dev(ctx, grey[p % RING], grey[t % RING], rows, cols, rb, win, levels, du[p % RING],
+                                      dv[p % RING], rb, st.run));
+        MICV_HIP(hipEventRecord(ev_pair[p], st.run));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            enqueued = p + 1;
+        }
+        cv.notify_all();
+    }
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return (done[0] >= enqueued && done[1] >= enqueued) || failed; });
+        if (failed) {
+            set_error("%s", down_err);
+            return MICV_EHIP;
+        }
+        if (enqueued < npairs) return MICV_EHIP;  // (unreachable: every early way out returns above)
+    }
     return MICV_OK;
 }
 

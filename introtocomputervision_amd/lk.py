@@ -136,6 +136,39 @@ def calcOpticalFlowPyrFrames(prevImg, nextImg, winSize=21, levels=4, ctx=None):
     return u, v
 
 
+def calcOpticalFlowPyrSequence(frames, winSize=21, levels=4, ctx=None, out=None):
+    """lk::calcOpticalFlowPyr over consecutive frames -- pairs (0, 1), (1, 2), ... -- as the ps5 driver walks a directory
+    of frames (ps5_cpp/src/Solution.cpp:255-285).  `frames`: a list of equal-shape host (numpy) frames, uint8 or float32,
+    grey or colour.  Every frame is uploaded once; upload, pyramid chain and download of consecutive pairs overlap
+    (micv_lk_flow_seq_host).  Returns (u, v) as [len(frames) - 1, rows, cols] float32 arrays (`out`, when given),
+    byte-identical to the per-pair calcOpticalFlowPyrFrames results."""
+    import ctypes as C
+    fs = [np.ascontiguousarray(f) for f in frames]
+    if len(fs) < 2:
+        raise ValueError("frames: at least two frames expected")
+    a = fs[0]
+    if a.dtype not in (np.uint8, np.float32) or a.ndim not in (2, 3) or any(f.shape != a.shape or f.dtype != a.dtype for f in fs):
+        raise ValueError("frames: equal-shape uint8 or float32 frames expected")
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    rows, cols = a.shape[:2]
+    n = len(fs) - 1
+    if out is None:
+        u = np.empty((n, rows, cols), np.float32)
+        v = np.empty((n, rows, cols), np.float32)
+    else:  # the caller's buffers (already touched pages: a fresh allocation is faulted in page by page during the download)
+        u, v = out
+        for a_, name in ((u, "out[0]"), (v, "out[1]")):
+            if not (isinstance(a_, np.ndarray) and a_.dtype == np.float32 and a_.shape == (n, rows, cols) and a_.flags.c_contiguous):
+                raise ValueError(f"{name}: a C-contiguous float32 array of shape {(n, rows, cols)} expected")
+    fp = (C.c_void_p * len(fs))(*[f.ctypes.data for f in fs])
+    up = (C.c_void_p * n)(*[u[i].ctypes.data for i in range(n)])
+    vp_ = (C.c_void_p * n)(*[v[i].ctypes.data for i in range(n)])
+    c = ctx if ctx is not None else default_context(0)
+    check(lib.micv_lk_flow_seq_host(c.handle, fp, len(fs), rows, cols, cols * cn * a.dtype.itemsize, cn,
+                                    0 if a.dtype == np.uint8 else 5, int(winSize), int(levels), up, vp_, cols * 4))
+    return u, v
+
+
 def calcOpticalFlowPyrBatch(prev, next_, winSize=21, levels=4, ctx=None, out=None, stream=None):
     """Batched device form: prev/next are [B, rows, cols] f32 CUDA tensors (contiguous).
     Returns (u, v) of the same shape.  One set of launches for the whole batch."""

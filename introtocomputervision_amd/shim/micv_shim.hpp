@@ -202,6 +202,35 @@ inline void calcOpticalFlowPyrLevels(const Mat &prevImg, const Mat &nextImg, Mat
 inline void calcOpticalFlowPyr(const Mat &prevImg, const Mat &nextImg, Mat &u, Mat &v, const size_t winSize = 21) {
     calcOpticalFlowPyrLevels(prevImg, nextImg, u, v, winSize, 4);
 }
+// An extension for the driver's frame loops (ps5_cpp/src/Solution.cpp:255-285: pairs (0, 1), (1, 2), ... of the frames
+// Config.cpp:17-46 loaded from a directory): the same flows as calling lk::calcOpticalFlowPyr pair by pair, with every
+// frame uploaded once and transfers overlapped with the chains (micv_lk_flow_seq_host).  u[p], v[p]: pair (p, p + 1).
+inline void calcOpticalFlowPyrSequence(const std::vector<Mat> &frames, std::vector<Mat> &u, std::vector<Mat> &v,
+                                       const size_t winSize = 21, const size_t levels = 4) {
+    micv_shim::require(frames.size() >= 2, "lk::calcOpticalFlowPyrSequence: at least two frames expected");
+    const Mat &f0 = frames[0];
+    micv_shim::require(micv_shim::frame_type_ok(f0), "lk::calcOpticalFlowPyrSequence: 1/3/4-channel CV_8U or CV_32F frames expected");
+    std::vector<const void *> fp;
+    for (const Mat &f : frames) {
+        micv_shim::require(f.rows == f0.rows && f.cols == f0.cols && f.type() == f0.type() && f.step == f0.step,
+                           "lk::calcOpticalFlowPyrSequence: frames of one size, type and row pitch expected");
+        fp.push_back(f.data);
+    }
+    const size_t n = frames.size() - 1;
+    std::vector<Mat> uu, vv;
+    std::vector<float *> up, vp;
+    for (size_t p = 0; p < n; p++) {
+        uu.emplace_back(f0.rows, f0.cols, micv_shim::F32);
+        vv.emplace_back(f0.rows, f0.cols, micv_shim::F32);
+        up.push_back(uu.back().ptr<float>());
+        vp.push_back(vv.back().ptr<float>());
+    }
+    micv_shim::check(micv_lk_flow_seq_host(micv_shim::context(), fp.data(), static_cast<int>(frames.size()), f0.rows, f0.cols,
+                                           f0.step, f0.channels(), micv_shim::depth_code(f0), static_cast<int>(winSize),
+                                           static_cast<int>(levels), up.data(), vp.data(), uu[0].step));
+    u = uu;
+    v = vv;
+}
 }  // namespace lk
 
 namespace pyr {

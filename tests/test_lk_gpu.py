@@ -956,3 +956,24 @@ def test_generic_chain_chunks_a_very_large_batch(mods):
         eu, ev = orc.lk_flow_pyr(prev[b], nxt[b], 5, 2)
         assert np.array_equal(host(u[b]), eu) and np.array_equal(host(v[b]), ev), b
     assert torch.equal(u[4096:], u[:nb - 4096]) and torch.equal(v[4096:], v[:nb - 4096])
+
+
+@pytest.mark.parametrize("n,shape,dtype", [(2, (48, 80), np.float32), (4, (96, 160, 3), np.uint8), (8, (135, 240), np.uint8),
+                                           (6, (70, 100, 4), np.float32)])
+def test_frame_sequence_matches_the_per_pair_host_calls(n, shape, dtype):
+    """lk.calcOpticalFlowPyrSequence (micv_lk_flow_seq_host): flows of pairs (t, t + 1) byte-identical to the per-pair host
+    entry, which the other tests pin to the oracle."""
+    from introtocomputervision_amd import lk
+    rng = np.random.default_rng(n * 7 + len(shape))
+    base = (rng.random(shape) * 255).astype(np.float32)
+    frames = []
+    for t in range(n):
+        f = np.roll(base, (t, 2 * t), axis=(0, 1)) + (rng.random(shape) * 3).astype(np.float32)
+        frames.append(np.clip(f, 0, 255).astype(dtype))
+    su, sv = lk.calcOpticalFlowPyrSequence(frames, 15, 4)
+    assert su.shape == (n - 1,) + tuple(shape[:2])
+    for p in range(n - 1):
+        pu, pv = lk.calcOpticalFlowPyrFrames(frames[p], frames[p + 1], 15, 4)
+        assert np.array_equal(su[p], pu) and np.array_equal(sv[p], pv), p
+    with pytest.raises(ValueError):
+        lk.calcOpticalFlowPyrSequence(frames[:1], 15, 4)

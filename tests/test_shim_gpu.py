@@ -180,3 +180,27 @@ def test_kernel_log_callback_python():
     n = len(got)
     pyr.pyrDown(img)
     assert len(got) == n
+
+
+def build_seq_demo(tmp):
+    exe = os.path.join(tmp, "seq_demo")
+    lib = os.path.join(ROOT, "introtocomputervision_amd")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "seq_demo.cpp"),
+                    "-o", exe, "-L" + lib, "-lmicv", "-Wl,-rpath," + lib], check=True)
+    return exe
+
+
+def test_sequence_demo_compiles_on_cpu(tmp_path):
+    build_seq_demo(str(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rows,cols,cn,f32", [(2, 40, 64, 1, 1), (3, 96, 160, 3, 0), (7, 120, 200, 1, 0), (9, 67, 131, 4, 1),
+                                                 (5, 540, 960, 3, 0)])
+def test_frame_sequence_entry_from_cpp(tmp_path, n, rows, cols, cn, f32):
+    """micv_lk_flow_seq_host (every frame uploaded once; upload, chain and download of consecutive pairs overlapped) and
+    the shim's lk::calcOpticalFlowPyrSequence, called from C++ through the C ABI: byte-identical to n - 1 per-pair
+    micv_lk_flow_pyr_frames_host calls -- grey / colour, 8-bit / f32 frames, 2 to 9 frames (the rings hold three)."""
+    exe = build_seq_demo(str(tmp_path))
+    out = subprocess.run([exe, str(n), str(rows), str(cols), str(cn), str(f32)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
