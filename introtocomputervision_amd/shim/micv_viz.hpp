@@ -318,6 +318,29 @@ inline std::pair<Mat, Mat> denseLKWrapper(const Mat &prevImg, const Mat &nextImg
     return std::make_pair(u.clone(), v.clone());
 }
 
+// The driver's frame loops (runProblem4, Solution.cpp:255-285: denseLKWrapper on frames (0, 1), (1, 2), ... of a
+// directory): the hierarchical flows of all consecutive pairs in ONE call of the frame-sequence entry (every frame
+// uploaded once, transfers beside the chains), then denseLKWrapper's drawing per pair.  Files: <prefix>/<name><p><ext>.
+inline std::vector<std::pair<Mat, Mat>> denseLKSequence(const std::vector<Mat> &frames, const size_t windowSize,
+                                                        const std::string &filePrefix, const std::string &outputImg,
+                                                        bool saveColorMaps = true, const std::string &ext = ".ppm") {
+    std::vector<Mat> u, v;
+    lk::calcOpticalFlowPyrSequence(frames, u, v, windowSize);
+    std::vector<std::pair<Mat, Mat>> out;
+    for (size_t p = 0; p < u.size(); p++) {
+        const std::string name = outputImg + std::to_string(p);
+        Mat velocityVectors = frames[p].clone();
+        drawVelocityVectors(velocityVectors, u[p], v[p], Scalar(0, 255, 0, 255));
+        imwrite(filePrefix + "/" + name + ext, velocityVectors);
+        if (saveColorMaps) {
+            imwrite(filePrefix + "/" + name + "-uColorMap" + ext, apply_colormap_jet(normalize_minmax_u8(u[p])));
+            imwrite(filePrefix + "/" + name + "-vColorMap" + ext, apply_colormap_jet(normalize_minmax_u8(v[p])));
+        }
+        out.emplace_back(u[p], v[p]);
+    }
+    return out;
+}
+
 // cv::resize(src, dst, size, fx, fy, INTER_NEAREST) for an integer up-scale factor k.
 inline Mat resize_nearest(const Mat &src, int rows, int cols) {
     Mat dst(rows, cols, src.type());

@@ -136,3 +136,29 @@ def test_ps5_demo_end_to_end(tmp_path, mode, win):
     iy = np.minimum(np.floor(np.arange(rows) * (l3.shape[0] / rows)).astype(int), l3.shape[0] - 1)
     ix = np.minimum(np.floor(np.arange(cols) * (l3.shape[1] / cols)).astype(int), l3.shape[1] - 1)
     assert np.array_equal(pyr[rows:, cols:], l3[iy][:, ix])
+
+
+@pytest.mark.gpu
+def test_ps5_demo_sequence_mode(tmp_path):
+    """examples/ps5_demo --sequence: four colour frames on disk -> the flows of the three consecutive pairs through ONE
+    call of the frame-sequence entry (micv_viz::denseLKSequence), each pair's files equal to the oracle's."""
+    import _oracle as orc
+    from introtocomputervision_amd import viz
+    d = str(tmp_path)
+    rows, cols = 120, 200
+    frames = []
+    for t in range(4):
+        _, _, pc, nc = _frames(rows, cols, 0x5EED0005 + t)
+        frames.append(pc if t % 2 == 0 else nc)
+        viz.imwrite(os.path.join(d, f"f{t}.ppm"), frames[-1])
+    exe = os.path.join(d, "ps5_demo")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "examples", "ps5_demo.cpp"), "-o", exe,
+                    "-L" + LIB, "-lmicv", "-Wl,-rpath," + LIB], check=True)
+    r = subprocess.run([exe, "--sequence", d, "15"] + [os.path.join(d, f"f{t}.ppm") for t in range(4)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for p in range(3):
+        eu, ev = orc.lk_flow_pyr(orc.to_gray(frames[p]), orc.to_gray(frames[p + 1]), 15, 4)
+        u = np.fromfile(os.path.join(d, f"u{p}.f32"), np.float32).reshape(rows, cols)
+        v = np.fromfile(os.path.join(d, f"v{p}.f32"), np.float32).reshape(rows, cols)
+        assert np.array_equal(u, eu) and np.array_equal(v, ev), p
+        assert np.array_equal(viz.imread(os.path.join(d, f"flow{p}.ppm")), viz.drawVelocityVectors(frames[p], eu, ev))
