@@ -68,7 +68,7 @@ size_t micv_ctx_scratch_bytes(const micv_ctx *ctx);
 #define MICV_OPT_LK_BUILD_OVERLAP  14 /* fused LK, window 15, >= 3 levels: no pyramid-build launch -- the top level reads level 0 itself and the launch of every level k >= 2 carries the build of level k - 1 as extra workgroups behind its tiles: 0 = for single pairs only (default: the latency case; with several passes in flight a batch is faster with the build launch), -1 = never, 1 = for every batch */
 #define MICV_OPT_LK_SPLIT          15 /* fused LK, window 15: a level launch SPLIT in two (r05, lk_split.hip) -- a pre-pass (pyrUp + warp + Sobel once per pixel, Ix / Iy / It into padded planes in HBM) plus a streaming window-sum kernel that carries its row-pass rows from block to block: 0 = never (default: measured 28-42 % slower than the fused launch, HBM traffic 2.4-3x), 1 = every whole-frame launch of at least 64 x 64 with a doubling coarse flow, 2 = 1 with the base flow through u, v, 3 = the pre-pass leaves only the warped image and the second half is the fused kernel in its no-flow mode */
 #define MICV_OPT_LK_STRIP          16 /* fused LK, window 15: the INTERIOR tiles of a level launch as vertical strips that a workgroup streams down in blocks of 16 rows, carrying the last 14 row-pass rows of the five product fields and two warped rows from block to block (lk_strip.hpp) -- no vertical halo recomputation; the border tiles of the same launch stay tiles: 0 = off (default: 15 % fewer instructions, the same time -- DESIGN.md section 5), n > 0 = on with row segments of n blocks (16 = 256 rows); + 8192 = only for launches of 4096 tiles or more */
-#define MICV_OPT_STEREO_EXACT      17 /* window stereo on 8-bit-valued images (integers 0..255 in both f32 images, radius <= 7): 0 = disparitySSD through the exact-sum kernels (stereo_exact.hip: integer dot products, sliding window sums, lanes = disparities), chosen on the device per call by a pre-pass that tests every pixel (default); 1 = disparityNCorr too (faster on textured images, slower on nearly flat ones: its exact route for scores within rounding noise of each other); -1 = always the float kernels that add every window in the contract's order.  Same disparities either way: all sums are integers below 2^24, exact in f32 in any order */
+#define MICV_OPT_STEREO_EXACT      17 /* disparitySSD on 8-bit-valued images (integers 0..255 in both f32 images, radius <= 7; serial:: semantics radius <= 5): 0 = the exact-sum kernels (stereo_exact.hip: integer dot products, sliding window sums, lanes = disparities), chosen on the device per call by a pre-pass that tests every pixel (default); -1 = always the float kernels that add every window in the contract's order.  Same disparities either way: all sums are integers below 2^24, exact in f32 in any order.  (disparityNCorr always takes the float kernels.) */
 #define MICV_OPT_COUNT            18
 int micv_ctx_set_option(micv_ctx *ctx, int option, int value);
 int micv_ctx_get_option(const micv_ctx *ctx, int option, int *value);

@@ -367,7 +367,7 @@ int micv_ctx_set_option(micv_ctx *ctx, int option, int value) {
     if (option == MICV_OPT_LK_STRIP)
         MICV_REQUIRE(value >= 0 && value <= 8192 + 4096 && (value & 8191) <= 4096, "micv_ctx_set_option: strip segments must be 0 (off) .. 4096 blocks of 16 rows (+ 8192: launches of 4096 tiles or more only)");
     if (option == MICV_OPT_STEREO_EXACT)
-        MICV_REQUIRE(value >= -1 && value <= 1, "micv_ctx_set_option: exact-sum stereo must be 0 (SSD), 1 (SSD and NCC) or -1 (never)");
+        MICV_REQUIRE(value >= -1 && value <= 0, "micv_ctx_set_option: exact-sum stereo must be 0 (automatic) or -1 (never)");
     ctx->opt[option] = value;
     return MICV_OK;
 }

@@ -572,12 +572,8 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
     }
     // 8-bit-valued images (every plain ps2 call, main.cpp:87-88): the exact-sum kernels go first and the kernels below
     // return at once unless the pack pre-pass found a pixel that is not an integer in 0..255 (no host round trip).
-    // (disparityNCorr takes them only on request, option value 1: its search orders candidates by an approximate score
-    // and sends every pixel whose best scores lie within the contract's own rounding noise through an exact route --
-    // a win on textured images, a loss on nearly flat ones such as the C3 synthetic pair)
-    const int xopt = ctx->opt[MICV_OPT_STEREO_EXACT];
-    const bool exact = xopt >= (ncc ? 1 : 0) && stereo_exact_covers(rad, flags, ncc);
-    const size_t exact_bytes = exact ? stereo_exact_scratch(rows, cols, rad, min_d, max_d, a.wcols, ncc, ctx->wave_slots(3)) : 0;
+    const bool exact = ctx->opt[MICV_OPT_STEREO_EXACT] >= 0 && stereo_exact_covers(rad, flags, ncc);
+    const size_t exact_bytes = exact ? stereo_exact_scratch(rows, cols, rad, min_d, max_d, a.wcols, ctx->wave_slots(3)) : 0;
     void *scratch = nullptr;
     if (energy_bytes + exact_bytes) MICV_TRY(ctx->reserve(energy_bytes + exact_bytes, &scratch));
     if (energy_bytes) a.energy = static_cast<const float *>(scratch);
@@ -588,7 +584,7 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
         a.fallback_flag = flag;
         a.epoch = ++ctx->stereo_epoch;
         MICV_TRY(stereo_exact_launch(s, static_cast<char *>(scratch) + energy_bytes, left, right, rows, cols, a.stride, rad,
-                                     min_d, max_d, flags, a.wcols, disp, a.dstride, ncc, flag, a.epoch, ctx->wave_slots(3)));
+                                     min_d, max_d, flags, a.wcols, disp, a.dstride, flag, a.epoch, ctx->wave_slots(3)));
     }
     if (flags & MICV_STEREO_ROLLING) {
         const dim3 grid(cdiv(cdiv(cols, 64 - 2 * rad), ST_ROLL_WAVES), cdiv(rows, ST_STRIP));

@@ -37,7 +37,6 @@
 #include <utility>
 
 #include "kernels.hpp"
-#include "ncc_arith.hpp"
 #include "stereo_exact.hpp"
 
 namespace micv {
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(256) void stereo_prep_kernel(StereoExactArgs a) {
     constexpr int NR = SX_Y + 2 * R, NG = sx_groups(R), WMAX = 2 * R + 1;
     __shared__ uint32_t csB[SX_Y][256 + WMAX], csA[SX_Y][256 + WMAX];
     const int s = blockIdx.y, q0 = a.qlo + blockIdx.x * 256;
-    const bool want_a = a.min_ssd_5e6 != 0 || a.ncc != 0;
+    const bool want_a = a.min_ssd_5e6 != 0;
     bool ok = true;
     for (int u = threadIdx.x; u < 256 + a.wcols - 1; u += 256) {
         const int q = q0 + u, qc = clampi(q, 0, a.cols - 1);
@@ -214,80 +213,27 @@ struct SxLds {
     __host__ __device__ int t_words() const { return npos_t * 9; }
     __host__ __device__ int words() const { return r_words() + t_words() + nbatch * res_stride; }
 };
-__host__ __device__ inline SxLds sx_lds_layout(int NG, int X, int WC, int nchunks, bool ncc) {
+__host__ __device__ inline SxLds sx_lds_layout(int NG, int X, int WC, int nchunks) {
     SxLds l;
     const int nouter = (X + WC - 1) / WC;
     l.rs = NG | 1;
     l.npos_r = nouter * WC + WC - 1 + 64;  // window columns of nouter * WC outputs, + 63 disparities, + 1
     l.npos_t = nouter * WC + 64;
     l.nbatch = (nouter * WC + 7) / 8;
-    l.res_stride = nchunks <= 2 && !ncc ? 64 : 80;
+    l.res_stride = nchunks <= 2 ? 64 : 80;
     return l;
 }
 
 #ifndef MICV_SX_WAVES
 #define MICV_SX_WAVES 3
 #endif
-enum { SX_SSD = 0, SX_SERIAL = 1, SX_NCC = 2 };
-
-// The slow, exact route of the NCC search for ONE pixel (wave-uniform y, x): every disparity's correlation summed
-// afresh from the packed words (lanes = disparities), the contract's score fl(C / fl(sqrt(fl(AT E)))) through the
-// exact short sequences of ncc_arith.hpp (all operands are integers below 2^24), first maximum.  Taken for the few
-// pixels whose approximate scores leave the winner open (see stereo_exact_kernel).
-template <int R, int WC>
-__device__ __forceinline__ int sx_ncc_pixel(const StereoExactArgs &a, int y, int x) {
-    constexpr int NG = sx_groups(R);
-    const int lane = threadIdx.x & 63;
-    const int s = y / SX_Y, J = y - s * SX_Y;  // window rows J .. J + 2 R of the strip
-    uint32_t mask[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        const int lo = J > 4 * g ? J : 4 * g, hi = J + 2 * R < 4 * g + 3 ? J + 2 * R : 4 * g + 3;
-        mask[g] = lo > hi ? 0u : (0xFFFFFFFFu << (8 * (lo - 4 * g))) & (0xFFFFFFFFu >> (8 * (4 * g + 3 - hi)));
-    }
-    const float at = (float)a.A[(size_t)y * a.cols + x];
-    float best = 0.f;  // DisparityNCorr.cu:16,212
-    int bestd = 0x7fffffff;
-    for (int d = a.min_d + lane; d <= a.max_d; d += 64) {
-        uint32_t C = 0, rw[WC][NG];
-#pragma unroll
-        for (int wx = 0; wx < WC; wx++) {  // every load first
-            const int rc = clampi(x - R + wx + d, 0, a.cols - 1);
-#pragma unroll
-            for (int g = 0; g < NG; g++) rw[wx][g] = a.rpack[((size_t)s * NG + g) * a.colsP + rc];
-        }
-#pragma unroll
-        for (int wx = 0; wx < WC; wx++) {
-            const uint32_t *lrec = a.lplan + ((size_t)s * a.lcols + x + wx) * SX_LW;  // record of column x - R + wx
-#pragma unroll
-            for (int g = 0; g < NG; g++) C = __builtin_amdgcn_udot4(lrec[g] & mask[g], rw[wx][g], C, false);
-        }
-        const float e = (float)a.B[(size_t)y * a.nB + (x + d - a.min_d)];
-        const float nc = ncc_div((float)C, ncc_sqrt(at * e));  // DisparityNCorr.cu:106
-        if (nc > best) {  // :108 (NaN -- a window of zeros -- never is); ascending d within the lane
-            best = nc;
-            bestd = d;
-        }
-    }
-    // first maximum over the lanes: the largest score, then the lowest disparity
-    float m = best;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    int dm = best == m && m > 0.f ? bestd : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int t = __shfl_xor(dm, o);
-        dm = t < dm ? t : dm;
-    }
-    return dm == 0x7fffffff ? -1 : dm;
-}
+enum { SX_SSD = 0, SX_SERIAL = 1 };
 
 template <int R, int WC, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MICV_SX_WAVES, MICV_SX_WAVES)))
 void stereo_exact_kernel(StereoExactArgs a) {
-    constexpr bool SERIAL = MODE == SX_SERIAL, NCC = MODE == SX_NCC;
+    constexpr bool SERIAL = MODE == SX_SERIAL;
     constexpr int NG = sx_groups(R), P = WC - 1, RS = NG | 1, TS = 9;
-    constexpr int NCC_NEAR = 24;  // scores within this many float steps of a pixel's best leave the winner open
     extern __shared__ uint32_t sx_lds[];
     if (__builtin_nontemporal_load(a.flag) == a.epoch) return;  // not 8-bit-valued: the float kernel does this call
     const int lane = threadIdx.x & 63;
@@ -296,7 +242,7 @@ void stereo_exact_kernel(StereoExactArgs a) {
     if (tile >= a.ntiles) return;  // whole wave; waves never synchronise with each other
     const int s = tile / a.nxs, ys = s * SX_Y, x0 = (tile - s * a.nxs) * a.X;
     const int nchunks = (a.max_d - a.min_d) / 64 + 1;
-    const SxLds lay = sx_lds_layout(NG, a.X, WC, nchunks, NCC);
+    const SxLds lay = sx_lds_layout(NG, a.X, WC, nchunks);
     uint32_t *Rs = sx_lds + wave * lay.words();
     int32_t *Ts = reinterpret_cast<int32_t *>(Rs + lay.r_words());
     int32_t *res = Ts + lay.t_words();
@@ -347,8 +293,6 @@ void stereo_exact_kernel(StereoExactArgs a) {
                     for (int j = 0; j < SX_Y; j++) {
                         int k = -(t[q][j] << 6) - i;
                         if (SERIAL && (p < -R || p > a.cols - 1 + R)) k = SX_INVALID - i;  // DisparitySSD.cpp:42-43
-                        // NCC: 1 / sqrt(E) to an ulp or two (0 for a window of zeros: its score is NaN in the contract, never a maximum)
-                        if (NCC) k = t[q][j] > 0 ? __float_as_int(__builtin_amdgcn_rsqf((float)t[q][j])) : 0;
                         Ts[i * TS + j] = k;
                     }
                 }
@@ -380,10 +324,7 @@ void stereo_exact_kernel(StereoExactArgs a) {
 #pragma unroll
             for (int j = 0; j < SX_Y; j++) Cp[j] += ring[k][j];
         }
-        int cur = 0, curd = 0;                                                     // NCC: curd = the winners' lanes
-        unsigned long long open = 0;                                              // NCC: pixels of the batch whose winner is open
-        const unsigned long long valid = nvalid >= 64 ? ~0ull : (1ull << nvalid) - 1;  // lanes that are disparities of their own
-        (void)curd; (void)open; (void)valid;
+        int cur = 0;
         // The packed left words of a column are fetched ONE COLUMN AHEAD, by hand: a scalar load shares its counter with
         // the LDS reads and returns out of order, so the compiler waits for everything (lgkmcnt(0)) at the first LDS use
         // behind one -- issued at the top of its own column the load's whole latency was exposed, once per column
@@ -423,15 +364,10 @@ void stereo_exact_kernel(StereoExactArgs a) {
                     sx_colsums<R, NG>(lw, rw, cs, std::make_index_sequence<SX_Y>{});
                 }
                 int key[SX_Y];
-                uint32_t Cfull[NCC ? SX_Y : 1];
 #pragma unroll
                 for (int j = 0; j < SX_Y; j++) {
                     const uint32_t C = Cp[j] + cs[j];
-                    if (NCC) Cfull[j] = C;
-                    if (NCC)
-                        key[j] = __float_as_int((float)C * __int_as_float(tk[j]));  // ~ C / sqrt(E): orders like the score (AT is the pixel's)
-                    else
-                        key[j] = (int)(C << 7) + tk[j];
+                    key[j] = (int)(C << 7) + tk[j];
                     Cp[j] = C - ring[m][j];
                 }
                 // next column's record (the last step of the unrolled body reads past the pointer bump below)
@@ -440,73 +376,12 @@ void stereo_exact_kernel(StereoExactArgs a) {
                 const int colres = sx_reduce8(key);
                 const unsigned long long sel = 0x0101010101010101ull << (x_rel & 7);  // lanes 8 j + (x_rel & 7)
                 asm("v_cndmask_b32 %0, %0, %1, %2" : "+v"(cur) : "v"(colres), "s"(sel));
-                if constexpr (NCC) {
-                    // The key carries no lane: find each row's winner among the lanes whose score is within NCC_NEAR float
-                    // steps of the row's maximum (v_readlane brings it back).  Normally that is ONE lane -- the maximum's.
-                    // More than one (equal scores, or scores the approximation cannot tell apart: error < 2^-20 relative,
-                    // see DESIGN.md) marks the pixel for the exact route after the search.
-                    int nnear = 0;
-#pragma unroll
-                    for (int j = 0; j < SX_Y; j++) {
-                        const int mj = __builtin_amdgcn_readlane(colres, 8 * j);
-                        const unsigned long long near = __builtin_amdgcn_ballot_w64((unsigned)(mj - key[j]) <= (unsigned)NCC_NEAR) & valid;
-                        nnear += __builtin_popcountll(near);
-                        // (one SGPR per VALU instruction on gfx9: the lane select goes through M0; both are SALU results)
-                        asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0"
-                            : "+v"(curd) : "s"((int)__builtin_ctzll(near)), "s"(8 * j + (x_rel & 7)));  // (M0 is not otherwise used by this kernel: no LDS-DMA, no s_movrel; checked in the ISA)
-                    }
-                    if (nnear != SX_Y) {
-                        // Seldom: some row has several near lanes.  They are harmless when they are the SAME window
-                        // seen through several disparities (columns clamped at the image's edge, flat regions): equal
-                        // correlation and equal energy, hence equal scores in the contract too -- the lowest lane wins,
-                        // which is what ctz picked.  (The energy comes from the global field: this branch only.)  A row
-                        // whose maximum is 0 has no winner at all (the flush writes -1).  Everything else is open.
-#pragma unroll
-                        for (int j = 0; j < SX_Y; j++) {
-                            const int mj = __builtin_amdgcn_readlane(colres, 8 * j);
-                            const unsigned long long near = __builtin_amdgcn_ballot_w64((unsigned)(mj - key[j]) <= (unsigned)NCC_NEAR) & valid;
-                            if (mj != 0 && __builtin_popcountll(near) != 1) {
-                                const int yy = ys + j < a.rows ? ys + j : a.rows - 1;
-                                const int pi = x0 + x_rel + d0 + dl - a.min_d;
-                                const int e = a.B[(size_t)yy * a.nB + (pi < a.nB ? pi : a.nB - 1)];
-                                const int wl = __builtin_ctzll(near);
-                                const int cw = __builtin_amdgcn_readlane((int)Cfull[j], wl), ew = __builtin_amdgcn_readlane(e, wl);
-                                const unsigned long long same = __builtin_amdgcn_ballot_w64((int)Cfull[j] == cw && e == ew && key[j] == mj);
-                                if ((near & ~same) != 0) open |= 1ull << (8 * j + (x_rel & 7));
-                            }
-                        }
-                    }
-                }
                 if ((x_rel & 7) == 7) {
                     // lane 8 j + c: row j, output column 8 b + c of this strip
                     const int b = x_rel >> 3, xr = 8 * b + (lane & 7), j = lane >> 3;
                     int32_t *rb = res + b * lay.res_stride;
                     const int y = ys + j, x = x0 + xr;
                     const bool inside = xr < a.X && x < a.cols && y < a.rows;
-                    if constexpr (NCC) {
-                        // score word: the approximate score's bits, bit 0 = "winner open"
-                        int sc = cur & ~1, d = d0 + curd;
-                        int op = (int)((open >> lane) & 1);
-                        if (chunk > 0) {
-                            const int pw = rb[lane], ps = pw & ~1;
-                            const int pd = reinterpret_cast<const int8_t *>(rb + 64)[lane];
-                            const int diff = sc > ps ? sc - ps : ps - sc;
-                            op |= (pw & 1) | (diff <= NCC_NEAR + 2 && (sc | ps) != 0 ? 1 : 0);
-                            if (!(sc > ps)) {  // the lower disparity wins ties
-                                sc = ps;
-                                d = pd;
-                            }
-                        }
-                        if (chunk + 1 < nchunks) {
-                            rb[lane] = sc | op;
-                            reinterpret_cast<int8_t *>(rb + 64)[lane] = (int8_t)d;
-                        } else {
-                            if (inside) a.disp[(size_t)y * a.dstride + x] = (int8_t)(sc > 0 ? d : -1);  // DisparityNCorr.cu:212: best starts at 0
-                            const unsigned long long todo = __builtin_amdgcn_ballot_w64(op != 0 && inside);
-                            if (lane < 2) rb[lane] = (int)(lane ? todo >> 32 : todo);
-                        }
-                        open = 0;
-                    } else {
                     auto decode = [&](int k, int dbase, int &score, int &d) {
                         const int dsel = ((-k) - xr) & 63;
                         score = (k + xr + dsel) >> 6;  // 2 C - B, exact
@@ -543,7 +418,6 @@ void stereo_exact_kernel(StereoExactArgs a) {
                         }
                         a.disp[(size_t)y * a.dstride + x] = (int8_t)d;
                     }
-                    }
                 }
             }
             rp += WC * RS;
@@ -553,30 +427,12 @@ void stereo_exact_kernel(StereoExactArgs a) {
         // the last column's look-ahead load is still in flight: its registers are free for reuse only once it has landed
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lraw));
     }
-    if constexpr (NCC) {
-        // the open pixels, one at a time, by the exact route
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int nb = (nouter * WC) >> 3;  // batches flushed
-        for (int b = 0; b < nb; b++) {
-            const int32_t *rb = res + b * lay.res_stride;
-            unsigned long long todo = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rb[0]) |
-                                      ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(rb[1]) << 32);
-            while (todo) {
-                const int l = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int y = ys + (l >> 3), x = x0 + 8 * b + (l & 7);
-                const int d = sx_ncc_pixel<R, WC>(a, y, x);
-                if (lane == 0) a.disp[(size_t)y * a.dstride + x] = (int8_t)d;
-            }
-        }
-    }
 }
 
 template <int R, int WC, int MODE>
 static int launch_search(hipStream_t s, const StereoExactArgs &a) {
     const int nchunks = (a.max_d - a.min_d) / 64 + 1;
-    const size_t lds = 4 * (size_t)sx_lds_layout(sx_groups(R), a.X, WC, nchunks, MODE == SX_NCC).words() * sizeof(uint32_t);
+    const size_t lds = 4 * (size_t)sx_lds_layout(sx_groups(R), a.X, WC, nchunks).words() * sizeof(uint32_t);
     auto k = stereo_exact_kernel<R, WC, MODE>;
     static size_t attr_set[16] = {0};  // per device: the launch may need more than 64 KB of dynamic LDS
     int dev = 0;
@@ -596,7 +452,6 @@ static int launch_r(hipStream_t s, const StereoExactArgs &a, bool serial) {
     stereo_prep_kernel<R><<<dim3(cdiv(a.qhi - a.qlo, 256), nstrips), 256, 0, s>>>(a);
     MICV_LAUNCH_CHECK();
     const bool full = a.wcols == 2 * R + 1;
-    if (a.ncc) return full ? launch_search<R, 2 * R + 1, SX_NCC>(s, a) : launch_search<R, 2 * R, SX_NCC>(s, a);
     if (serial) return full ? launch_search<R, 2 * R + 1, SX_SERIAL>(s, a) : MICV_EUNSUPPORTED;
     if (full) return launch_search<R, 2 * R + 1, SX_SSD>(s, a);
     return launch_search<R, 2 * R, SX_SSD>(s, a);
@@ -605,6 +460,11 @@ static int launch_r(hipStream_t s, const StereoExactArgs &a, bool serial) {
 }  // namespace
 
 bool stereo_exact_covers(int rad, int flags, bool ncc) {
+    // disparityNCorr stays with the float kernels: its score's own roundings decide between candidates wherever the image is
+    // nearly flat (the C3 pair: a quarter of the pixels), and an approximate-score search with an exact route for those
+    // pixels -- built and bit-exact in r06 -- was slower than the float kernel on flat AND on textured 1080p pairs
+    // (0.88 / 0.60 ms against 0.316; profiles/r06/stereo_exact.md)
+    if (ncc) return false;
     if (rad < 1 || rad > 7) return false;                       // (2r+1)^2 * 255^2 < 2^24
     if ((flags & MICV_STEREO_SERIAL) && rad > 5) return false;  // the invalid-position keys need a spare bit
     if ((flags & MICV_STEREO_COLS_2R) && rad < 2) return false;
@@ -613,7 +473,7 @@ bool stereo_exact_covers(int rad, int flags, bool ncc) {
 
 // Output columns per wave: a wave's work is X + wcols - 1 columns (+ staging); the launch takes ceil(waves / slots)
 // rounds of the chip's resident waves.  Picks the strip count with the least (rounds x columns).
-static void sx_tiling(int rows, int cols, int rad, int wcols, int nchunks, bool ncc, int wave_slots3, int *X_out, int *nxs_out) {
+static void sx_tiling(int rows, int cols, int rad, int wcols, int nchunks, int wave_slots3, int *X_out, int *nxs_out) {
     const int nstrips = cdiv(rows, SX_Y), XMAX = 128;
     long best_cost = -1;
     int bx = XMAX, bn = cdiv(cols, XMAX);
@@ -622,7 +482,7 @@ static void sx_tiling(int rows, int cols, int rad, int wcols, int nchunks, bool 
         if (X > XMAX) continue;
         const long waves = (long)nstrips * cdiv(cols, X);
         // three waves per SIMD while a wave's LDS stays within a twelfth of the CU's 160 KB, else two
-        const size_t lds = (size_t)sx_lds_layout(sx_groups(rad), X, wcols, nchunks, ncc).words() * 4;
+        const size_t lds = (size_t)sx_lds_layout(sx_groups(rad), X, wcols, nchunks).words() * 4;
         long slots = lds * 12 <= 160 * 1024 ? wave_slots3 : wave_slots3 / 3 * 2;
         if (MICV_SX_WAVES == 4) {
             if (lds * 16 > 160 * 1024) continue;
@@ -639,7 +499,7 @@ static void sx_tiling(int rows, int cols, int rad, int wcols, int nchunks, bool 
 
 static void sx_geometry(StereoExactArgs &a, int rad, int wave_slots3) {
     const int nchunks = (a.max_d - a.min_d) / 64 + 1;
-    sx_tiling(a.rows, a.cols, rad, a.wcols, nchunks, a.ncc != 0, wave_slots3, &a.X, &a.nxs);
+    sx_tiling(a.rows, a.cols, rad, a.wcols, nchunks, wave_slots3, &a.X, &a.nxs);
     a.ntiles = (int)cdiv(a.rows, SX_Y) * a.nxs;
     a.colsP = (a.cols + 63) & ~63;
     a.nB = a.cols + (a.max_d - a.min_d);
@@ -651,9 +511,9 @@ static void sx_geometry(StereoExactArgs &a, int rad, int wave_slots3) {
     if (a.qhi < a.cols) a.qhi = a.cols;
 }
 
-size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, bool ncc, int wave_slots3) {
+size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int wave_slots3) {
     StereoExactArgs a;
-    a.rows = rows; a.cols = cols; a.min_d = min_d; a.max_d = max_d; a.wcols = wcols; a.ncc = ncc;
+    a.rows = rows; a.cols = cols; a.min_d = min_d; a.max_d = max_d; a.wcols = wcols;
     sx_geometry(a, rad, wave_slots3);
     const int nstrips = cdiv(rows, SX_Y);
     return Carver::need((size_t)nstrips * a.lcols * SX_LW, 4) + Carver::need((size_t)nstrips * sx_groups(rad) * a.colsP, 4) +
@@ -662,11 +522,11 @@ size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, i
 
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
                         int stride, int rad, int min_d, int max_d, int flags, int wcols, int8_t *disp, int dstride,
-                        bool ncc, unsigned *flag, unsigned epoch, int wave_slots3) {
+                        unsigned *flag, unsigned epoch, int wave_slots3) {
     StereoExactArgs a;
     const int nstrips = cdiv(rows, SX_Y);
     a.left = left; a.right = right; a.stride = stride; a.rows = rows; a.cols = cols;
-    a.min_d = min_d; a.max_d = max_d; a.wcols = wcols; a.ncc = ncc;
+    a.min_d = min_d; a.max_d = max_d; a.wcols = wcols;
     sx_geometry(a, rad, wave_slots3);
     Carver cv(scratch);
     a.lplan = cv.take<uint32_t>((size_t)nstrips * a.lcols * SX_LW);

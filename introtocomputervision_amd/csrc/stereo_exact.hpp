@@ -21,15 +21,14 @@ struct StereoExactArgs {
     int dstride;
     int X, nxs, ntiles;  // output columns per wave, strips per row of strips, waves
     int min_ssd_5e6;
-    int ncc;  // disparityNCorr: the search maximises C / sqrt(AT E) instead of 2 C - B
 };
 
 // Whether the exact path has a kernel for this call at all (radius, flags); the images decide on the device.
 bool stereo_exact_covers(int rad, int flags, bool ncc);
-size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, bool ncc, int wave_slots3);
+size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int wave_slots3);
 // Enqueues pre-pass + search (wave_slots3: waves the device holds at three per SIMD).  `scratch` holds stereo_exact_scratch() bytes.
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
                         int stride, int rad, int min_d, int max_d, int flags, int wcols, int8_t *disp, int dstride,
-                        bool ncc, unsigned *flag, unsigned epoch, int wave_slots3);
+                        unsigned *flag, unsigned epoch, int wave_slots3);
 
 }  // namespace micv

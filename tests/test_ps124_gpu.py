@@ -342,10 +342,10 @@ def test_ssd_1080p_known_ramp(M):
 
 
 def _stereo_ctxs():
-    """(exact-sum kernels for SSD and NCC, float kernels only): MICV_OPT_STEREO_EXACT = 1 / -1."""
+    """(exact-sum kernels for disparitySSD = the default, float kernels only): MICV_OPT_STEREO_EXACT = 0 / -1."""
     from introtocomputervision_amd._capi import Context, OPT_STEREO_EXACT
     exact, flt = Context(0), Context(0)
-    exact.set_option(OPT_STEREO_EXACT, 1)
+    exact.set_option(OPT_STEREO_EXACT, 0)
     flt.set_option(OPT_STEREO_EXACT, -1)
     return exact, flt
 
@@ -411,12 +411,11 @@ def test_ssd_exact_sum_kernels_leave_other_images_to_the_float_kernels(M):
 
 
 @pytest.mark.parametrize("rad,lo,hi,flags,kind", [
-    (2, -20, 0, 0, "noise"), (3, -70, 5, 1, "levels"), (5, -127, 0, 0, "flat"), (5, -128, 127, 8, "levels"),
-    (6, 0, 127, 0, "noise"), (7, -100, 27, 1, "flat"), (4, -5, 5, 0, "far")])
-def test_ncorr_exact_sum_kernels_on_request(M, rad, lo, hi, flags, kind):
-    """MICV_OPT_STEREO_EXACT = 1: disparityNCorr searches with an approximate score and settles every pixel whose best
-    scores are within rounding noise of each other by the contract's own arithmetic -- equal and nearly equal scores
-    (three grey levels, flat patches, windows of zeros) included; byte for byte the oracle's result."""
+    (2, -20, 0, 0, "noise"), (3, -70, 5, 1, "levels"), (5, -127, 0, 0, "flat"), (5, -128, 127, 8, "levels"), (4, -5, 5, 0, "far")])
+def test_ncorr_on_8bit_images_keeps_the_float_kernels(M, rad, lo, hi, flags, kind):
+    """disparityNCorr on the same 8-bit-valued pairs (equal and nearly equal scores: three grey levels, flat patches,
+    windows of zeros): the float kernels with either option value, byte for byte the oracle's result.  (An exact-sum NCC
+    search was built in r06 and dropped: slower than these kernels on flat and on textured pairs)"""
     harris, stereo, hough, synth = M
     exact, flt = _stereo_ctxs()
     rng = np.random.default_rng(rad * 77 + hi)
@@ -693,8 +692,10 @@ def test_harris_image_tiles_read_nothing_below_the_image(M, win, rows):
     buf = torch.full((rows + 64, cols), float("nan"), device="cuda")  # whatever lies below must not matter either
     view = buf[:rows]
     view.copy_(dev(img))
+    last = torch.full((rows + 64, cols), float("nan"), device="cuda")[64:]  # the image ends where the allocation does
+    last.copy_(dev(img))
     gx, gy = harris.getGradients(dev(img), 3)
     R = harris.getCornerResponse(gx, gy, win, 1.5, 0.04)
-    for d in (view, buf[64:64 + rows].copy_(dev(img))):  # below: NaN rows / the end of the allocation
+    for d in (view, last):
         out = harris.cornersFromImage(d, 3, win, 1.5, 0.04, 5e8, 5, want_response=True)
         assert host(out["response"]).tobytes() == host(R).tobytes()
