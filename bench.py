@@ -625,8 +625,8 @@ def main(argv=None):
                 comm_selftest = "ok"
             else:
                 # pairs mode: the communicator is diagnostic only, so it must not be able to take the measurement down
-                # with it -- it runs on a helper thread with a deadline (ctypes releases the GIL; a rank stuck inside
-                # ncclCommInitRank because a peer failed early is left behind, the bench goes on and says so)
+                # with it silently -- it runs on a helper thread with a deadline (ctypes releases the GIL); a failure is
+                # reported in the line and the bench goes on, a rank stuck inside ncclCommInitRank ends the run (below)
                 import threading
                 from introtocomputervision_amd import shard as _shard
                 box = {}
@@ -643,7 +643,16 @@ def main(argv=None):
                 th = threading.Thread(target=_run, daemon=True)
                 th.start()
                 th.join(timeout=float(os.environ.get("MICV_BENCH_SELFTEST_TIMEOUT_S", "90")))
-                comm_selftest = box.get("r", f"TIMEOUT on rank {rank} (no answer from micv_comm_create / micv_comm_selftest)")
+                if "r" not in box:
+                    # the helper may still be inside a collective on this process group and stream; going on to
+                    # all_gather_object and the timed steps beside it could interleave collectives out of order across the
+                    # ranks (a hang) or put RCCL work into the measured region.  A rank that cannot build a communicator in
+                    # 90 s has no measurement to give: say so and leave (the launcher ends the other ranks).
+                    sys.stderr.write(json.dumps({"error": f"comm selftest TIMEOUT on rank {rank}: no answer from micv_comm_create / "
+                                                          "micv_comm_selftest; nothing was timed"}) + "\n")
+                    sys.stderr.flush()
+                    os._exit(3)
+                comm_selftest = box["r"]
         except Exception as e:  # noqa: BLE001 -- reported in the JSON line
             comm_selftest = f"FAILED on rank {rank}: {e}"
             if args.mode == "rowshard":

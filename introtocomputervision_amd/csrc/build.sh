@@ -11,6 +11,9 @@ name="${MICV_OUT:-libmicv.so}"
 out="$here/../$name"
 obj="$here/.obj"
 [[ "$name" != "libmicv.so" ]] && obj="$here/.obj_${name%.so}"
+# objects are keyed on the extra flags as well (the audit's -DMICV_LK_COL_FULLWAIT rebuild used to leave its
+# objects where a later plain build would find them fresh and link them)
+[[ -n "${EXTRA_HIPCC_FLAGS:-}" ]] && obj="${obj}_$(printf '%s' "${EXTRA_HIPCC_FLAGS}" | cksum | cut -d' ' -f1)"
 mkdir -p "$obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 #   -fno-gpu-flush-denormals-to-zero  keep f32 subnormals, as the host oracle does.
@@ -37,8 +40,7 @@ echo "built $out"
 if [[ -n "${MICV_AUDIT:-}" && -z "${MICV_AUDIT_DONE:-}" ]]; then
   audit="$here/../../tools/audit_asm_loads.py"
   if ! python3 "$audit" ${EXTRA_HIPCC_FLAGS:-}; then
-    echo "audit failed: rebuilding lk_fused / lk_split with -DMICV_LK_COL_FULLWAIT"
-    rm -f "$obj/lk_fused.o" "$obj/lk_split.o"
+    echo "audit failed: rebuilding with -DMICV_LK_COL_FULLWAIT (its own object directory)"
     MICV_AUDIT_DONE=1 EXTRA_HIPCC_FLAGS="${EXTRA_HIPCC_FLAGS:-} -DMICV_LK_COL_FULLWAIT" bash "$here/build.sh"
     python3 "$audit" ${EXTRA_HIPCC_FLAGS:-} -DMICV_LK_COL_FULLWAIT
   fi
