@@ -573,7 +573,7 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
     // 8-bit-valued images (every plain ps2 call, main.cpp:87-88): the exact-sum kernels go first and the kernels below
     // return at once unless the pack pre-pass found a pixel that is not an integer in 0..255 (no host round trip).
     const bool exact = ctx->opt[MICV_OPT_STEREO_EXACT] >= 0 && stereo_exact_covers(rad, flags, ncc);
-    const size_t exact_bytes = exact ? stereo_exact_scratch(rows, cols, rad, min_d, max_d, a.wcols, ctx->wave_slots(3)) : 0;
+    const size_t exact_bytes = exact ? stereo_exact_scratch(rows, cols, rad, min_d, max_d, a.wcols, flags, ctx->wave_slots(3)) : 0;
     void *scratch = nullptr;
     if (energy_bytes + exact_bytes) MICV_TRY(ctx->reserve(energy_bytes + exact_bytes, &scratch));
     if (energy_bytes) a.energy = static_cast<const float *>(scratch);
@@ -582,7 +582,8 @@ static int stereo_common(const char *fn, micv_ctx *ctx, const float *left, const
         unsigned *flag;
         MICV_TRY(ctx->stereo_flag_word(&flag));
         a.fallback_flag = flag;
-        a.epoch = ++ctx->stereo_epoch;
+        if (++ctx->stereo_epoch == 0) ++ctx->stereo_epoch;  // (0 is what the flag word holds before any call)
+        a.epoch = ctx->stereo_epoch;
         MICV_TRY(stereo_exact_launch(s, static_cast<char *>(scratch) + energy_bytes, left, right, rows, cols, a.stride, rad,
                                      min_d, max_d, flags, a.wcols, disp, a.dstride, flag, a.epoch, ctx->wave_slots(3)));
     }

@@ -511,13 +511,13 @@ static void sx_geometry(StereoExactArgs &a, int rad, int wave_slots3) {
     if (a.qhi < a.cols) a.qhi = a.cols;
 }
 
-size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int wave_slots3) {
+size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int flags, int wave_slots3) {
     StereoExactArgs a;
     a.rows = rows; a.cols = cols; a.min_d = min_d; a.max_d = max_d; a.wcols = wcols;
     sx_geometry(a, rad, wave_slots3);
     const int nstrips = cdiv(rows, SX_Y);
     return Carver::need((size_t)nstrips * a.lcols * SX_LW, 4) + Carver::need((size_t)nstrips * sx_groups(rad) * a.colsP, 4) +
-           Carver::need((size_t)rows * cols, 4) + Carver::need((size_t)rows * a.nB, 4);
+           ((flags & MICV_STEREO_MIN_SSD_5E6) ? Carver::need((size_t)rows * cols, 4) : 0) + Carver::need((size_t)rows * a.nB, 4);
 }
 
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
@@ -531,7 +531,7 @@ int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const f
     Carver cv(scratch);
     a.lplan = cv.take<uint32_t>((size_t)nstrips * a.lcols * SX_LW);
     a.rpack = cv.take<uint32_t>((size_t)nstrips * sx_groups(rad) * a.colsP);
-    a.A = cv.take<int32_t>((size_t)rows * cols);
+    a.A = (flags & MICV_STEREO_MIN_SSD_5E6) ? cv.take<int32_t>((size_t)rows * cols) : nullptr;  // only the 5e6 threshold reads it
     a.B = cv.take<int32_t>((size_t)rows * a.nB);
     a.flag = flag; a.epoch = epoch;
     a.disp = disp; a.dstride = dstride;

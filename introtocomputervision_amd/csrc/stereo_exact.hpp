@@ -12,7 +12,7 @@ struct StereoExactArgs {
     int qlo, qhi;     // columns the pre-pass visits
     uint32_t *rpack;  // [strip][word][colsP]: packed rows of `right`
     int colsP;
-    int32_t *A;  // [rows][cols]  window energy of left at output x
+    int32_t *A;  // [rows][cols]  window energy of left at output x (MIN_SSD_5E6 only, else null)
     int32_t *B;  // [rows][nB]    window energy of right at position p = x + d, p - min_d in [0, nB)
     int nB;
     unsigned *flag;  // holds `epoch` once a pixel of this call was found not to be an integer in 0..255
@@ -25,7 +25,7 @@ struct StereoExactArgs {
 
 // Whether the exact path has a kernel for this call at all (radius, flags); the images decide on the device.
 bool stereo_exact_covers(int rad, int flags, bool ncc);
-size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int wave_slots3);
+size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int flags, int wave_slots3);
 // Enqueues pre-pass + search (wave_slots3: waves the device holds at three per SIMD).  `scratch` holds stereo_exact_scratch() bytes.
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
                         int stride, int rad, int min_d, int max_d, int flags, int wcols, int8_t *disp, int dstride,
