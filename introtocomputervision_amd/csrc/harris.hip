@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
     const int d = DT > 0 ? DT : d_rt;
     __shared__ float T[(TH + 2 * DMAX) * (TW + 2 * DMAX + 1)];
     __shared__ __attribute__((aligned(16))) float RM[(TH + 2 * DMAX) * TW];
-    __shared__ __attribute__((aligned(16))) int RN[(TH + 2 * DMAX) * TW];
+    // (counts as bytes -- a row window holds at most 2 d + 1 <= 33 equal cells: r06, 34 -> 26 KB of LDS for d = 5 = six
+    // workgroups per CU instead of four, and one dword store for four cells' counts)
+    __shared__ __attribute__((aligned(16))) unsigned char RN[(TH + 2 * DMAX) * TW];
     const int RW = TW + 2 * d, RH = TH + 2 * d, TS = RW | 1;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     // Staging: 128 lanes per region row (RW <= 96), two rows per pass of the workgroup, four
@@ -474,6 +476,24 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         const int xx = x0 - d + lx;
         const bool col_in = (unsigned)xx < (unsigned)cols;
         const int xc = clampi(xx, 0, cols - 1);
+        if constexpr (DT > 0) {
+            // every load of the tile in flight at once (r06: the kernel's time was the four dependent rounds of four loads)
+            constexpr int NRB = (TH + 2 * DT + 7) / 8;
+            float v[NRB][4];
+#pragma unroll
+            for (int b = 0; b < NRB; b++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    v[b][k] = resp[(size_t)clampi(y0 - d + 8 * b + 2 * k + lr, 0, rows - 1) * rstride + xc];
+#pragma unroll
+            for (int b = 0; b < NRB; b++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int ly = 8 * b + 2 * k + lr, yy = y0 - d + ly;
+                    if (ly < RH && lx < RW)
+                        T[ly * TS + lx] = (col_in && (unsigned)yy < (unsigned)rows) ? v[b][k] : __builtin_nanf("");
+                }
+        } else
         for (int rb = 0; rb < RH; rb += 8) {
             float v[4];
 #pragma unroll
@@ -502,7 +522,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
             int n[4];
             nms_window4<DT>(v, nullptr, m, n);
             *reinterpret_cast<hv4f *>(RM + r * TW + c4) = (hv4f){m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<int4 *>(RN + r * TW + c4) = make_int4(n[0], n[1], n[2], n[3]);
+            *reinterpret_cast<unsigned *>(RN + r * TW + c4) = (unsigned)n[0] | ((unsigned)n[1] << 8) | ((unsigned)n[2] << 16) | ((unsigned)n[3] << 24);
         }
         __syncthreads();
         // column pass: job = (column, group of four rows)
@@ -543,7 +563,7 @@ __global__ __launch_bounds__(256) void harris_nms_tiled_kernel(const float *__re
         int n = 0;
         for (int k = 0; k <= 2 * d; k++) n += tp[k] == m ? 1 : 0;
         RM[i] = m;
-        RN[i] = n;
+        RN[i] = (unsigned char)n;
     }
     __syncthreads();
     const int c = threadIdx.x & 63, x = x0 + c;
