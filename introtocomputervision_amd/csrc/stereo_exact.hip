@@ -93,17 +93,22 @@ __device__ __forceinline__ void sx_colsums(const uint32_t (&l)[NG], const uint32
 // search kernel walks it with a plain pointer); right: pack[s][g][column], columns 0 .. cols - 1.
 // Energies: B(y, p) = window sum of right^2 at position p = x + d (window columns p - R .. p - R + wcols - 1, each
 // clamped on its own), p in [min_d, cols - 1 + max_d]; A(y, x) the same of left at x (only MIN_SSD_5E6 reads it).
-// One workgroup = 256 consecutive columns q of one strip (+ wcols - 1 more for the windows that start in them).
+// One workgroup = 256 consecutive columns q of one strip, of which it owns the first 256 - (wcols - 1).
 template <int R>
 __global__ __launch_bounds__(256) void stereo_prep_kernel(StereoExactArgs a) {
     constexpr int NR = SX_Y + 2 * R, NG = sx_groups(R), WMAX = 2 * R + 1;
     __shared__ uint32_t csB[SX_Y][256 + WMAX], csA[SX_Y][256 + WMAX];
-    const int s = blockIdx.y, q0 = a.qlo + blockIdx.x * 256;
+    // ONE pass: a workgroup owns 256 - (wcols - 1) columns and its last wcols - 1 threads take the columns the windows that
+    // start in them reach into (with 256 owned columns those few threads ran a second pass alone, every load of it
+    // exposed: r06, 17.2 -> see profiles/r06/stereo_exact.md)
+    const int nown = 256 - (a.wcols - 1);
+    const int s = blockIdx.y, q0 = a.qlo + blockIdx.x * nown;
     const bool want_a = a.min_ssd_5e6 != 0;
     bool ok = true;
-    for (int u = threadIdx.x; u < 256 + a.wcols - 1; u += 256) {
+    {
+        const int u = threadIdx.x;
         const int q = q0 + u, qc = clampi(q, 0, a.cols - 1);
-        const bool own = u < 256;                                                   // this workgroup stores column q
+        const bool own = u < nown;                                                  // this workgroup stores column q
         const bool need_l = (own && q + R >= 0 && q + R < a.lcols) || want_a;
         uint32_t lw[SX_LW], rw[NG];
 #pragma unroll
@@ -151,7 +156,8 @@ __global__ __launch_bounds__(256) void stereo_prep_kernel(StereoExactArgs a) {
     if (!ok) *a.flag = a.epoch;  // every failing thread stores the same word
     __syncthreads();
     const int p = q0 + (int)threadIdx.x + R;  // the window that starts at column q0 + t
-    const bool b_ok = p >= a.min_d && p - a.min_d < a.nB, a_ok = want_a && p >= 0 && p < a.cols;
+    const bool mine = (int)threadIdx.x < nown;
+    const bool b_ok = mine && p >= a.min_d && p - a.min_d < a.nB, a_ok = mine && want_a && p >= 0 && p < a.cols;
     if (!b_ok && !a_ok) return;
 #pragma unroll
     for (int j = 0; j < SX_Y; j++) {
@@ -449,7 +455,7 @@ static int launch_search(hipStream_t s, const StereoExactArgs &a) {
 template <int R>
 static int launch_r(hipStream_t s, const StereoExactArgs &a, bool serial) {
     const int nstrips = cdiv(a.rows, SX_Y);
-    stereo_prep_kernel<R><<<dim3(cdiv(a.qhi - a.qlo, 256), nstrips), 256, 0, s>>>(a);
+    stereo_prep_kernel<R><<<dim3(cdiv(a.qhi - a.qlo, 256 - (a.wcols - 1)), nstrips), 256, 0, s>>>(a);
     MICV_LAUNCH_CHECK();
     const bool full = a.wcols == 2 * R + 1;
     if (serial) return full ? launch_search<R, 2 * R + 1, SX_SERIAL>(s, a) : MICV_EUNSUPPORTED;
