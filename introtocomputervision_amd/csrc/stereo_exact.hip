@@ -31,13 +31,14 @@
 // instructions per (pixel, disparity) of the float kernel that re-adds every window in the contract's order.
 //
 // Which images qualify is decided ON THE DEVICE, without a host round trip: the pack pre-pass tests every pixel
-// (integer, 0..255) and writes the launch's epoch into the context's flag word on the first failure; this kernel
-// returns at once when the flag holds its epoch, the float kernels of stereo.hip (launched behind it) when it does
-// not.  MICV_OPT_STEREO_EXACT = -1 never takes this path.
+// (integer, 0..255) and writes the launch's epoch into the context's flag word on the first failure; the search launch
+// holds the exact-sum tiles and, behind them, the float kernel's tiles of the same call (stereo_float.hpp) -- whichever
+// the flag does not select leave at once.  MICV_OPT_STEREO_EXACT = -1 never takes this path.
 #include <utility>
 
 #include "kernels.hpp"
 #include "stereo_exact.hpp"
+#include "stereo_float.hpp"
 
 namespace micv {
 
@@ -235,13 +236,23 @@ __host__ __device__ inline SxLds sx_lds_layout(int NG, int X, int WC, int nchunk
 #endif
 enum { SX_SSD = 0, SX_SERIAL = 1 };
 
-template <int R, int WC, int MODE>
+// The launch holds BOTH searches of the call: workgroups [0, nblk_exact) are exact-sum tiles, the ones behind them the float
+// kernel's tiles (stereo_float.hpp, RPW rows per wave) -- whichever the flag word does not select leave at once.  (As a
+// separate launch behind this one the float kernel's empty pass cost 4.7 us per call on 8-bit-valued pairs.)
+template <int R, int WC, int MODE, int RPW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MICV_SX_WAVES, MICV_SX_WAVES)))
-void stereo_exact_kernel(StereoExactArgs a) {
+void stereo_exact_kernel(StereoExactArgs a, StereoArgs f) {
     constexpr bool SERIAL = MODE == SX_SERIAL;
     constexpr int NG = sx_groups(R), P = WC - 1, RS = NG | 1, TS = 9;
     extern __shared__ uint32_t sx_lds[];
-    if (__builtin_nontemporal_load(a.flag) == a.epoch) return;  // not 8-bit-valued: the float kernel does this call
+    const bool float_images = __builtin_nontemporal_load(a.flag) == a.epoch;  // a pixel was not an integer in 0..255
+    if ((int)blockIdx.x >= a.nblk_exact) {
+        if (!float_images) return;
+        const int t = (int)blockIdx.x - a.nblk_exact;
+        stereo_tile<R, SERIAL ? ST_SSD_SERIAL : ST_SSD, RPW, ST_DCH_DEFAULT>(f, reinterpret_cast<float *>(sx_lds), t % a.fgx, t / a.fgx);
+        return;
+    }
+    if (float_images) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = blockIdx.x * 4 + wave;
@@ -435,11 +446,16 @@ void stereo_exact_kernel(StereoExactArgs a) {
     }
 }
 
-template <int R, int WC, int MODE>
-static int launch_search(hipStream_t s, const StereoExactArgs &a) {
+template <int R, int WC, int MODE, int RPW>
+static int launch_search(hipStream_t s, StereoExactArgs a, const StereoArgs &f) {
     const int nchunks = (a.max_d - a.min_d) / 64 + 1;
-    const size_t lds = 4 * (size_t)sx_lds_layout(sx_groups(R), a.X, WC, nchunks).words() * sizeof(uint32_t);
-    auto k = stereo_exact_kernel<R, WC, MODE>;
+    const size_t lds_exact = 4 * (size_t)sx_lds_layout(sx_groups(R), a.X, WC, nchunks).words() * sizeof(uint32_t);
+    const size_t lds_float = 4 * (size_t)(RPW + 2 * R) * (64 + ST_DCH_DEFAULT) * sizeof(float);
+    const size_t lds = lds_exact > lds_float ? lds_exact : lds_float;
+    a.nblk_exact = cdiv(a.ntiles, 4);
+    a.fgx = cdiv(a.cols, 64 - 2 * R);
+    const int nblk_float = a.fgx * (int)cdiv(a.rows, 4 * RPW);
+    auto k = stereo_exact_kernel<R, WC, MODE, RPW>;
     static size_t attr_set[16] = {0};  // per device: the launch may need more than 64 KB of dynamic LDS
     int dev = 0;
     MICV_HIP(hipGetDevice(&dev));
@@ -447,20 +463,20 @@ static int launch_search(hipStream_t s, const StereoExactArgs &a) {
         MICV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev < 16) attr_set[dev] = lds;
     }
-    k<<<cdiv(a.ntiles, 4), 256, lds, s>>>(a);
+    k<<<a.nblk_exact + nblk_float, 256, lds, s>>>(a, f);
     MICV_LAUNCH_CHECK();
     return MICV_OK;
 }
 
-template <int R>
-static int launch_r(hipStream_t s, const StereoExactArgs &a, bool serial) {
+template <int R, int RPW>
+static int launch_r(hipStream_t s, const StereoExactArgs &a, const StereoArgs &f, bool serial) {
     const int nstrips = cdiv(a.rows, SX_Y);
     stereo_prep_kernel<R><<<dim3(cdiv(a.qhi - a.qlo, 256 - (a.wcols - 1)), nstrips), 256, 0, s>>>(a);
     MICV_LAUNCH_CHECK();
     const bool full = a.wcols == 2 * R + 1;
-    if (serial) return full ? launch_search<R, 2 * R + 1, SX_SERIAL>(s, a) : MICV_EUNSUPPORTED;
-    if (full) return launch_search<R, 2 * R + 1, SX_SSD>(s, a);
-    return launch_search<R, 2 * R, SX_SSD>(s, a);
+    if (serial) return full ? launch_search<R, 2 * R + 1, SX_SERIAL, RPW>(s, a, f) : MICV_EUNSUPPORTED;
+    if (full) return launch_search<R, 2 * R + 1, SX_SSD, RPW>(s, a, f);
+    return launch_search<R, 2 * R, SX_SSD, RPW>(s, a, f);
 }
 
 }  // namespace
@@ -471,6 +487,9 @@ bool stereo_exact_covers(int rad, int flags, bool ncc) {
     // pixels -- built and bit-exact in r06 -- was slower than the float kernel on flat AND on textured 1080p pairs
     // (0.88 / 0.60 ms against 0.316; profiles/r06/stereo_exact.md)
     if (ncc) return false;
+    // ROLLING is a compatibility mode with a kernel of its own (on 8-bit-valued images it equals the fresh sums, so nothing is
+    // lost in results; its float fallback is not the tile the exact-sum launch carries)
+    if (flags & MICV_STEREO_ROLLING) return false;
     if (rad < 1 || rad > 7) return false;                       // (2r+1)^2 * 255^2 < 2^24
     if ((flags & MICV_STEREO_SERIAL) && rad > 5) return false;  // the invalid-position keys need a spare bit
     if ((flags & MICV_STEREO_COLS_2R) && rad < 2) return false;
@@ -528,7 +547,7 @@ size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, i
 
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
                         int stride, int rad, int min_d, int max_d, int flags, int wcols, int8_t *disp, int dstride,
-                        unsigned *flag, unsigned epoch, int wave_slots3) {
+                        unsigned *flag, unsigned epoch, int wave_slots3, const StereoArgs &f, bool rows10) {
     StereoExactArgs a;
     const int nstrips = cdiv(rows, SX_Y);
     a.left = left; a.right = right; a.stride = stride; a.rows = rows; a.cols = cols;
@@ -543,15 +562,12 @@ int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const f
     a.disp = disp; a.dstride = dstride;
     a.min_ssd_5e6 = (flags & MICV_STEREO_MIN_SSD_5E6) ? 1 : 0;
     const bool serial = flags & MICV_STEREO_SERIAL;
+#define MICV_SX_CASE(RR) \
+    case RR: return rows10 ? launch_r<RR, 10>(s, a, f, serial) : launch_r<RR, 8>(s, a, f, serial);
     switch (rad) {
-        case 1: return launch_r<1>(s, a, serial);
-        case 2: return launch_r<2>(s, a, serial);
-        case 3: return launch_r<3>(s, a, serial);
-        case 4: return launch_r<4>(s, a, serial);
-        case 5: return launch_r<5>(s, a, serial);
-        case 6: return launch_r<6>(s, a, serial);
-        case 7: return launch_r<7>(s, a, serial);
+        MICV_SX_CASE(1) MICV_SX_CASE(2) MICV_SX_CASE(3) MICV_SX_CASE(4) MICV_SX_CASE(5) MICV_SX_CASE(6) MICV_SX_CASE(7)
     }
+#undef MICV_SX_CASE
     return MICV_EUNSUPPORTED;
 }
 

@@ -1,6 +1,7 @@
 // stereo_exact.hpp -- the exact-sum stereo path for 8-bit-valued images (stereo_exact.hip), as stereo.hip sees it.
 #pragma once
 #include "common.hpp"
+#include "stereo_float.hpp"
 
 namespace micv {
 
@@ -21,14 +22,16 @@ struct StereoExactArgs {
     int dstride;
     int X, nxs, ntiles;  // output columns per wave, strips per row of strips, waves
     int min_ssd_5e6;
+    int nblk_exact, fgx;  // workgroups of exact-sum tiles in the launch; the float tiles behind them: fgx strips of columns per row of tiles
 };
 
 // Whether the exact path has a kernel for this call at all (radius, flags); the images decide on the device.
 bool stereo_exact_covers(int rad, int flags, bool ncc);
 size_t stereo_exact_scratch(int rows, int cols, int rad, int min_d, int max_d, int wcols, int flags, int wave_slots3);
-// Enqueues pre-pass + search (wave_slots3: waves the device holds at three per SIMD).  `scratch` holds stereo_exact_scratch() bytes.
+// Enqueues pre-pass + search (wave_slots3: waves the device holds at three per SIMD).  The search launch carries the
+// float kernel's tiles for the same call (`f`, 8 or 10 rows per wave) as trailing workgroups: nothing else to launch.  `scratch` holds stereo_exact_scratch() bytes.
 int stereo_exact_launch(hipStream_t s, void *scratch, const float *left, const float *right, int rows, int cols,
                         int stride, int rad, int min_d, int max_d, int flags, int wcols, int8_t *disp, int dstride,
-                        unsigned *flag, unsigned epoch, int wave_slots3);
+                        unsigned *flag, unsigned epoch, int wave_slots3, const StereoArgs &f, bool rows10);
 
 }  // namespace micv

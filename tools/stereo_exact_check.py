@@ -85,3 +85,13 @@ for rad in (5, 3, 7):
     f = min(timeit(lambda: stereo.disparitySSD(L, R, rad, -127, 0, ctx=fast)) for _ in range(3))
     s = min(timeit(lambda: stereo.disparitySSD(L, R, rad, -127, 0, ctx=slow)) for _ in range(3))
     print(json.dumps({"radius": rad, "ssd_exact_ms": round(f, 4), "ssd_float_ms": round(s, 4)}))
+# what a float pair costs with the exact-sum path enabled (pre-pass + the float tiles riding in the search launch) against the
+# float kernels alone
+fl = (left + 0.25).astype(np.float32)
+fr = (right + 0.25).astype(np.float32)
+FL, FR = torch.from_numpy(fl).cuda(), torch.from_numpy(fr).cuda()
+a = stereo.disparitySSD(FL, FR, 5, -127, 0, ctx=fast).cpu().numpy()
+b = stereo.disparitySSD(FL, FR, 5, -127, 0, ctx=slow).cpu().numpy()
+f = min(timeit(lambda: stereo.disparitySSD(FL, FR, 5, -127, 0, ctx=fast)) for _ in range(3))
+s = min(timeit(lambda: stereo.disparitySSD(FL, FR, 5, -127, 0, ctx=slow)) for _ in range(3))
+print(json.dumps({"float_pair_identical": bool(np.array_equal(a, b)), "with_prepass_ms": round(f, 4), "float_kernels_only_ms": round(s, 4)}))
