@@ -1,4 +1,4 @@
-// stereo_exact.hip -- ps2 window stereo on 8-bit-valued images (a12 / a13), the exact-sum kernels.
+// stereo_exact.hip -- ps2 window stereo on 8-bit-valued images (a12: disparitySSD), the exact-sum kernels.
 //
 // Every plain ps2 call hands over 8-bit images converted to CV_32F (ps2_cpp/src/main.cpp:87-88,115-117), and
 // serial::disparitySSD sums integers by definition (DisparitySSD.cpp:45-51).  When both images hold integers in
@@ -8,7 +8,7 @@
 //
 //   SSD(y, x, d) = A(y, x) + B(y, x + d) - 2 C(y, x, d)
 //     A = window sum of left^2, B = window sum of right^2 (one value per window POSITION, formed once per position
-//     by stereo_energy8_kernel -- the same sharing DisparityNCorr's energy field already uses), C = window sum of
+//     by the pre-pass -- the same sharing DisparityNCorr's energy field already uses), C = window sum of
 //     left * right.  A does not depend on d, so arg min_d SSD = arg max_d (2 C - B).
 //
 // Kernel shape (stereo_exact_kernel): LANES ARE DISPARITIES.  One wave64 owns 8 output rows x X output columns and
@@ -18,7 +18,7 @@
 // its LDS strip (consecutive lanes, conflict-free).  v_dot4_u32_u8 multiplies four rows and accumulates in one
 // instruction, so the 8 column sums of 2r + 1 rows cost 18 instructions (r = 5; rows outside a window are masked
 // in the scalar operand, shared runs of full words are formed once).  The window sum slides along x IN the lane:
-//   C += cs(x + 2r);  [use];  C -= cs(x)       (a ring of 2r column sums per row, statically indexed)
+//   C += cs(x + 2r);  [use];  C -= cs(x)       (a ring of 2r + 1 column sums per row, statically indexed)
 // -- no cross-lane traffic at all until the arg max, which is the one thing the lanes of a pixel share.  The key
 //   key = (2 C - B(x + d)) * 64 - (x_rel + lane)    = v_lshl_add_u32(C, 7, T[x_rel + lane]), T from the LDS strip
 // orders by cost, then by lane (lowest disparity wins ties: the contract's strict '<'), in one instruction; the
