@@ -4,6 +4,7 @@
 // by construction.  Device buffers are allocated per call like the reference's GpuMats.
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -261,7 +262,13 @@ int micv_lk_flow_seq_host(micv_ctx *ctx, const void *const *frames, int nframes,
     };
     // (ONE thread for both fields: two -- a stream and a thread per field -- measured slower, 0.48-0.52 against 0.45 ms
     // per pair: copies to pageable memory do not overlap each other either)
-    std::thread tu(download, 0);
+    std::thread tu;
+    try {
+        tu = std::thread(download, 0);
+    } catch (const std::exception &e) {  // (no thread to be had: nothing has been enqueued for it yet)
+        set_error("micv_lk_flow_seq_host: cannot start the download thread: %s", e.what());
+        return MICV_EHIP;
+    }
     struct Joiner {  // (declared after Scope: runs first -- the thread is gone before its stream is)
         std::thread &a; std::mutex &mu; std::condition_variable &cv; bool &stop;
         ~Joiner() {
